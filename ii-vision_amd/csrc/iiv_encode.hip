@@ -1,0 +1,962 @@
+// iiv_encode.hip -- video.Video.encode_frame on gfx950
+// (reference: transcoder/video.py:72-301, transcoder/screen.py:383-547).
+//
+// One workgroup per independent video stream; all stream state lives in HBM
+// (StreamState) between launches and in LDS inside one.
+//
+//   prologue_kernel (1024 threads / stream)           video.py:104-119, 254-271
+//     diff_weights of current screen vs target from the precomputed
+//     edit-distance table, hole masking, update_priority accumulation, nonce
+//     draw from the numpy MT19937 stream, 64-bit key sort -> `order[]`.
+//   greedy_kernel   (256 threads = one lane per page byte / stream)
+//                                                     video.py:121-187, 275-301
+//     pops `order[]` (then the pushed bag), scores every byte of the page
+//     against the popped content via the store table, ranks candidates with a
+//     ballot prefix + wave top-2 reduction, applies <=3 stores, emits one
+//     opcode per step.
+//
+// How the reference's heap is restated (proved equivalent on the CPU by
+// oracle/iiv_oracle.c:step_struct against the imported reference):
+//   * initial heap entries (-priority, nonce, page, offset) all have negative
+//     keys, re-queued entries have key 65536-p > 0 (np.uint16 negation wraps,
+//     video.py:178) => initial entries pop first, in sorted order;
+//   * a byte whose update_priority is 0 is never selected again inside one
+//     generator (video.py:130,159 skip it), so lazy deletion is permanent and
+//     validity only ever decays;
+//   * _compute_error's heap (video.py:290-301) only matters up to the first two
+//     entries whose priority is non-zero => top-2 of (delta, nonce, offset).
+// RNG: both global MT19937 streams are advanced on the device exactly as
+// random.getrandbits(8) (high byte) and np.random.randint(0,256,n) (low byte)
+// advance them (video.py:178,265,291).
+#include "iiv_host.h"
+
+#include <stdlib.h>
+#include <vector>
+
+namespace iiv {
+
+constexpr int kPushedCap = 16384;  // >= 2 pushes x 7680 non-hole bytes
+
+struct StreamState {
+    uint8_t mem[2][8192];     // [is_aux] Video.memory_map / aux_memory_map
+    int32_t up[2][8192];      // [is_aux] Video.update_priority / aux_update_priority
+    uint16_t dw[8192];        // diff_weights of the live generator
+    uint16_t order[8192];     // sorted initial entries: page << 8 | offset
+    uint32_t pushed[kPushedCap];  // (2047-p) << 21 | nonce << 13 | page << 8 | offset; ~0 = popped
+    uint32_t mt_py[624];      // random's MT19937 block
+    uint32_t mt_np[624];      // np.random's MT19937 block
+    int32_t mt_py_idx, mt_np_idx;
+    int32_t n_sorted, head, n_pushed, exhausted;
+    int32_t gen_active, gen_is_aux, gen_frame, error;
+    int32_t out_of_work[2];
+    int32_t pad_[2];
+    unsigned long long draws_py, draws_np, ops, pad_ops;
+};
+
+enum { kErrNone = 0, kErrHoles = 1, kErrNegative = 2, kErrPaletteBit = 3, kErrPushedOverflow = 4, kErrNoGenerator = 5, kErrGuard = 6 };
+
+// ------------------------------------------------------------------------- prologue
+
+constexpr int kProThreads = 1024;
+
+template <int MODE>
+__global__ __launch_bounds__(kProThreads) void prologue_kernel(StreamState *__restrict__ states,
+                                                               const uint8_t *__restrict__ frames_main,
+                                                               const uint8_t *__restrict__ frames_aux, int n_frames,
+                                                               int frame, int is_aux,
+                                                               const uint16_t *__restrict__ table)
+{
+    constexpr int BITS = ModeTraits<MODE>::kBits;
+    constexpr int NB = ModeTraits<MODE>::kBanks;
+    __shared__ __attribute__((aligned(16))) uint8_t cur[NB][8192];
+    __shared__ __attribute__((aligned(16))) uint8_t tgt[NB][8192];
+    __shared__ unsigned long long keys[8192];
+    __shared__ uint8_t nonce[8192];
+    __shared__ uint32_t mtb[2][624];
+    __shared__ uint32_t wsum[kProThreads / 64];
+    __shared__ int flag_bad;
+
+    const int tid = threadIdx.x;
+    StreamState &S = states[blockIdx.x];
+    const size_t fbase = ((size_t)blockIdx.x * n_frames + frame) * 8192;
+
+    if (tid == 0) flag_bad = 0;
+    // stage current screen and target memory maps (16 B per lane per load)
+    for (int i = tid; i < 512 * NB; i += kProThreads) {
+        int b = i >> 9, k = i & 511;
+        reinterpret_cast<uint4 *>(cur[b])[k] = reinterpret_cast<const uint4 *>(S.mem[b])[k];
+        const uint8_t *src = (b == 0 ? frames_main : frames_aux) + fbase;
+        reinterpret_cast<uint4 *>(tgt[b])[k] = reinterpret_cast<const uint4 *>(src)[k];
+    }
+    for (int i = tid; i < 624; i += kProThreads) mtb[0][i] = S.mt_np[i];
+    __syncthreads();
+
+    // 8 consecutive bytes of one page row per thread (row-major, as nonzero() walks them)
+    const int i0 = tid * 8;
+    const int page = i0 >> 8;
+    const int own_b = (MODE == kDHGR && is_aux) ? 1 : 0;
+    const uint8_t *cur_own = cur[own_b] + page * 256, *cur_oth = cur[NB - 1 - own_b] + page * 256;
+    const uint8_t *tgt_own = tgt[own_b] + page * 256, *tgt_oth = tgt[NB - 1 - own_b] + page * 256;
+
+    int32_t upv[8];
+    {
+        const int4 *p = reinterpret_cast<const int4 *>(S.up[is_aux] + i0);
+        int4 a = p[0], b = p[1];
+        upv[0] = a.x; upv[1] = a.y; upv[2] = a.z; upv[3] = a.w;
+        upv[4] = b.x; upv[5] = b.y; upv[6] = b.z; upv[7] = b.w;
+    }
+    uint32_t dwv[8];
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        int y = (i0 & 255) + j;
+        if (is_hole(y)) {
+            dwv[j] = 0;  // video.py:111
+            if (cur_own[y] != 0) bad = kErrHoles;  // video.py:87
+            continue;
+        }
+        int odd = y & 1;
+        int o = byte_offset<MODE>(y, is_aux);
+        uint32_t cp, cn, tp, tn;
+        neighbours<MODE>(cur_own, cur_oth, y, is_aux, cp, cn);
+        neighbours<MODE>(tgt_own, tgt_oth, y, is_aux, tp, tn);
+        uint32_t cm = masked_window<MODE>(cp, cur_own[y], cn, odd);
+        uint32_t tm = masked_window<MODE>(tp, tgt_own[y], tn, odd);
+        // screen.py:441-443: pair = (source << bits) + target
+        dwv[j] = table[((size_t)o << (2 * BITS)) + ((size_t)cm << BITS) + tm];
+    }
+    uint32_t nzmask = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        int32_t u = upv[j];
+        if (dwv[j] == 0) u = 0;  // video.py:115
+        u += (int32_t)dwv[j];    // video.py:116
+        if (u < 0) bad = kErrNegative;  // video.py:117
+        upv[j] = u;
+        if (u != 0) nzmask |= 1u << j;
+    }
+    {
+        int4 *p = reinterpret_cast<int4 *>(S.up[is_aux] + i0);
+        p[0] = make_int4(upv[0], upv[1], upv[2], upv[3]);
+        p[1] = make_int4(upv[4], upv[5], upv[6], upv[7]);
+        uint4 d;
+        d.x = dwv[0] | (dwv[1] << 16);
+        d.y = dwv[2] | (dwv[3] << 16);
+        d.z = dwv[4] | (dwv[5] << 16);
+        d.w = dwv[6] | (dwv[7] << 16);
+        *reinterpret_cast<uint4 *>(S.dw + i0) = d;
+    }
+    if (bad) flag_bad = bad;
+
+    // exclusive scan of per-thread non-zero counts (row-major rank of each entry)
+    const int cnt = __popc(nzmask);
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int v = __shfl_up(incl, d, 64);
+        if (lane_id() >= d) incl += v;
+    }
+    if (lane_id() == 63) wsum[tid >> 6] = (uint32_t)incl;
+    __syncthreads();
+    int wbase = 0, total = 0;
+    for (int w = 0; w < kProThreads / 64; w++) {
+        int v = (int)wsum[w];
+        if (w < (tid >> 6)) wbase += v;
+        total += v;
+    }
+    const int rank0 = wbase + incl - cnt;
+    const int n = total;
+
+    // n draws of np.random.randint(0, 256): low byte of the next n MT outputs (video.py:265)
+    int idx = S.mt_np_idx;
+    {
+        int cb = 0;
+        int first = idx;             // position of draw 0 inside block 0
+        int remaining = n;
+        int blk = 0;
+        while (true) {
+            // draws that live in block `blk`: global positions [blk*624, blk*624+624)
+            for (int w = tid; w < 624; w += kProThreads) {
+                int r = blk * 624 + w - first;
+                if (r >= 0 && r < n) nonce[r] = (uint8_t)(mt_temper(mtb[cb][w]) & 0xff);
+            }
+            int last_needed = first + n;  // one past the last global position
+            if (last_needed <= (blk + 1) * 624) break;
+            mt_twist<kProThreads>(mtb[cb], mtb[cb ^ 1], tid);
+            cb ^= 1;
+            blk++;
+        }
+        (void)remaining;
+        __syncthreads();
+        // persist the generator: block `cb` with index (first + n) - blk*624 in [0,624]
+        for (int w = tid; w < 624; w += kProThreads) S.mt_np[w] = mtb[cb][w];
+        if (tid == 0) {
+            S.mt_np_idx = first + n - blk * 624;
+            S.draws_np += (unsigned long long)n;
+        }
+    }
+
+    // keys (-priority, nonce, page, offset) -> ascending u64 (video.py:259-268)
+    {
+        int r = rank0;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (nzmask & (1u << j)) {
+                unsigned long long k = ((unsigned long long)(0x7fffffffu - (uint32_t)upv[j]) << 21) |
+                                       ((unsigned long long)nonce[r] << 13) | (unsigned long long)(i0 + j);
+                keys[r] = k;
+                r++;
+            }
+    }
+    int N = 64;
+    while (N < n) N <<= 1;
+    __syncthreads();
+    for (int i = n + tid; i < N; i += kProThreads) keys[i] = ~0ull;
+    __syncthreads();
+    // bitonic sort of N keys in LDS
+    for (int k = 2; k <= N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (N >> 1); t += kProThreads) {
+                int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                int hi = lo | j;
+                unsigned long long a = keys[lo], b = keys[hi];
+                bool asc = (lo & k) == 0;
+                if ((a > b) == asc) {
+                    keys[lo] = b;
+                    keys[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < n; i += kProThreads) S.order[i] = (uint16_t)(keys[i] & 0x1fff);
+    if (tid == 0) {
+        S.n_sorted = n;
+        S.head = 0;
+        S.n_pushed = 0;
+        S.exhausted = 0;
+        S.gen_active = 1;
+        S.gen_is_aux = is_aux;
+        S.gen_frame = frame;
+        if (flag_bad && S.error == 0) S.error = flag_bad;
+    }
+}
+
+// ------------------------------------------------------------------------- greedy
+
+constexpr int kChunk = 8;  // initial-list entries whose store-table rows are gathered together
+
+template <int MODE>
+__global__ __launch_bounds__(256) void greedy_kernel(StreamState *__restrict__ states,
+                                                     const uint8_t *__restrict__ frames_main,
+                                                     const uint8_t *__restrict__ frames_aux, int n_frames, int frame,
+                                                     int is_aux, int n_ops, const uint16_t *__restrict__ store,
+                                                     uint8_t *__restrict__ ops_out, size_t ops_stride,
+                                                     size_t ops_base)
+{
+    constexpr int BITS = ModeTraits<MODE>::kBits;
+    constexpr int CB = ModeTraits<MODE>::kContentBits;
+    constexpr int NB = ModeTraits<MODE>::kBanks;
+    constexpr uint32_t INF = 0xffffffffu;
+    __shared__ __attribute__((aligned(16))) uint8_t tgt[NB][8192];  // [0] = bank being encoded, [1] = the other one
+    __shared__ __attribute__((aligned(16))) uint16_t dwf[8192];     // diff_weight | (priority != 0) << 15
+    __shared__ __attribute__((aligned(16))) uint16_t order[8192];
+    __shared__ uint32_t mt[2][624];
+    __shared__ uint32_t xw_cnt[4];
+    __shared__ uint32_t xw_key[8];
+    __shared__ unsigned long long xw_pop[4];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    StreamState &S = states[blockIdx.x];
+    const size_t fbase = ((size_t)blockIdx.x * n_frames + frame) * 8192;
+    uint8_t *out = ops_out + (size_t)blockIdx.x * ops_stride + ops_base;
+
+    if (!S.gen_active || S.error) {
+        if (tid == 0 && !S.error) S.error = kErrNoGenerator;
+        return;
+    }
+
+    // ---- stage target bytes, diff weights + validity flags, sorted order, RNG block
+    for (int i = tid; i < 512 * NB; i += 256) {
+        int b = i >> 9, k = i & 511;
+        const uint8_t *src;
+        if (MODE == kDHGR)
+            src = ((b == 0) == (is_aux != 0) ? frames_aux : frames_main) + fbase;
+        else
+            src = frames_main + fbase;
+        reinterpret_cast<uint4 *>(tgt[b])[k] = reinterpret_cast<const uint4 *>(src)[k];
+    }
+    for (int i = tid; i < 1024; i += 256) {
+        uint4 d = reinterpret_cast<const uint4 *>(S.dw)[i];
+        const int4 *up = reinterpret_cast<const int4 *>(S.up[is_aux] + i * 8);
+        int4 u0 = up[0], u1 = up[1];
+        d.x |= (u0.x ? 0x8000u : 0u) | (u0.y ? 0x80000000u : 0u);
+        d.y |= (u0.z ? 0x8000u : 0u) | (u0.w ? 0x80000000u : 0u);
+        d.z |= (u1.x ? 0x8000u : 0u) | (u1.y ? 0x80000000u : 0u);
+        d.w |= (u1.z ? 0x8000u : 0u) | (u1.w ? 0x80000000u : 0u);
+        reinterpret_cast<uint4 *>(dwf)[i] = d;
+        reinterpret_cast<uint4 *>(order)[i] = reinterpret_cast<const uint4 *>(S.order)[i];
+    }
+    for (int i = tid; i < 624; i += 256) mt[0][i] = S.mt_py[i];
+    __syncthreads();
+    int cb = 0;  // mt[cb] = current block, mt[cb^1] = the block after it
+    mt_twist<256>(mt[0], mt[1], tid);
+    int mt_idx = S.mt_py_idx;
+    if (mt_idx >= 624) {
+        mt_twist<256>(mt[1], mt[0], tid);
+        cb = 1;
+        mt_idx -= 624;
+    }
+
+    const int n_sorted = S.n_sorted;
+    int head = S.head, n_pushed = S.n_pushed, exhausted = S.exhausted;
+    int done = 0, err = 0;
+    unsigned long long draws = 0, pad_ops = 0;
+    const int y = tid;
+    const int odd = y & 1;
+    const int o = byte_offset<MODE>(y, is_aux);
+    const uint16_t *store_o = store + ((size_t)o << (CB + BITS));
+
+    // every iteration either emits an opcode, skips >= 1 list entry or pops a pushed
+    // entry, so this bound is never reached; it turns a logic error into an error
+    // code instead of a hung GPU.
+    int guard = n_ops + 8192 + 2 * kPushedCap + 64;
+    while (done < n_ops && !err) {
+        if (--guard < 0) {
+            err = kErrGuard;
+            break;
+        }
+        if (exhausted) {
+            // video.py:249-251: pad forever with (32, target[0,0], [0,0,0,0])
+            uint32_t c0 = tgt[0][0];
+            for (int i = done + tid; i < n_ops; i += 256) {
+                uint8_t *q = out + (size_t)i * 6;
+                q[0] = 32; q[1] = (uint8_t)c0; q[2] = 0; q[3] = 0; q[4] = 0; q[5] = 0;
+            }
+            pad_ops += (unsigned long long)(n_ops - done);
+            done = n_ops;
+            break;
+        }
+
+        // ---- form a chunk of entries (uniform across the workgroup)
+        uint32_t ent[kChunk];
+        int pos[kChunk];
+        int cnt = 0, chunk_end = head;
+        bool from_pushed = false;
+        __syncthreads();  // validity flags written by their owner lanes -> visible to the scan
+        if (head < n_sorted) {
+            int idx = head + lane;
+            uint32_t e = idx < n_sorted ? (uint32_t)order[idx] : 0u;
+            bool v = idx < n_sorted && (dwf[e] & 0x8000u);
+            unsigned long long mask = __ballot(v);
+            int window_end = head + 64 < n_sorted ? head + 64 : n_sorted;
+            if (mask == 0) {
+                head = window_end;
+                continue;
+            }
+#pragma unroll
+            for (int m = 0; m < kChunk; m++) {
+                ent[m] = 0;
+                pos[m] = 0;
+                if (mask) {
+                    int l = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    ent[m] = __builtin_amdgcn_readlane(e, l);
+                    pos[m] = head + l;
+                    cnt = m + 1;
+                }
+            }
+            chunk_end = mask ? pos[kChunk - 1] + 1 : window_end;
+        } else {
+            // pop-min over the pushed bag
+            from_pushed = true;
+            unsigned long long best = ~0ull;
+            for (int i = tid; i < n_pushed; i += 256) {
+                unsigned long long k = ((unsigned long long)S.pushed[i] << 32) | (unsigned)i;
+                best = k < best ? k : best;
+            }
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                unsigned long long other = __shfl_xor(best, d, 64);
+                best = other < best ? other : best;
+            }
+            if (lane == 0) xw_pop[wave] = best;
+            __syncthreads();
+            best = xw_pop[0];
+            for (int w = 1; w < 4; w++) best = xw_pop[w] < best ? xw_pop[w] : best;
+            uint32_t bk = (uint32_t)(best >> 32);
+            if (bk == INF) {
+                exhausted = 1;  // video.py:189
+                continue;
+            }
+            if (tid == 0) S.pushed[(uint32_t)best] = INF;
+#pragma unroll
+            for (int m = 0; m < kChunk; m++) {
+                ent[m] = 0;
+                pos[m] = 0;
+            }
+            ent[0] = bk & 0x1fff;
+            cnt = 1;
+            if (!(dwf[ent[0]] & 0x8000u)) continue;  // video.py:130
+        }
+
+        // ---- gather the store-table row of every chunk entry (all in flight together)
+        uint32_t ndv[kChunk];
+#pragma unroll
+        for (int m = 0; m < kChunk; m++) {
+            ndv[m] = 0;
+            if (m < cnt) {
+                int p = ent[m] >> 8;
+                uint32_t c = tgt[0][ent[m]];
+                const uint8_t *own_row = tgt[0] + p * 256;
+                const uint8_t *oth_row = tgt[NB - 1] + p * 256;
+                uint32_t pv, nx;
+                neighbours<MODE>(own_row, oth_row, y, is_aux, pv, nx);
+                uint32_t win = masked_window<MODE>(pv, own_row[y], nx, odd);
+                ndv[m] = store_o[((size_t)(c & ((1u << CB) - 1)) << BITS) + win];
+            }
+        }
+
+        // ---- process the chunk sequentially
+        uint32_t dead = 0;
+#pragma unroll
+        for (int m = 0; m < kChunk; m++) {
+            if (m >= cnt || done >= n_ops || err) break;
+            if (dead & (1u << m)) {
+                head = pos[m] + 1;
+                continue;
+            }
+            const int p = ent[m] >> 8, x = ent[m] & 255;
+            const uint32_t c = tgt[0][ent[m]];  // video.py:134
+            if (MODE == kDHGR && c >= 0x80) {   // video.py:137
+                err = kErrPaletteBit;
+                break;
+            }
+            const uint32_t nd = ndv[m];
+            const uint32_t w = dwf[p * 256 + y];
+            const uint32_t dwy = (y == x) ? 0u : (w & 0x7fffu);       // video.py:141
+            const bool nzy = (w & 0x8000u) && (y != x);               // video.py:140
+            const int d = (int)nd - (int)dwy;                         // screen.py:547
+            const bool cand = d < 0;                                  // video.py:283
+            const unsigned long long bal = __ballot(cand);
+            if (lane == 0) xw_cnt[wave] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            const uint32_t c0 = xw_cnt[0], c1 = xw_cnt[1], c2 = xw_cnt[2], c3 = xw_cnt[3];
+            const int C = (int)(c0 + c1 + c2 + c3);
+            const int wbase = (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
+            uint32_t key = INF;
+            if (cand) {
+                // one random.getrandbits(8) per candidate, ascending offset (video.py:290-293)
+                int j = mt_idx + wbase + prefix_popc(bal);
+                uint32_t word = j < 624 ? mt[cb][j] : mt[cb ^ 1][j - 624];
+                uint32_t nonce = mt_temper(word) >> 24;
+                if (nzy)  // video.py:159
+                    key = ((uint32_t)(d + 2048) << 17) | (nonce << 9) | ((uint32_t)y << 1) | (nd != 0 ? 1u : 0u);
+            }
+            uint32_t k1 = key, k2 = INF;
+#pragma unroll
+            for (int s = 1; s < 64; s <<= 1) {
+                uint32_t o1 = __shfl_xor(k1, s, 64), o2 = __shfl_xor(k2, s, 64);
+                uint32_t lo = k1 < o1 ? k1 : o1, hi = k1 < o1 ? o1 : k1;
+                uint32_t m2 = k2 < o2 ? k2 : o2;
+                k1 = lo;
+                k2 = hi < m2 ? hi : m2;
+            }
+            if (lane == 0) {
+                xw_key[2 * wave] = k1;
+                xw_key[2 * wave + 1] = k2;
+            }
+            __syncthreads();
+            uint32_t K1 = INF, K2 = INF;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                uint32_t k = xw_key[q];
+                if (k < K1) {
+                    K2 = K1;
+                    K1 = k;
+                } else if (k < K2) {
+                    K2 = k;
+                }
+            }
+            const int y1 = K1 != INF ? (int)((K1 >> 1) & 255) : -1;
+            const int f1 = K1 != INF ? (int)(K1 & 1) : 0;
+            const int y2 = K2 != INF ? (int)((K2 >> 1) & 255) : -1;
+            const int f2 = K2 != INF ? (int)(K2 & 1) : 0;
+            if (n_pushed + f1 + f2 > kPushedCap) {
+                err = kErrPushedOverflow;
+                break;
+            }
+
+            // ---- apply (video.py:140-144, 170-178; screen.py:256-293)
+            if (y == x) {
+                dwf[p * 256 + x] = 0;
+                S.up[is_aux][p * 256 + x] = 0;
+                S.mem[is_aux][p * 256 + x] = (uint8_t)c;
+            }
+            if (y == y1 || y == y2) {
+                const int second = (y == y2) ? 1 : 0;
+                S.up[is_aux][p * 256 + y] = (int32_t)nd;  // byte_pair_difference == nd[y] (screen.py:383-398)
+                S.mem[is_aux][p * 256 + y] = (uint8_t)c;
+                dwf[p * 256 + y] = (uint16_t)((w & 0x7fffu) | (nd ? 0x8000u : 0u));
+                if (nd) {
+                    int j = mt_idx + C + (second ? f1 : 0);
+                    uint32_t word = j < 624 ? mt[cb][j] : mt[cb ^ 1][j - 624];
+                    uint32_t nonce = mt_temper(word) >> 24;  // video.py:178
+                    S.pushed[n_pushed + (second ? f1 : 0)] =
+                        ((2047u - nd) << 21) | (nonce << 13) | ((uint32_t)p << 8) | (uint32_t)y;
+                }
+            }
+            if (tid == 0) {
+                uint8_t *q = out + (size_t)done * 6;
+                q[0] = (uint8_t)(p + 32);
+                q[1] = (uint8_t)c;
+                q[2] = (uint8_t)x;
+                q[3] = (uint8_t)(y1 >= 0 ? y1 : x);  // video.py:185-186
+                q[4] = (uint8_t)(y2 >= 0 ? y2 : x);
+                q[5] = (uint8_t)x;
+            }
+            // later chunk entries that this step resolved exactly are now dead
+#pragma unroll
+            for (int m2 = 0; m2 < kChunk; m2++)
+                if (m2 > m && m2 < cnt) {
+                    if (y1 >= 0 && !f1 && ent[m2] == (uint32_t)((p << 8) | y1)) dead |= 1u << m2;
+                    if (y2 >= 0 && !f2 && ent[m2] == (uint32_t)((p << 8) | y2)) dead |= 1u << m2;
+                }
+            mt_idx += C + f1 + f2;
+            draws += (unsigned long long)(C + f1 + f2);
+            n_pushed += f1 + f2;
+            done++;
+            if (!from_pushed) head = pos[m] + 1;
+            if (mt_idx >= 624) {
+                __syncthreads();  // every lane is done with block cb
+                mt_twist<256>(mt[cb ^ 1], mt[cb], tid);
+                cb ^= 1;
+                mt_idx -= 624;
+            }
+        }
+        if (!from_pushed && !err && done < n_ops) head = chunk_end > head ? chunk_end : head;
+    }
+
+    // ---- write the generator back
+    __syncthreads();
+    for (int i = tid; i < 1024; i += 256) {
+        uint4 d = reinterpret_cast<const uint4 *>(dwf)[i];
+        d.x &= 0x7fff7fffu; d.y &= 0x7fff7fffu; d.z &= 0x7fff7fffu; d.w &= 0x7fff7fffu;
+        reinterpret_cast<uint4 *>(S.dw)[i] = d;
+    }
+    for (int i = tid; i < 624; i += 256) S.mt_py[i] = mt[cb][i];
+    if (tid == 0) {
+        S.mt_py_idx = mt_idx;
+        S.head = head;
+        S.n_pushed = n_pushed;
+        S.exhausted = exhausted;
+        if (exhausted) S.out_of_work[is_aux] = 1;
+        S.draws_py += draws;
+        S.ops += (unsigned long long)done;
+        S.pad_ops += pad_ops;
+        if (err && S.error == 0) S.error = err;
+    }
+}
+
+// stand-alone packed view of the current screen for IIV_STATE_PACKED: reuse iiv_bitmap's pack
+
+// ------------------------------------------------------------------------- host object
+
+struct Encoder {
+    int mode;
+    int n_streams;
+    const uint16_t *d_table;
+    const uint16_t *d_store;
+    StreamState *d_states;
+    // generator bookkeeping shared by all streams (same schedule)
+    int gen_active, gen_is_aux, gen_frame;
+    // profiling
+    int profiling;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<int> ev_class;  // class of interval i = events [2i, 2i+1]
+    double ms[2];
+    int64_t launches[2];
+};
+
+static void seed_by_array(uint32_t mt[624], const uint32_t *key, int n)
+{
+    mt[0] = 19650218u;
+    for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    int i = 1, j = 0;
+    for (int k = 624 > n ? 624 : n; k; k--) {
+        mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+        i++; j++;
+        if (i >= 624) { mt[0] = mt[623]; i = 1; }
+        if (j >= n) j = 0;
+    }
+    for (int k = 623; k; k--) {
+        mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+        i++;
+        if (i >= 624) { mt[0] = mt[623]; i = 1; }
+    }
+    mt[0] = 0x80000000u;
+}
+
+static void seed_genrand(uint32_t mt[624], uint32_t s)
+{
+    mt[0] = s;
+    for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+}
+
+int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, int n_streams, Encoder **out)
+{
+    if ((mode != kHGR && mode != kDHGR) || !d_table || !d_store || n_streams <= 0 || !out)
+        return set_error(IIV_ERR_INVALID, "iiv_encoder_create: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return set_error(IIV_ERR_NO_DEVICE, "iiv_encoder_create: no HIP device");
+    Encoder *e = new Encoder();
+    e->mode = mode;
+    e->n_streams = n_streams;
+    e->d_table = d_table;
+    e->d_store = d_store;
+    e->d_states = nullptr;
+    e->gen_active = 0;
+    e->gen_is_aux = 0;
+    e->gen_frame = 0;
+    e->profiling = 0;
+    e->ms[0] = e->ms[1] = 0;
+    e->launches[0] = e->launches[1] = 0;
+    hipError_t he = hipMalloc(&e->d_states, sizeof(StreamState) * (size_t)n_streams);
+    if (he != hipSuccess) {
+        delete e;
+        return hip_check(he, "hipMalloc(stream states)");
+    }
+    // Video.__init__ (video.py:21-62): blank screen, zero priorities.  RNG
+    // streams default to random.seed(0) / np.random.seed(0).
+    StreamState *h = (StreamState *)calloc(1, sizeof(StreamState));
+    uint32_t key0 = 0;
+    seed_by_array(h->mt_py, &key0, 1);
+    h->mt_py_idx = 624;
+    seed_genrand(h->mt_np, 0);
+    h->mt_np_idx = 624;
+    int rc = IIV_OK;
+    for (int s = 0; s < n_streams && !rc; s++)
+        rc = hip_check(hipMemcpy(e->d_states + s, h, sizeof(StreamState), hipMemcpyHostToDevice), "init state");
+    free(h);
+    if (rc) {
+        (void)hipFree(e->d_states);
+        delete e;
+        return rc;
+    }
+    *out = e;
+    return IIV_OK;
+}
+
+void encoder_destroy(Encoder *e)
+{
+    if (!e) return;
+    for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
+    if (e->d_states) (void)hipFree(e->d_states);
+    delete e;
+}
+
+static int state_item(int mode, int what, size_t &off, size_t &bytes, bool &writable)
+{
+    writable = true;
+    switch (what) {
+    case IIV_STATE_MEM_MAIN: off = offsetof(StreamState, mem[0]); bytes = 8192; return 0;
+    case IIV_STATE_MEM_AUX:
+        if (mode != kDHGR) return -1;
+        off = offsetof(StreamState, mem[1]); bytes = 8192; return 0;
+    case IIV_STATE_UP_MAIN: off = offsetof(StreamState, up[0]); bytes = 8192 * 4; return 0;
+    case IIV_STATE_UP_AUX:
+        if (mode != kDHGR) return -1;
+        off = offsetof(StreamState, up[1]); bytes = 8192 * 4; return 0;
+    case IIV_STATE_OUT_OF_WORK: off = offsetof(StreamState, out_of_work); bytes = 8; return 0;
+    case IIV_STATE_COUNTERS: off = offsetof(StreamState, draws_py); bytes = 32; writable = false; return 0;
+    default: return -1;
+    }
+}
+
+int encoder_get_state(Encoder *e, int s, int what, void *buf, size_t bytes)
+{
+    if (!e || !buf || s < 0 || s >= e->n_streams) return set_error(IIV_ERR_INVALID, "get_state: bad argument");
+    IIV_HIP(hipDeviceSynchronize());
+    uint8_t *base = reinterpret_cast<uint8_t *>(e->d_states + s);
+    if (what == IIV_STATE_RNG_PY || what == IIV_STATE_RNG_NP) {
+        if (bytes != 625 * 4) return set_error(IIV_ERR_INVALID, "get_state: RNG state is 625 u32");
+        size_t o_mt = what == IIV_STATE_RNG_PY ? offsetof(StreamState, mt_py) : offsetof(StreamState, mt_np);
+        size_t o_ix = what == IIV_STATE_RNG_PY ? offsetof(StreamState, mt_py_idx) : offsetof(StreamState, mt_np_idx);
+        IIV_HIP(hipMemcpy(buf, base + o_mt, 624 * 4, hipMemcpyDeviceToHost));
+        IIV_HIP(hipMemcpy((uint8_t *)buf + 624 * 4, base + o_ix, 4, hipMemcpyDeviceToHost));
+        return IIV_OK;
+    }
+    if (what == IIV_STATE_PACKED) {
+        if (bytes != 4096 * 8) return set_error(IIV_ERR_INVALID, "get_state: packed is 32x128 u64");
+        uint64_t *d_p = nullptr;
+        IIV_HIP(hipMalloc(&d_p, 4096 * 8));
+        int rc = pack(e->mode, 1, base + offsetof(StreamState, mem[0]), base + offsetof(StreamState, mem[1]), d_p, 0);
+        if (!rc) rc = hip_check(hipMemcpy(buf, d_p, 4096 * 8, hipMemcpyDeviceToHost), "copy packed");
+        (void)hipFree(d_p);
+        return rc;
+    }
+    size_t off, want;
+    bool writable;
+    if (state_item(e->mode, what, off, want, writable)) return set_error(IIV_ERR_INVALID, "get_state: unknown item %d", what);
+    if (bytes != want) return set_error(IIV_ERR_INVALID, "get_state: item %d is %zu bytes, got %zu", what, want, bytes);
+    IIV_HIP(hipMemcpy(buf, base + off, bytes, hipMemcpyDeviceToHost));
+    return IIV_OK;
+}
+
+int encoder_set_state(Encoder *e, int s, int what, const void *buf, size_t bytes)
+{
+    if (!e || !buf || s < 0 || s >= e->n_streams) return set_error(IIV_ERR_INVALID, "set_state: bad argument");
+    IIV_HIP(hipDeviceSynchronize());
+    uint8_t *base = reinterpret_cast<uint8_t *>(e->d_states + s);
+    if (what == IIV_STATE_RNG_PY || what == IIV_STATE_RNG_NP) {
+        if (bytes != 625 * 4) return set_error(IIV_ERR_INVALID, "set_state: RNG state is 625 u32");
+        uint32_t idx = ((const uint32_t *)buf)[624];
+        if (idx > 624) return set_error(IIV_ERR_INVALID, "set_state: RNG index %u > 624", idx);
+        size_t o_mt = what == IIV_STATE_RNG_PY ? offsetof(StreamState, mt_py) : offsetof(StreamState, mt_np);
+        size_t o_ix = what == IIV_STATE_RNG_PY ? offsetof(StreamState, mt_py_idx) : offsetof(StreamState, mt_np_idx);
+        IIV_HIP(hipMemcpy(base + o_mt, buf, 624 * 4, hipMemcpyHostToDevice));
+        IIV_HIP(hipMemcpy(base + o_ix, (const uint8_t *)buf + 624 * 4, 4, hipMemcpyHostToDevice));
+        return IIV_OK;
+    }
+    size_t off, want;
+    bool writable;
+    if (state_item(e->mode, what, off, want, writable) || !writable)
+        return set_error(IIV_ERR_INVALID, "set_state: item %d is not settable", what);
+    if (bytes != want) return set_error(IIV_ERR_INVALID, "set_state: item %d is %zu bytes, got %zu", what, want, bytes);
+    IIV_HIP(hipMemcpy(base + off, buf, bytes, hipMemcpyHostToDevice));
+    return IIV_OK;
+}
+
+static int prof_begin(Encoder *e, int cls, hipStream_t st, size_t &slot)
+{
+    slot = e->ev_class.size();
+    if (e->ev_pool.size() < 2 * (slot + 1)) {
+        hipEvent_t a, b;
+        IIV_HIP(hipEventCreate(&a));
+        IIV_HIP(hipEventCreate(&b));
+        e->ev_pool.push_back(a);
+        e->ev_pool.push_back(b);
+    }
+    e->ev_class.push_back(cls);
+    IIV_HIP(hipEventRecord(e->ev_pool[2 * slot], st));
+    return IIV_OK;
+}
+
+static int prof_end(Encoder *e, size_t slot, hipStream_t st)
+{
+    IIV_HIP(hipEventRecord(e->ev_pool[2 * slot + 1], st));
+    return IIV_OK;
+}
+
+static int prof_flush(Encoder *e)
+{
+    for (size_t i = 0; i < e->ev_class.size(); i++) {
+        IIV_HIP(hipEventSynchronize(e->ev_pool[2 * i + 1]));
+        float ms = 0;
+        IIV_HIP(hipEventElapsedTime(&ms, e->ev_pool[2 * i], e->ev_pool[2 * i + 1]));
+        e->ms[e->ev_class[i]] += ms;
+        e->launches[e->ev_class[i]] += 1;
+    }
+    e->ev_class.clear();
+    return IIV_OK;
+}
+
+int encoder_profile(Encoder *e, int enable)
+{
+    if (!e) return set_error(IIV_ERR_INVALID, "profile: null encoder");
+    e->profiling = enable ? 1 : 0;
+    if (enable) {
+        e->ev_class.clear();
+        e->ms[0] = e->ms[1] = 0;
+        e->launches[0] = e->launches[1] = 0;
+    }
+    return IIV_OK;
+}
+
+int encoder_profile_read(Encoder *e, double ms[2], int64_t launches[2])
+{
+    if (!e) return set_error(IIV_ERR_INVALID, "profile_read: null encoder");
+    int rc = prof_flush(e);
+    if (rc) return rc;
+    ms[0] = e->ms[0];
+    ms[1] = e->ms[1];
+    launches[0] = e->launches[0];
+    launches[1] = e->launches[1];
+    return IIV_OK;
+}
+
+int encode(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux, int n_frames, const iiv_segment *segs, int n_segs,
+           uint8_t *d_ops, hipStream_t st)
+{
+    if (!e || !d_main || !segs || n_segs < 0 || n_frames <= 0 || (!d_ops && n_segs > 0))
+        return set_error(IIV_ERR_INVALID, "iiv_encode: bad argument");
+    if (e->mode == kDHGR && !d_aux) return set_error(IIV_ERR_INVALID, "iiv_encode: DHGR needs aux frames");
+    size_t total = 0;
+    for (int i = 0; i < n_segs; i++) {
+        const iiv_segment &g = segs[i];
+        if (g.n_ops < 0 || g.frame < 0 || g.frame >= n_frames || (g.is_aux != 0 && g.is_aux != 1) ||
+            (e->mode == kHGR && g.is_aux))
+            return set_error(IIV_ERR_INVALID, "iiv_encode: bad segment %d", i);
+        total += (size_t)g.n_ops;
+    }
+    const size_t stride = total * 6;
+    size_t done = 0;
+    for (int i = 0; i < n_segs; i++) {
+        const iiv_segment &g = segs[i];
+        if (g.n_ops == 0) {
+            // encode_frame() only creates a lazy generator (video.py:72-93): remember
+            // it, run nothing.  A later restart == 0 segment will start it.
+            if (g.restart) {
+                e->gen_active = 2;  // created, prologue pending
+                e->gen_is_aux = g.is_aux;
+                e->gen_frame = g.frame;
+            }
+            continue;
+        }
+        bool need_prologue = g.restart != 0;
+        if (!g.restart) {
+            if (!e->gen_active) return set_error(IIV_ERR_INVALID, "iiv_encode: segment %d continues no generator", i);
+            if (e->gen_is_aux != g.is_aux || e->gen_frame != g.frame)
+                return set_error(IIV_ERR_INVALID, "iiv_encode: segment %d continues a different target/bank", i);
+            if (e->gen_active == 2) need_prologue = true;
+        }
+        size_t slot = 0;
+        if (need_prologue) {
+            if (e->profiling) { int prc = prof_begin(e, 0, st, slot); if (prc) return prc; }
+            if (e->mode == kDHGR)
+                hipLaunchKernelGGL(prologue_kernel<kDHGR>, dim3(e->n_streams), dim3(kProThreads), 0, st, e->d_states,
+                                   d_main, d_aux, n_frames, g.frame, g.is_aux, e->d_table);
+            else
+                hipLaunchKernelGGL(prologue_kernel<kHGR>, dim3(e->n_streams), dim3(kProThreads), 0, st, e->d_states,
+                                   d_main, d_aux, n_frames, g.frame, g.is_aux, e->d_table);
+            IIV_HIP(hipGetLastError());
+            if (e->profiling) { int prc = prof_end(e, slot, st); if (prc) return prc; }
+        }
+        e->gen_active = 1;
+        e->gen_is_aux = g.is_aux;
+        e->gen_frame = g.frame;
+        if (e->profiling) { int prc = prof_begin(e, 1, st, slot); if (prc) return prc; }
+        if (e->mode == kDHGR)
+            hipLaunchKernelGGL(greedy_kernel<kDHGR>, dim3(e->n_streams), dim3(256), 0, st, e->d_states, d_main, d_aux,
+                               n_frames, g.frame, g.is_aux, g.n_ops, e->d_store, d_ops, stride, done * 6);
+        else
+            hipLaunchKernelGGL(greedy_kernel<kHGR>, dim3(e->n_streams), dim3(256), 0, st, e->d_states, d_main, d_aux,
+                               n_frames, g.frame, g.is_aux, g.n_ops, e->d_store, d_ops, stride, done * 6);
+        IIV_HIP(hipGetLastError());
+        if (e->profiling) { int prc = prof_end(e, slot, st); if (prc) return prc; }
+        done += (size_t)g.n_ops;
+    }
+    return IIV_OK;
+}
+
+__global__ void error_scan_kernel(const StreamState *states, int n, int *result)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && states[i].error) {
+        atomicMin(&result[0], i);
+    }
+}
+
+int encoder_check(Encoder *e, int *bad_stream, hipStream_t st)
+{
+    if (!e) return set_error(IIV_ERR_INVALID, "check: null encoder");
+    int *d_res = nullptr;
+    IIV_HIP(hipMalloc(&d_res, sizeof(int)));
+    int init = 0x7fffffff;
+    int rc = hip_check(hipMemcpyAsync(d_res, &init, sizeof(int), hipMemcpyHostToDevice, st), "check init");
+    if (!rc) {
+        hipLaunchKernelGGL(error_scan_kernel, dim3((e->n_streams + 255) / 256), dim3(256), 0, st, e->d_states,
+                           e->n_streams, d_res);
+        rc = hip_check(hipGetLastError(), "error_scan launch");
+    }
+    int first = 0x7fffffff;
+    if (!rc) rc = hip_check(hipMemcpyAsync(&first, d_res, sizeof(int), hipMemcpyDeviceToHost, st), "check read");
+    if (!rc) rc = hip_check(hipStreamSynchronize(st), "check sync");
+    (void)hipFree(d_res);
+    if (rc) return rc;
+    if (first == 0x7fffffff) return IIV_OK;
+    if (bad_stream) *bad_stream = first;
+    int32_t code = 0;
+    IIV_HIP(hipMemcpy(&code, reinterpret_cast<uint8_t *>(e->d_states + first) + offsetof(StreamState, error), 4,
+                      hipMemcpyDeviceToHost));
+    static const char *names[] = {"",
+                                  "memory map has non-zero screen-hole bytes (video.py:87)",
+                                  "negative update_priority (video.py:117)",
+                                  "DHGR content byte has the palette bit set (video.py:137)",
+                                  "pushed-entry capacity exceeded",
+                                  "next() on a stream with no generator",
+                                  "internal: greedy loop guard tripped"};
+    int is_overflow = code == kErrPushedOverflow;
+    return set_error(is_overflow ? IIV_ERR_OVERFLOW : IIV_ERR_ASSERT, "stream %d: %s", first,
+                     (code > 0 && code < 7) ? names[code] : "unknown error");
+}
+
+}  // namespace iiv
+
+// ------------------------------------------------------------------------- C ABI
+
+struct iiv_encoder {
+    iiv::Encoder *impl;
+};
+
+extern "C" {
+
+int iiv_encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store_table, int n_streams,
+                       iiv_encoder **out)
+{
+    if (!out) return iiv::set_error(IIV_ERR_INVALID, "iiv_encoder_create: out is NULL");
+    iiv::Encoder *impl = nullptr;
+    int rc = iiv::encoder_create(mode, d_table, d_store_table, n_streams, &impl);
+    if (rc) return rc;
+    *out = new iiv_encoder{impl};
+    return IIV_OK;
+}
+
+void iiv_encoder_destroy(iiv_encoder *enc)
+{
+    if (!enc) return;
+    iiv::encoder_destroy(enc->impl);
+    delete enc;
+}
+
+int iiv_encoder_get_state(iiv_encoder *enc, int stream_index, int what, void *host_buf, size_t bytes)
+{
+    if (!enc) return iiv::set_error(IIV_ERR_INVALID, "null encoder");
+    return iiv::encoder_get_state(enc->impl, stream_index, what, host_buf, bytes);
+}
+
+int iiv_encoder_set_state(iiv_encoder *enc, int stream_index, int what, const void *host_buf, size_t bytes)
+{
+    if (!enc) return iiv::set_error(IIV_ERR_INVALID, "null encoder");
+    return iiv::encoder_set_state(enc->impl, stream_index, what, host_buf, bytes);
+}
+
+int iiv_encode(iiv_encoder *enc, const uint8_t *d_frames_main, const uint8_t *d_frames_aux, int n_frames,
+               const iiv_segment *segments, int n_segments, uint8_t *d_ops_out, void *stream)
+{
+    if (!enc) return iiv::set_error(IIV_ERR_INVALID, "null encoder");
+    return iiv::encode(enc->impl, d_frames_main, d_frames_aux, n_frames, segments, n_segments, d_ops_out,
+                       (hipStream_t)stream);
+}
+
+int iiv_encoder_check(iiv_encoder *enc, int *bad_stream, void *stream)
+{
+    if (!enc) return iiv::set_error(IIV_ERR_INVALID, "null encoder");
+    return iiv::encoder_check(enc->impl, bad_stream, (hipStream_t)stream);
+}
+
+int iiv_encoder_profile(iiv_encoder *enc, int enable)
+{
+    if (!enc) return iiv::set_error(IIV_ERR_INVALID, "null encoder");
+    return iiv::encoder_profile(enc->impl, enable);
+}
+
+int iiv_encoder_profile_read(iiv_encoder *enc, double ms[2], int64_t launches[2])
+{
+    if (!enc) return iiv::set_error(IIV_ERR_INVALID, "null encoder");
+    return iiv::encoder_profile_read(enc->impl, ms, launches);
+}
+
+}  // extern "C"

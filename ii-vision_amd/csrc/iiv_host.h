@@ -1,0 +1,38 @@
+// iiv_host.h -- host-side declarations shared by the translation units of
+// libiivision.so (the C ABI itself is include/iivision.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/iivision.h"
+#include "iiv_device.h"
+
+namespace iiv {
+
+int set_error(int code, const char *fmt, ...);
+int hip_check(hipError_t e, const char *what);
+
+#define IIV_HIP(expr)                                    \
+    do {                                                 \
+        int _rc = ::iiv::hip_check((expr), #expr);       \
+        if (_rc) return _rc;                             \
+    } while (0)
+
+// iiv_tables.hip
+int cie2000_matrix(const uint8_t rgb[48], double out_f[256], int32_t out_i[256], hipStream_t st);
+int pixel_strings(int mode, uint32_t *d_dots, uint8_t *d_pixels, ulonglong2 *d_strings, hipStream_t st);
+int build_table(int mode, const int32_t dm[256], uint16_t *d_out, int symmetric, hipStream_t st);
+int build_store_table(int mode, const int32_t dm[256], uint16_t *d_out, hipStream_t st);
+
+// iiv_bitmap.hip
+int pack(int mode, int n, const uint8_t *d_main, const uint8_t *d_aux, uint64_t *d_packed, hipStream_t st);
+int diff_weights(int mode, const uint16_t *d_table, int n, const uint64_t *d_src, const uint64_t *d_tgt,
+                 int is_aux, int32_t *d_out, hipStream_t st);
+int compute_delta_pages(int mode, const uint16_t *d_table, int n, const uint64_t *d_tgt, const int32_t *d_pages,
+                        const int32_t *d_contents, const int32_t *d_dw_rows, int is_aux, int32_t *d_out,
+                        hipStream_t st);
+
+}  // namespace iiv

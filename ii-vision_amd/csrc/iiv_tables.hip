@@ -1,0 +1,393 @@
+// iiv_tables.hip -- make_data_tables on gfx950 (reference: transcoder/make_data_tables.py).
+//
+// K3 cie2000_kernel     compute_diff_matrix            make_data_tables.py:55-70
+// K1 pixel_kernel       to_dots + colour model         screen.py:743-789, colours.py:100-148
+// K2 table_kernel       compute_edit_distance          make_data_tables.py:111-174
+//    store_kernel       the (target window, content) sub-table the greedy loop reads
+//
+// The table build is integer ALU + streaming u16 stores: each thread owns 8
+// consecutive j columns (their colour strings live in registers) and walks a
+// tile of i rows whose string is wave-uniform, so every wave store is 1 KiB
+// contiguous.  No MFMA: there is no contraction here, only a 10/18-step
+// min-plus recurrence per pair.
+#include "iiv_host.h"
+
+namespace iiv {
+
+// ------------------------------------------------------------------ CIE2000
+
+// colormath 3.0.0 RGB_to_XYZ + XYZ_to_Lab (sRGB, D65/2deg, no adaptation).
+__device__ static void rgb_to_lab(const uint8_t *rgb, double lab[3])
+{
+    double lin[3];
+    for (int i = 0; i < 3; i++) {
+        double v = rgb[i] / 255.0;
+        lin[i] = v <= 0.04045 ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4);
+    }
+    const double M[3][3] = {{0.412424, 0.357579, 0.180464},
+                            {0.212656, 0.715158, 0.0721856},
+                            {0.0193324, 0.119193, 0.950444}};
+    const double illum[3] = {0.95047, 1.00000, 1.08883};
+    const double CIE_E = 216.0 / 24389.0;
+    double t[3];
+    for (int r = 0; r < 3; r++) {
+        double s = M[r][0] * lin[0] + M[r][1] * lin[1] + M[r][2] * lin[2];
+        s = s > 0.0 ? s : 0.0;
+        double v = s / illum[r];
+        t[r] = v > CIE_E ? pow(v, 1.0 / 3.0) : (7.787 * v) + (16.0 / 116.0);
+    }
+    lab[0] = (116.0 * t[1]) - 16.0;
+    lab[1] = 500.0 * (t[0] - t[1]);
+    lab[2] = 200.0 * (t[1] - t[2]);
+}
+
+__device__ static inline double deg(double r) { return r * (180.0 / 3.14159265358979323846); }
+__device__ static inline double rad(double d) { return d * (3.14159265358979323846 / 180.0); }
+
+// colormath 3.0.0 color_diff_matrix.delta_e_cie2000, Kl=Kc=Kh=1.
+__device__ static double delta_e_cie2000(const double c1[3], const double c2[3])
+{
+    double L = c1[0], a = c1[1], b = c1[2];
+    double L2 = c2[0], a2 = c2[1], b2 = c2[2];
+    double avg_Lp = (L + L2) / 2.0;
+    double C1 = sqrt(a * a + b * b);
+    double C2 = sqrt(a2 * a2 + b2 * b2);
+    double avg_C = (C1 + C2) / 2.0;
+    double G = 0.5 * (1 - sqrt(pow(avg_C, 7.0) / (pow(avg_C, 7.0) + pow(25.0, 7.0))));
+    double a1p = (1.0 + G) * a;
+    double a2p = (1.0 + G) * a2;
+    double C1p = sqrt(a1p * a1p + b * b);
+    double C2p = sqrt(a2p * a2p + b2 * b2);
+    double avg_Cp = (C1p + C2p) / 2.0;
+    double h1p = deg(atan2(b, a1p));
+    h1p += (h1p < 0) * 360;
+    double h2p = deg(atan2(b2, a2p));
+    h2p += (h2p < 0) * 360;
+    double avg_Hp = (((fabs(h1p - h2p) > 180) * 360) + h1p + h2p) / 2.0;
+    double T = 1 - 0.17 * cos(rad(avg_Hp - 30)) + 0.24 * cos(rad(2 * avg_Hp)) +
+               0.32 * cos(rad(3 * avg_Hp + 6)) - 0.2 * cos(rad(4 * avg_Hp - 63));
+    double diff = h2p - h1p;
+    double delta_hp = diff + (fabs(diff) > 180) * 360;
+    delta_hp -= (h2p > h1p) * 720;
+    double dLp = L2 - L;
+    double dCp = C2p - C1p;
+    double dHp = 2 * sqrt(C2p * C1p) * sin(rad(delta_hp) / 2.0);
+    double S_L = 1 + ((0.015 * pow(avg_Lp - 50, 2.0)) / sqrt(20 + pow(avg_Lp - 50, 2.0)));
+    double S_C = 1 + 0.045 * avg_Cp;
+    double S_H = 1 + 0.015 * avg_Cp * T;
+    double d_ro = 30 * exp(-(pow(((avg_Hp - 275) / 25), 2.0)));
+    double R_C = sqrt((pow(avg_Cp, 7.0)) / (pow(avg_Cp, 7.0) + pow(25.0, 7.0)));
+    double R_T = -2 * R_C * sin(2 * rad(d_ro));
+    return sqrt(pow(dLp / S_L, 2.0) + pow(dCp / S_C, 2.0) + pow(dHp / S_H, 2.0) +
+                R_T * (dCp / S_C) * (dHp / S_H));
+}
+
+__global__ void cie2000_kernel(const uint8_t *rgb, double *out_f, int32_t *out_i)
+{
+    int t = threadIdx.x;  // 256 threads: (i, j)
+    int i = t >> 4, j = t & 15;
+    double l1[3], l2[3];
+    rgb_to_lab(rgb + 3 * i, l1);
+    rgb_to_lab(rgb + 3 * j, l2);
+    double d = delta_e_cie2000(l1, l2);
+    out_f[t] = d;
+    out_i[t] = (int32_t)d;  // int(): truncation (make_data_tables.py:68)
+}
+
+// ------------------------------------------------------------------ colour strings
+
+// HGRBitmap._double_pixels (screen.py:712-739)
+__host__ __device__ static inline uint32_t double_pixels(uint32_t v)
+{
+    uint32_t r = 0;
+    for (int k = 0; k < 7; k++)
+        if (v & (1u << k)) r |= 3u << (2 * k);
+    if (v & 0x40) r |= 1u << 14;
+    return r;
+}
+
+// to_dots (screen.py:743-789; DHGR: identity, screen.py:983-990)
+template <int MODE> __host__ __device__ static inline uint32_t to_dots(uint32_t m, int o)
+{
+    if (MODE == kDHGR) return m;
+    uint32_t h = (m & 7) << 5;
+    uint32_t hp = (h & 0x80) >> 7;
+    uint32_t res = double_pixels(h & 0x7f) >> (11 - hp);
+    uint32_t b, bp;
+    if (o == 0) {
+        b = (m >> 3) & 0xff;
+        bp = (b & 0x80) >> 7;
+    } else {
+        bp = (m >> 3) & 1;
+        b = ((m >> 4) & 0x7f) ^ (bp << 7);
+    }
+    res &= ~(0x3fffu << (3 + bp));
+    res ^= double_pixels(b & 0x7f) << (3 + bp);
+    uint32_t f = ((m >> 12) & 3) ^ (((m >> 11) & 1) << 7);
+    uint32_t fp = (f & 0x80) >> 7;
+    res &= ~(0xfu << (17 + fp));
+    res ^= double_pixels(f & 0x7f) << (17 + fp);
+    return res & ((1u << 21) - 1);
+}
+
+// Colour value of pixel k = rol4(dots[k..k+3], (phase + k) & 3) (colours.py:100-134);
+// the string is returned as packed nibbles, pixel k in nibble k (lo: 0..15, hi: 16..).
+template <int MODE> __host__ __device__ static inline void colour_string(uint32_t m, int o, uint64_t &lo, uint32_t &hi)
+{
+    uint32_t dots = to_dots<MODE>(m, o);
+    int ph = phase_of(MODE, o);
+    lo = 0;
+    hi = 0;
+    for (int k = 0; k < ModeTraits<MODE>::kDots; k++) {
+        uint32_t w = (dots >> k) & 0xf;
+        int r = (ph + k) & 3;
+        uint32_t c = ((w << r) | (w >> (4 - r))) & 0xf;
+        if (k < 16)
+            lo |= (uint64_t)c << (4 * k);
+        else
+            hi |= c << (4 * (k - 16));
+    }
+}
+
+template <int MODE>
+__global__ void pixel_kernel(uint32_t *dots_out, uint8_t *pix_out, ulonglong2 *strings)
+{
+    constexpr int BITS = ModeTraits<MODE>::kBits, ND = ModeTraits<MODE>::kDots;
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;  // o * 2^bits + m
+    if (idx >= (ModeTraits<MODE>::kOffsets << BITS)) return;
+    int o = idx >> BITS;
+    uint32_t m = idx & ((1u << BITS) - 1);
+    uint64_t lo;
+    uint32_t hi;
+    colour_string<MODE>(m, o, lo, hi);
+    if (strings) strings[idx] = make_ulonglong2(lo, (unsigned long long)hi);
+    if (dots_out) dots_out[idx] = to_dots<MODE>(m, o);
+    if (pix_out)
+        for (int k = 0; k < ND; k++)
+            pix_out[(size_t)idx * ND + k] = (uint8_t)(k < 16 ? (lo >> (4 * k)) & 0xf : (hi >> (4 * (k - 16))) & 0xf);
+}
+
+// ------------------------------------------------------------------ edit distance
+
+template <int K> __device__ static inline uint32_t nib(uint64_t lo, uint32_t hi)
+{
+    if (K < 8) return ((uint32_t)lo >> (4 * K)) & 0xf;
+    if (K < 16) return ((uint32_t)(lo >> 32) >> (4 * (K - 8))) & 0xf;
+    return (hi >> (4 * (K - 16))) & 0xf;
+}
+
+// weighted Damerau-Levenshtein between two equal-length colour strings with
+// insert/delete cost 1e5 and transpose cost 1 (make_data_tables.py:30-41,98-104)
+// reduces to E[k] = min(E[k-1] + sub(a_k,b_k), E[k-2] + 1 if a_{k-1}a_k == b_k b_{k-1}).
+// lut = 16x16 substitute costs (u16) in LDS.
+template <int N, int K> struct EditStep {
+    __device__ static inline void run(uint64_t alo, uint32_t ahi, uint64_t blo, uint32_t bhi,
+                                      const uint16_t *lut, uint32_t &e1, uint32_t &e2)
+    {
+        uint32_t a = nib<K>(alo, ahi), b = nib<K>(blo, bhi);
+        uint32_t s = (a == b) ? 0u : (uint32_t)lut[a * 16 + b];
+        uint32_t e = e1 + s;
+        if (K >= 1) {
+            uint32_t ap = nib<(K >= 1 ? K - 1 : 0)>(alo, ahi), bp = nib<(K >= 1 ? K - 1 : 0)>(blo, bhi);
+            uint32_t t = e2 + 1;
+            if (ap == b && a == bp && t < e) e = t;
+        }
+        e2 = e1;
+        e1 = e;
+        EditStep<N, K + 1>::run(alo, ahi, blo, bhi, lut, e1, e2);
+    }
+};
+template <int N> struct EditStep<N, N> {
+    __device__ static inline void run(uint64_t, uint32_t, uint64_t, uint32_t, const uint16_t *, uint32_t &, uint32_t &) {}
+};
+
+template <int N>
+__device__ static inline uint32_t edit_distance(uint64_t alo, uint32_t ahi, uint64_t blo, uint32_t bhi, const uint16_t *lut)
+{
+    uint32_t e1 = 0, e2 = 0;
+    EditStep<N, 0>::run(alo, ahi, blo, bhi, lut, e1, e2);
+    return e1;
+}
+
+constexpr int kTableRowsPerBlock = 32;
+constexpr int kTableColsPerThread = 8;
+
+// grid: x = column tile (2^bits / (256*8)), y = row tile (2^bits / 32), z = byte offset
+template <int MODE>
+__global__ __launch_bounds__(256) void table_kernel(const ulonglong2 *__restrict__ strings,
+                                                    const uint16_t *__restrict__ sub, uint16_t *__restrict__ out,
+                                                    int symmetric)
+{
+    constexpr int BITS = ModeTraits<MODE>::kBits, ND = ModeTraits<MODE>::kDots;
+    __shared__ uint16_t lut[256];
+    lut[threadIdx.x] = sub[threadIdx.x];
+    __syncthreads();
+    const int o = blockIdx.z;
+    const ulonglong2 *S = strings + ((size_t)o << BITS);
+    uint16_t *T = out + ((size_t)o << (2 * BITS));
+    const int j0 = (blockIdx.x * 256 + threadIdx.x) * kTableColsPerThread;
+    uint64_t blo[kTableColsPerThread];
+    uint32_t bhi[kTableColsPerThread];
+#pragma unroll
+    for (int c = 0; c < kTableColsPerThread; c++) {
+        ulonglong2 v = S[j0 + c];
+        blo[c] = v.x;
+        bhi[c] = (uint32_t)v.y;
+    }
+    const int i0 = blockIdx.y * kTableRowsPerBlock;
+    for (int r = 0; r < kTableRowsPerBlock; r++) {
+        const int i = i0 + r;
+        ulonglong2 av = S[i];  // wave-uniform
+        uint64_t alo = av.x;
+        uint32_t ahi = (uint32_t)av.y;
+        uint32_t e[kTableColsPerThread];
+#pragma unroll
+        for (int c = 0; c < kTableColsPerThread; c++) {
+            uint32_t v = edit_distance<ND>(alo, ahi, blo[c], bhi[c], lut);
+            // make_data_tables.py:156: only j < i is stored; screen.py:358-365 mirrors it
+            if (!symmetric && (j0 + c) >= i) v = 0;
+            e[c] = v;
+        }
+        uint4 pk;
+        pk.x = e[0] | (e[1] << 16);
+        pk.y = e[2] | (e[3] << 16);
+        pk.z = e[4] | (e[5] << 16);
+        pk.w = e[6] | (e[7] << 16);
+        *reinterpret_cast<uint4 *>(T + ((size_t)i << BITS) + j0) = pk;
+    }
+}
+
+// S[o][content][m] = ED(string(poke(m, content)), string(m))
+template <int MODE>
+__global__ __launch_bounds__(256) void store_kernel(const ulonglong2 *__restrict__ strings,
+                                                    const uint16_t *__restrict__ sub, uint16_t *__restrict__ out)
+{
+    constexpr int BITS = ModeTraits<MODE>::kBits, ND = ModeTraits<MODE>::kDots, CB = ModeTraits<MODE>::kContentBits;
+    __shared__ uint16_t lut[256];
+    lut[threadIdx.x] = sub[threadIdx.x];
+    __syncthreads();
+    size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // ((o << CB) + content) << BITS) + m
+    if (idx >= ((size_t)ModeTraits<MODE>::kOffsets << (CB + BITS))) return;
+    uint32_t m = idx & ((1u << BITS) - 1);
+    uint32_t content = (idx >> BITS) & ((1u << CB) - 1);
+    int o = (int)(idx >> (BITS + CB));
+    // byte parity inside the column: HGR o is the parity; DHGR poke ignores it
+    uint32_t pm = poke_window<MODE>(m, content, o & 1);
+    const ulonglong2 *S = strings + ((size_t)o << BITS);
+    ulonglong2 a = S[pm], b = S[m];
+    out[idx] = (uint16_t)edit_distance<ND>(a.x, (uint32_t)a.y, b.x, (uint32_t)b.y, lut);
+}
+
+// ------------------------------------------------------------------ host side
+
+// compute_substitute_costs (make_data_tables.py:73-89): the fill loop writes
+// (c,d) and (d,c) on every iteration, so the result is dm's lower triangle
+// mirrored: sub[u][v] = dm[max(u,v)][min(u,v)].
+static void substitute_costs(const int32_t dm[256], uint16_t sub[256])
+{
+    int32_t s[256];
+    for (int i = 0; i < 16; i++)
+        for (int j = 0; j < 16; j++) {
+            s[i * 16 + j] = dm[i * 16 + j];
+            s[j * 16 + i] = dm[i * 16 + j];
+        }
+    for (int i = 0; i < 256; i++) sub[i] = (uint16_t)s[i];
+}
+
+template <int MODE> static int pixel_strings_impl(uint32_t *d_dots, uint8_t *d_pixels, ulonglong2 *d_strings, hipStream_t st)
+{
+    int n = ModeTraits<MODE>::kOffsets << ModeTraits<MODE>::kBits;
+    hipLaunchKernelGGL(pixel_kernel<MODE>, dim3((n + 255) / 256), dim3(256), 0, st, d_dots, d_pixels, d_strings);
+    return hip_check(hipGetLastError(), "pixel_kernel launch");
+}
+
+int pixel_strings(int mode, uint32_t *d_dots, uint8_t *d_pixels, ulonglong2 *d_strings, hipStream_t st)
+{
+    return mode == kDHGR ? pixel_strings_impl<kDHGR>(d_dots, d_pixels, d_strings, st)
+                         : pixel_strings_impl<kHGR>(d_dots, d_pixels, d_strings, st);
+}
+
+struct TableScratch {
+    ulonglong2 *strings = nullptr;
+    uint16_t *sub = nullptr;
+    ~TableScratch()
+    {
+        if (strings) (void)hipFree(strings);
+        if (sub) (void)hipFree(sub);
+    }
+};
+
+static int prepare_scratch(int mode, const int32_t dm[256], TableScratch &sc, hipStream_t st)
+{
+    size_t n = (size_t)num_offsets(mode) << masked_bits(mode);
+    IIV_HIP(hipMalloc(&sc.strings, n * sizeof(ulonglong2)));
+    IIV_HIP(hipMalloc(&sc.sub, 256 * sizeof(uint16_t)));
+    uint16_t sub[256];
+    substitute_costs(dm, sub);
+    IIV_HIP(hipMemcpyAsync(sc.sub, sub, sizeof(sub), hipMemcpyHostToDevice, st));
+    IIV_HIP(hipStreamSynchronize(st));  // `sub` is a stack buffer
+    return pixel_strings(mode, nullptr, nullptr, sc.strings, st);
+}
+
+int build_table(int mode, const int32_t dm[256], uint16_t *d_out, int symmetric, hipStream_t st)
+{
+    TableScratch sc;
+    int rc = prepare_scratch(mode, dm, sc, st);
+    if (rc) return rc;
+    int bits = masked_bits(mode);
+    dim3 grid((1u << bits) / (256 * kTableColsPerThread), (1u << bits) / kTableRowsPerBlock, num_offsets(mode));
+    if (mode == kDHGR)
+        hipLaunchKernelGGL(table_kernel<kDHGR>, grid, dim3(256), 0, st, sc.strings, sc.sub, d_out, symmetric);
+    else
+        hipLaunchKernelGGL(table_kernel<kHGR>, grid, dim3(256), 0, st, sc.strings, sc.sub, d_out, symmetric);
+    rc = hip_check(hipGetLastError(), "table_kernel launch");
+    if (rc) return rc;
+    IIV_HIP(hipStreamSynchronize(st));  // scratch is freed on return
+    return IIV_OK;
+}
+
+int build_store_table(int mode, const int32_t dm[256], uint16_t *d_out, hipStream_t st)
+{
+    TableScratch sc;
+    int rc = prepare_scratch(mode, dm, sc, st);
+    if (rc) return rc;
+    size_t n = (size_t)num_offsets(mode) << (content_bits(mode) + masked_bits(mode));
+    dim3 grid((unsigned)((n + 255) / 256));
+    if (mode == kDHGR)
+        hipLaunchKernelGGL(store_kernel<kDHGR>, grid, dim3(256), 0, st, sc.strings, sc.sub, d_out);
+    else
+        hipLaunchKernelGGL(store_kernel<kHGR>, grid, dim3(256), 0, st, sc.strings, sc.sub, d_out);
+    rc = hip_check(hipGetLastError(), "store_kernel launch");
+    if (rc) return rc;
+    IIV_HIP(hipStreamSynchronize(st));
+    return IIV_OK;
+}
+
+int cie2000_matrix(const uint8_t rgb[48], double out_f[256], int32_t out_i[256], hipStream_t st)
+{
+    uint8_t *d_rgb = nullptr;
+    double *d_f = nullptr;
+    int32_t *d_i = nullptr;
+    IIV_HIP(hipMalloc(&d_rgb, 48));
+    IIV_HIP(hipMalloc(&d_f, 256 * sizeof(double)));
+    IIV_HIP(hipMalloc(&d_i, 256 * sizeof(int32_t)));
+    int rc = IIV_OK;
+    do {
+        if ((rc = hip_check(hipMemcpyAsync(d_rgb, rgb, 48, hipMemcpyHostToDevice, st), "copy rgb"))) break;
+        hipLaunchKernelGGL(cie2000_kernel, dim3(1), dim3(256), 0, st, d_rgb, d_f, d_i);
+        if ((rc = hip_check(hipGetLastError(), "cie2000_kernel launch"))) break;
+        double f[256];
+        int32_t iv[256];
+        if ((rc = hip_check(hipMemcpyAsync(f, d_f, sizeof(f), hipMemcpyDeviceToHost, st), "copy f"))) break;
+        if ((rc = hip_check(hipMemcpyAsync(iv, d_i, sizeof(iv), hipMemcpyDeviceToHost, st), "copy i"))) break;
+        if ((rc = hip_check(hipStreamSynchronize(st), "sync"))) break;
+        if (out_f) memcpy(out_f, f, sizeof(f));
+        if (out_i) memcpy(out_i, iv, sizeof(iv));
+    } while (0);
+    (void)hipFree(d_rgb);
+    (void)hipFree(d_f);
+    (void)hipFree(d_i);
+    return rc;
+}
+
+}  // namespace iiv

@@ -1,0 +1,293 @@
+"""ctypes binding of libiivision.so (include/iivision.h).
+
+PyTorch is plumbing here: it owns device memory (torch tensors whose data_ptr()
+is handed to the C ABI) and the HIP stream.  There is no CPU fallback: if the
+library or a GPU is missing, every compute entry point raises.
+"""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libiivision.so")
+
+HGR = 0
+DHGR = 1
+
+OK = 0
+ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_ASSERT, ERR_OVERFLOW = -1, -2, -3, -4, -5
+
+STATE_MEM_MAIN, STATE_MEM_AUX, STATE_UP_MAIN, STATE_UP_AUX = 0, 1, 2, 3
+STATE_RNG_PY, STATE_RNG_NP, STATE_OUT_OF_WORK, STATE_PACKED, STATE_COUNTERS = 4, 5, 6, 7, 8
+
+# every symbol include/iivision.h declares
+SYMBOLS = [
+    "iiv_version", "iiv_last_error", "iiv_device_count",
+    "iiv_masked_bits", "iiv_masked_dots", "iiv_num_offsets", "iiv_table_entries",
+    "iiv_store_table_entries",
+    "iiv_cie2000_matrix", "iiv_pixel_strings", "iiv_build_table", "iiv_build_store_table",
+    "iiv_pack", "iiv_diff_weights", "iiv_compute_delta_pages",
+    "iiv_encoder_create", "iiv_encoder_destroy", "iiv_encoder_get_state", "iiv_encoder_set_state",
+    "iiv_encode", "iiv_encoder_check", "iiv_encoder_profile", "iiv_encoder_profile_read",
+]
+
+
+class Segment(C.Structure):
+    _fields_ = [("frame", C.c_int32), ("is_aux", C.c_int32), ("restart", C.c_int32), ("n_ops", C.c_int32)]
+
+
+class IIVError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libiivision error %d: %s" % (code, msg))
+        self.code = code
+
+
+class IIVAssertionError(AssertionError):
+    """One of the reference's `assert`s fired on the device."""
+
+
+_lib = None
+
+
+def lib():
+    """Load libiivision.so; fails loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s not found: build it with `make -C ii-vision_amd/csrc` "
+            "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback." % LIB_PATH)
+    # torch bundles its own HIP runtime (SONAME libamdhip64.so.7).  Import it first so
+    # that our NEEDED entry resolves to that already-loaded copy: two HIP/HSA runtimes
+    # in one process cannot both own the device.
+    import torch  # noqa: F401
+    L = C.CDLL(LIB_PATH)
+    vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
+    L.iiv_version.restype = C.c_char_p
+    L.iiv_last_error.restype = C.c_char_p
+    L.iiv_device_count.restype = i32
+    for f in ("iiv_masked_bits", "iiv_masked_dots", "iiv_num_offsets"):
+        getattr(L, f).restype = i32
+        getattr(L, f).argtypes = [i32]
+    for f in ("iiv_table_entries", "iiv_store_table_entries"):
+        getattr(L, f).restype = sz
+        getattr(L, f).argtypes = [i32]
+    L.iiv_cie2000_matrix.argtypes = [vp, vp, vp, vp]
+    L.iiv_pixel_strings.argtypes = [i32, vp, vp, vp]
+    L.iiv_build_table.argtypes = [i32, vp, vp, i32, vp]
+    L.iiv_build_store_table.argtypes = [i32, vp, vp, vp]
+    L.iiv_pack.argtypes = [i32, i32, vp, vp, vp, vp]
+    L.iiv_diff_weights.argtypes = [i32, vp, i32, vp, vp, i32, vp, vp]
+    L.iiv_compute_delta_pages.argtypes = [i32, vp, i32, vp, vp, vp, vp, i32, vp, vp]
+    L.iiv_encoder_create.argtypes = [i32, vp, vp, i32, C.POINTER(vp)]
+    L.iiv_encoder_destroy.argtypes = [vp]
+    L.iiv_encoder_destroy.restype = None
+    L.iiv_encoder_get_state.argtypes = [vp, i32, i32, vp, sz]
+    L.iiv_encoder_set_state.argtypes = [vp, i32, i32, vp, sz]
+    L.iiv_encode.argtypes = [vp, vp, vp, i32, C.POINTER(Segment), i32, vp, vp]
+    L.iiv_encoder_check.argtypes = [vp, C.POINTER(i32), vp]
+    L.iiv_encoder_profile.argtypes = [vp, i32]
+    L.iiv_encoder_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    for name in SYMBOLS:
+        getattr(L, name)  # AttributeError if the library lacks a declared symbol
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc == OK:
+        return
+    msg = lib().iiv_last_error().decode("utf-8", "replace")
+    if rc == ERR_ASSERT:
+        raise IIVAssertionError(msg)
+    raise IIVError(rc, msg)
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("libiivision needs an AMD GPU (torch.cuda.is_available() is False); "
+                           "there is no CPU fallback")
+    return torch
+
+
+def stream_ptr():
+    torch = _torch()
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def hptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ---- P1 -------------------------------------------------------------------------
+
+def cie2000_matrix(rgb):
+    """rgb: (16,3) uint8 indexed by HGRColours value -> (float64 (16,16), int32 (16,16))."""
+    _torch()
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8).reshape(48)
+    f = np.zeros((16, 16), dtype=np.float64)
+    i = np.zeros((16, 16), dtype=np.int32)
+    check(lib().iiv_cie2000_matrix(hptr(rgb), hptr(f), hptr(i), stream_ptr()))
+    return f, i
+
+
+def pixel_strings(mode):
+    torch = _torch()
+    L = lib()
+    n = L.iiv_num_offsets(mode) << L.iiv_masked_bits(mode)
+    nd = L.iiv_masked_dots(mode)
+    dots = torch.empty(n, dtype=torch.int32, device="cuda")
+    pix = torch.empty((n, nd), dtype=torch.uint8, device="cuda")
+    check(L.iiv_pixel_strings(mode, dptr(dots), dptr(pix), stream_ptr()))
+    shape = (L.iiv_num_offsets(mode), 1 << L.iiv_masked_bits(mode))
+    return dots.view(shape), pix.view(shape + (nd,))
+
+
+def build_table(mode, dm, symmetric=True):
+    """Device tensor (num_offsets, 2**(2*bits)) int16-typed storage of the u16 table."""
+    torch = _torch()
+    L = lib()
+    dm = np.ascontiguousarray(dm, dtype=np.int32).reshape(256)
+    bits = L.iiv_masked_bits(mode)
+    out = torch.empty((L.iiv_num_offsets(mode), 1 << (2 * bits)), dtype=torch.int16, device="cuda")
+    check(L.iiv_build_table(mode, hptr(dm), dptr(out), 1 if symmetric else 0, stream_ptr()))
+    return out
+
+
+def build_store_table(mode, dm):
+    torch = _torch()
+    L = lib()
+    dm = np.ascontiguousarray(dm, dtype=np.int32).reshape(256)
+    out = torch.empty(L.iiv_store_table_entries(mode), dtype=torch.int16, device="cuda")
+    check(L.iiv_build_store_table(mode, hptr(dm), dptr(out), stream_ptr()))
+    return out
+
+
+def table_to_numpy(t):
+    """u16 view of a table tensor on the host."""
+    return t.cpu().numpy().view(np.uint16)
+
+
+# ---- P2 -------------------------------------------------------------------------
+
+def pack(mode, main_mem, aux_mem=None):
+    """main/aux: uint8 arrays (..., 32, 256) on host -> uint64 (..., 32, 128) on host."""
+    torch = _torch()
+    main_mem = np.ascontiguousarray(main_mem, dtype=np.uint8)
+    lead = main_mem.shape[:-2]
+    n = int(np.prod(lead)) if lead else 1
+    dm_ = torch.from_numpy(main_mem.reshape(n, 32, 256)).cuda()
+    da = None
+    if mode == DHGR:
+        da = torch.from_numpy(np.ascontiguousarray(aux_mem, dtype=np.uint8).reshape(n, 32, 256)).cuda()
+    out = torch.empty((n, 32, 128), dtype=torch.int64, device="cuda")
+    check(lib().iiv_pack(mode, n, dptr(dm_), dptr(da), dptr(out), stream_ptr()))
+    return out.cpu().numpy().view(np.uint64).reshape(lead + (32, 128))
+
+
+def diff_weights(mode, table, src_packed, tgt_packed, is_aux):
+    torch = _torch()
+    src = torch.from_numpy(np.ascontiguousarray(src_packed, dtype=np.uint64).view(np.int64).reshape(1, 32, 128)).cuda()
+    tgt = torch.from_numpy(np.ascontiguousarray(tgt_packed, dtype=np.uint64).view(np.int64).reshape(1, 32, 128)).cuda()
+    out = torch.empty((32, 256), dtype=torch.int32, device="cuda")
+    check(lib().iiv_diff_weights(mode, dptr(table), 1, dptr(src), dptr(tgt), int(bool(is_aux)), dptr(out),
+                                 stream_ptr()))
+    return out.cpu().numpy()
+
+
+def compute_delta_pages(mode, table, tgt_packed, pages, contents, dw_rows, is_aux):
+    torch = _torch()
+    tgt = torch.from_numpy(np.ascontiguousarray(tgt_packed, dtype=np.uint64).view(np.int64)).cuda()
+    pages = np.ascontiguousarray(pages, dtype=np.int32).reshape(-1)
+    n = len(pages)
+    dp = torch.from_numpy(pages).cuda()
+    dc = torch.from_numpy(np.ascontiguousarray(contents, dtype=np.int32).reshape(-1)).cuda()
+    dr = torch.from_numpy(np.ascontiguousarray(dw_rows, dtype=np.int32).reshape(n, 256)).cuda()
+    out = torch.empty((n, 256), dtype=torch.int32, device="cuda")
+    check(lib().iiv_compute_delta_pages(mode, dptr(table), n, dptr(tgt), dptr(dp), dptr(dc), dptr(dr),
+                                        int(bool(is_aux)), dptr(out), stream_ptr()))
+    return out.cpu().numpy()
+
+
+# ---- P3 -------------------------------------------------------------------------
+
+class Encoder:
+    """n_streams independent video.Video states resident on the GPU."""
+
+    def __init__(self, mode, table, store_table, n_streams=1):
+        _torch()
+        self.mode = mode
+        self.n_streams = int(n_streams)
+        self._table = table            # keep the device tensors alive
+        self._store = store_table
+        h = C.c_void_p()
+        check(lib().iiv_encoder_create(mode, dptr(table), dptr(store_table), self.n_streams, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().iiv_encoder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    _ITEMS = {
+        STATE_MEM_MAIN: ((32, 256), np.uint8), STATE_MEM_AUX: ((32, 256), np.uint8),
+        STATE_UP_MAIN: ((32, 256), np.int32), STATE_UP_AUX: ((32, 256), np.int32),
+        STATE_RNG_PY: ((625,), np.uint32), STATE_RNG_NP: ((625,), np.uint32),
+        STATE_OUT_OF_WORK: ((2,), np.int32), STATE_PACKED: ((32, 128), np.uint64),
+        STATE_COUNTERS: ((4,), np.uint64),
+    }
+
+    def get_state(self, what, stream=0, out=None):
+        shape, dt = self._ITEMS[what]
+        if out is None:
+            out = np.empty(shape, dtype=dt)
+        assert out.flags.c_contiguous and out.dtype == dt and out.shape == shape
+        check(lib().iiv_encoder_get_state(self._h, int(stream), what, hptr(out), out.nbytes))
+        return out
+
+    def set_state(self, what, value, stream=0):
+        shape, dt = self._ITEMS[what]
+        a = np.ascontiguousarray(value, dtype=dt).reshape(shape)
+        check(lib().iiv_encoder_set_state(self._h, int(stream), what, hptr(a), a.nbytes))
+
+    def encode(self, frames_main, frames_aux, segments, ops_out=None):
+        """frames_*: CUDA uint8 tensors (n_streams, n_frames, 32, 256); segments: list of
+        (frame, is_aux, restart, n_ops).  Returns the CUDA uint8 tensor
+        (n_streams, total_ops, 6).  Asynchronous."""
+        torch = _torch()
+        n_frames = frames_main.shape[1]
+        assert frames_main.shape[0] == self.n_streams and frames_main.is_contiguous()
+        segs = (Segment * len(segments))(*[Segment(int(f), int(a), int(r), int(k)) for (f, a, r, k) in segments])
+        total = sum(int(s[3]) for s in segments)
+        if ops_out is None:
+            ops_out = torch.empty((self.n_streams, total, 6), dtype=torch.uint8, device="cuda")
+        check(lib().iiv_encode(self._h, dptr(frames_main), dptr(frames_aux), int(n_frames), segs, len(segments),
+                               dptr(ops_out), stream_ptr()))
+        return ops_out
+
+    def check(self):
+        bad = C.c_int(-1)
+        check(lib().iiv_encoder_check(self._h, C.byref(bad), stream_ptr()))
+
+    def profile(self, enable=True):
+        check(lib().iiv_encoder_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self):
+        ms = (C.c_double * 2)()
+        n = (C.c_int64 * 2)()
+        check(lib().iiv_encoder_profile_read(self._h, ms, n))
+        return {"prologue_ms": ms[0], "greedy_ms": ms[1], "prologue_launches": n[0], "greedy_launches": n[1]}

@@ -1,0 +1,170 @@
+"""Encode a sequence of images as an optimized stream of screen changes -- on the GPU.
+
+Host-side mirror of the reference's transcoder/video.py: `Video` keeps the same
+constructor, attributes (memory_map, aux_memory_map, pixelmap, update_priority,
+aux_update_priority, out_of_work, frame_number) and methods (tick, encode_frame),
+and `encode_frame` is still a lazy, never-ending generator of
+(page, content, offsets) tuples.  The work -- diff weights, priority ranking, the
+greedy selection loop and both MT19937 nonce streams -- runs in the gfx950 kernels
+of csrc/iiv_encode.hip through iiv_encode() (include/iivision.h).
+
+State model: between device calls the host numpy arrays and Python's / NumPy's
+global RNG states are authoritative, exactly as in the reference, so code that
+pokes `video.memory_map.page_offset` or reseeds `random` keeps working; each device
+call uploads them, runs, and downloads them back *in place*.
+
+Budget: a generator may be abandoned after any next() (movie.py:94-109 does so at
+every frame and bank flip), and its side effects must then be exactly those of
+the opcodes consumed.  Without a hint every next() is therefore one device call.
+`encode_frame(target, is_aux, budget=K)` promises that K opcodes will be pulled;
+they are then computed by one launch.  Batched, many-stream encoding (what
+bench.py measures) goes through stream_batch.StreamBatch instead.
+"""
+
+import random
+from typing import Iterator, List, Tuple
+
+import numpy as np
+
+import _iiv_native as native
+import screen
+from palette import Palette
+from video_mode import VideoMode
+
+
+class Video:
+    """Encodes sequence of images into prioritized screen byte changes."""
+
+    CLOCK_SPEED = 1024 * 1024  # type: int
+
+    def __init__(
+            self,
+            frame_grabber,
+            ticks_per_second: float,
+            mode: VideoMode = VideoMode.HGR,
+            palette: Palette = Palette.NTSC
+    ):
+        self.mode = mode  # type: VideoMode
+        self.frame_grabber = frame_grabber
+        self.ticks_per_second = float(ticks_per_second)  # type: float
+        self.ticks_per_frame = (
+                self.ticks_per_second / frame_grabber.input_frame_rate
+        )  # type: float
+        self.frame_number = 0  # type: int
+        self.palette = palette  # type: Palette
+
+        # Empty screen (video.py:37-53); the pixelmap aliases the memory maps
+        self.memory_map = screen.MemoryMap(screen_page=1)
+        if self.mode == VideoMode.DHGR:
+            self.aux_memory_map = screen.MemoryMap(screen_page=1)
+            self.pixelmap = screen.DHGRBitmap(
+                palette=palette, main_memory=self.memory_map, aux_memory=self.aux_memory_map)
+        else:
+            self.pixelmap = screen.HGRBitmap(palette=palette, main_memory=self.memory_map)
+
+        # Pending edit weights, accumulated across frames (video.py:55-58)
+        self.update_priority = np.zeros((32, 256), dtype=np.int32)
+        if self.mode == VideoMode.DHGR:
+            self.aux_update_priority = np.zeros((32, 256), dtype=np.int32)
+
+        # True once the main / aux bank has run out of work (video.py:60-62)
+        self.out_of_work = {True: False, False: False}
+
+        tables = self.pixelmap.edit_distances(palette)
+        self._mode_id = native.DHGR if mode == VideoMode.DHGR else native.HGR
+        self._enc = native.Encoder(self._mode_id, tables.table, tables.store, n_streams=1)
+        self._live = None  # the generator whose state the device currently holds
+
+    def tick(self, ticks: int) -> bool:
+        """Keep track of when it is time for a new image frame (video.py:64-70)."""
+        if ticks >= (self.ticks_per_frame * self.frame_number):
+            self.frame_number += 1
+            return True
+        return False
+
+    # ------------------------------------------------------------------ device sync
+
+    def _upload(self):
+        e = self._enc
+        e.set_state(native.STATE_MEM_MAIN, self.memory_map.page_offset)
+        e.set_state(native.STATE_UP_MAIN, self.update_priority)
+        if self.mode == VideoMode.DHGR:
+            e.set_state(native.STATE_MEM_AUX, self.aux_memory_map.page_offset)
+            e.set_state(native.STATE_UP_AUX, self.aux_update_priority)
+        e.set_state(native.STATE_RNG_PY, np.array(random.getstate()[1], dtype=np.uint32))
+        st = np.random.get_state()
+        e.set_state(native.STATE_RNG_NP,
+                    np.concatenate([np.asarray(st[1], dtype=np.uint32), np.array([st[2]], dtype=np.uint32)]))
+
+    def _download(self):
+        e = self._enc
+        # in place: callers (and self.pixelmap) hold references to these arrays
+        self.memory_map.page_offset[...] = e.get_state(native.STATE_MEM_MAIN)
+        self.update_priority[...] = e.get_state(native.STATE_UP_MAIN)
+        if self.mode == VideoMode.DHGR:
+            self.aux_memory_map.page_offset[...] = e.get_state(native.STATE_MEM_AUX)
+            self.aux_update_priority[...] = e.get_state(native.STATE_UP_AUX)
+        self.pixelmap.packed[...] = e.get_state(native.STATE_PACKED)
+        random.setstate((3, tuple(int(x) for x in e.get_state(native.STATE_RNG_PY)), None))
+        npw = e.get_state(native.STATE_RNG_NP)
+        st = np.random.get_state()
+        np.random.set_state((st[0], npw[:624].copy(), int(npw[624]), st[3], st[4]))
+
+    def _device_steps(self, token, target, is_aux, n_ops):
+        """[prologue +] n_ops greedy steps of generator `token`; returns (n_ops, 6) uint8."""
+        import torch
+        restart = 0 if self._live is token else 1
+        if restart and token.started:
+            raise RuntimeError("this encode_frame() generator cannot be resumed: another generator "
+                               "has run on this Video since (the reference's heap is not kept)")
+        self._upload()
+        main = np.ascontiguousarray(target.main_memory.page_offset, dtype=np.uint8)
+        fm = torch.from_numpy(main[None, None]).cuda()
+        fa = None
+        if self.mode == VideoMode.DHGR:
+            aux = np.ascontiguousarray(target.aux_memory.page_offset, dtype=np.uint8)
+            fa = torch.from_numpy(aux[None, None]).cuda()
+        ops = self._enc.encode(fm, fa, [(0, int(bool(is_aux)), restart, int(n_ops))])
+        self._enc.check()
+        self._live = token
+        token.started = True
+        self._download()
+        oow = self._enc.get_state(native.STATE_OUT_OF_WORK)
+        if oow[1 if is_aux else 0]:
+            self.out_of_work[bool(is_aux)] = True  # video.py:189
+        return ops[0].cpu().numpy()
+
+    # ------------------------------------------------------------------ encode
+
+    def encode_frame(
+            self,
+            target: screen.Bitmap,
+            is_aux: bool,
+            budget: int = None,
+    ) -> Iterator[Tuple[int, int, List[int]]]:
+        """Converge towards target frame in priority order of edit distance.
+
+        Lazy generator, as in the reference (video.py:72-93): nothing happens until
+        the first next(); it never terminates (pads forever once out of work).
+        """
+        memory_map = self.aux_memory_map if is_aux else self.memory_map
+        update_priority = self.aux_update_priority if is_aux else self.update_priority
+
+        # Make sure nothing is leaking into screen holes (video.py:87)
+        assert np.count_nonzero(memory_map.page_offset[screen.SCREEN_HOLES]) == 0
+
+        print("Similarity %f" % (update_priority.mean()))
+
+        yield from self._index_changes(target, is_aux, budget)
+
+    def _index_changes(self, target_pixelmap, is_aux, budget):
+        class _Token:
+            started = False
+
+        token = _Token()
+        chunk = int(budget) if budget else 1
+        while True:
+            ops = self._device_steps(token, target_pixelmap, is_aux, chunk)
+            for k in range(len(ops)):
+                yield int(ops[k, 0]), int(ops[k, 1]), [int(o) for o in ops[k, 2:6]]
+            chunk = 1

@@ -1,0 +1,166 @@
+/*
+ * iivision.h -- C ABI of the MI355X (gfx950) ][-Vision transcode hot path.
+ *
+ * This is the drop-in boundary: plain C, pointers and sizes only, no torch
+ * types.  Pointers named d_* are DEVICE pointers (HBM), everything else is host
+ * memory.  `stream` is a hipStream_t passed as void* (NULL = default stream);
+ * all kernels are enqueued on it and, unless noted, calls return without
+ * synchronising.  Every function returns IIV_OK (0) or a negative error code;
+ * iiv_last_error() gives a message for the calling thread's last failure.
+ *
+ * The reference (KrisKennaway/ii-vision) is pure Python with no FFI of its own,
+ * so each entry point cites the reference Python interface it stands behind
+ * (paths relative to the reference checkout).  The host-side mirror of those
+ * interfaces lives in ii-vision_amd/transcoder/ and binds this file via ctypes
+ * (see INTEGRATION.md).
+ */
+#ifndef IIVISION_H
+#define IIVISION_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IIV_OK 0
+#define IIV_ERR_INVALID (-1)   /* bad argument                                   */
+#define IIV_ERR_HIP (-2)       /* a HIP runtime call failed                      */
+#define IIV_ERR_NO_DEVICE (-3) /* no gfx950 device visible                       */
+#define IIV_ERR_ASSERT (-4)    /* a reference `assert` would have fired          */
+#define IIV_ERR_OVERFLOW (-5)  /* internal capacity exceeded                     */
+
+/* transcoder/video_mode.py:6-8 */
+#define IIV_HGR 0
+#define IIV_DHGR 1
+
+const char *iiv_version(void);
+const char *iiv_last_error(void);
+int iiv_device_count(void);
+
+/* ---- mode constants (transcoder/screen.py:606-645, 879-919) -------------- */
+int iiv_masked_bits(int mode);       /* MASKED_BITS: HGR 14, DHGR 13          */
+int iiv_masked_dots(int mode);       /* MASKED_DOTS: HGR 18, DHGR 10          */
+int iiv_num_offsets(int mode);       /* len(BYTE_MASKS): HGR 2, DHGR 4        */
+size_t iiv_table_entries(int mode);  /* num_offsets * 2^(2*MASKED_BITS)       */
+size_t iiv_store_table_entries(int mode); /* num_offsets * 2^content_bits * 2^MASKED_BITS */
+
+/* ==== P1: make_data_tables (transcoder/make_data_tables.py) ================ */
+
+/* compute_diff_matrix (make_data_tables.py:55-70).  rgb = 16 rows x 3 bytes,
+ * row i = RGB of the palette colour whose HGRColours value is i
+ * (palette.py:37-78).  One f64 HIP thread per colour pair.  out_f = float
+ * Delta-E 2000, out_i = int() of it; either may be NULL.  Synchronises. */
+int iiv_cie2000_matrix(const uint8_t rgb[48], double out_f[256], int32_t out_i[256], void *stream);
+
+/* to_dots + dots_to_nominal_colour_pixel_values for every masked value
+ * (screen.py:743-789, 983-990; colours.py:100-148).
+ * d_dots:   [num_offsets][2^bits] u32      (may be NULL)
+ * d_pixels: [num_offsets][2^bits][masked_dots] u8, one colour value per byte */
+int iiv_pixel_strings(int mode, uint32_t *d_dots, uint8_t *d_pixels, void *stream);
+
+/* compute_edit_distance (make_data_tables.py:111-174) for one mode; dm is the
+ * 16x16 int matrix from iiv_cie2000_matrix (substitute costs follow
+ * compute_substitute_costs, make_data_tables.py:73-89).
+ * d_out: [num_offsets][2^(2*bits)] u16.
+ * symmetric != 0: the full symmetric table that Bitmap.edit_distances() returns
+ *                 after its load-time mirror (screen.py:343-367);
+ * symmetric == 0: lower triangle only (j < i), byte-identical to the array the
+ *                 reference stores in its .npz (make_data_tables.py:156-172). */
+int iiv_build_table(int mode, const int32_t dm[256], uint16_t *d_out, int symmetric, void *stream);
+
+/* Derived "store" sub-table used by the greedy loop:
+ *   S[o][content][m] = table[o][(mask(poke(m, content)) << bits) + m]
+ * i.e. every value Bitmap.compute_delta_page / byte_pair_difference
+ * (screen.py:383-398, 525-547) can ever look up, densely packed
+ * (DHGR 4x128x8192, HGR 2x256x16384 u16). */
+int iiv_build_store_table(int mode, const int32_t dm[256], uint16_t *d_out, void *stream);
+
+/* ==== P2: screen.Bitmap operations, batched over n independent screens ===== */
+/* Memory maps are (32,256) u8 page/offset arrays (screen.MemoryMap,
+ * screen.py:101-125); d_aux is ignored (may be NULL) for HGR. */
+
+/* Bitmap._pack (screen.py:207-226): d_packed [n][32][128] u64 */
+int iiv_pack(int mode, int n, const uint8_t *d_main, const uint8_t *d_aux, uint64_t *d_packed,
+             void *stream);
+
+/* Bitmap.diff_weights (screen.py:400-449) from packed source/target:
+ * d_out [n][32][256] i32. */
+int iiv_diff_weights(int mode, const uint16_t *d_table, int n, const uint64_t *d_src_packed,
+                     const uint64_t *d_tgt_packed, int is_aux, int32_t *d_out, void *stream);
+
+/* Bitmap.compute_delta_page (screen.py:525-547) for n (page, content) queries
+ * against ONE target bitmap: d_pages[n], d_contents[n] i32, d_dw_rows [n][256]
+ * i32 (the diff_weights row of each query's page), d_out [n][256] i32. */
+int iiv_compute_delta_pages(int mode, const uint16_t *d_table, int n, const uint64_t *d_tgt_packed,
+                            const int32_t *d_pages, const int32_t *d_contents,
+                            const int32_t *d_dw_rows, int is_aux, int32_t *d_out, void *stream);
+
+/* ==== P3: video.Video (transcoder/video.py:16-301) ========================= */
+
+typedef struct iiv_encoder iiv_encoder;
+
+/* One encoder = n_streams independent Video objects of one (mode, palette),
+ * all state resident in HBM.  d_table = full symmetric table, d_store_table =
+ * iiv_build_store_table output; both must outlive the encoder.
+ * Initial state = Video.__init__ (video.py:21-62): blank screen, zero
+ * priorities; both RNG streams seeded as random.seed(0) / np.random.seed(0)
+ * until set with iiv_encoder_set_state. */
+int iiv_encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store_table,
+                       int n_streams, iiv_encoder **out);
+void iiv_encoder_destroy(iiv_encoder *enc);
+
+/* state items, per stream */
+#define IIV_STATE_MEM_MAIN 0 /* Video.memory_map.page_offset        u8  [32][256] */
+#define IIV_STATE_MEM_AUX 1  /* Video.aux_memory_map.page_offset    u8  [32][256] */
+#define IIV_STATE_UP_MAIN 2  /* Video.update_priority               i32 [32][256] */
+#define IIV_STATE_UP_AUX 3   /* Video.aux_update_priority           i32 [32][256] */
+#define IIV_STATE_RNG_PY 4   /* random.getstate()[1]: 624 words + index, u32[625] */
+#define IIV_STATE_RNG_NP 5   /* np.random.get_state()[1], [2]:      u32[625]      */
+#define IIV_STATE_OUT_OF_WORK 6 /* Video.out_of_work {False,True}   i32[2]        */
+#define IIV_STATE_PACKED 7   /* Video.pixelmap.packed (get only)    u64 [32][128] */
+#define IIV_STATE_COUNTERS 8 /* get only: u64[4] = draws_py, draws_np, ops, pad_ops */
+int iiv_encoder_get_state(iiv_encoder *enc, int stream_index, int what, void *host_buf, size_t bytes);
+int iiv_encoder_set_state(iiv_encoder *enc, int stream_index, int what, const void *host_buf, size_t bytes);
+
+/* One segment = what movie.py does between two generator creations:
+ * `op_seq = video.encode_frame(target, is_aux)` (if restart) followed by n_ops
+ * calls of next(op_seq) (movie.py:94-109).  restart == 0 continues the
+ * generator created by the previous segment (same target, same bank). */
+typedef struct {
+    int32_t frame;   /* index into the frame arrays: the target of this segment */
+    int32_t is_aux;  /* bank (video.py:79-84); must be 0 for HGR                */
+    int32_t restart; /* 1 = new generator (prologue runs on the first next())   */
+    int32_t n_ops;   /* number of next() calls                                  */
+} iiv_segment;
+
+/* Video.encode_frame / _index_changes / _heapify_priorities / _compute_error
+ * (video.py:72-301) for every stream of the encoder, all segments, in stream
+ * order on `stream`.
+ * d_frames_main / d_frames_aux: [n_streams][n_frames][32][256] u8 target
+ *   memory maps (aux may be NULL for HGR).
+ * d_ops_out: [n_streams][sum(n_ops)][6] u8 = (page+32, content, o0, o1, o2, o3)
+ *   per yielded tuple (video.py:187, 251).
+ * A segment with n_ops == 0 has no effect (the generator is lazy).
+ * Does not synchronise; iiv_encoder_check() reports asynchronous failures. */
+int iiv_encode(iiv_encoder *enc, const uint8_t *d_frames_main, const uint8_t *d_frames_aux,
+               int n_frames, const iiv_segment *segments, int n_segments, uint8_t *d_ops_out,
+               void *stream);
+
+/* Synchronises `stream` and returns IIV_ERR_ASSERT / IIV_ERR_OVERFLOW if any
+ * stream hit one of the reference's asserts (video.py:87,117,124,137,154-155)
+ * or an internal capacity limit; *bad_stream (may be NULL) gets its index. */
+int iiv_encoder_check(iiv_encoder *enc, int *bad_stream, void *stream);
+
+/* Kernel timing with HIP events recorded on the launch stream.
+ * iiv_encoder_profile(enc, 1) starts collecting; iiv_encoder_profile_read
+ * synchronises and returns accumulated milliseconds and launch counts for
+ * kernel class 0 = prologue (diff/rank), 1 = greedy (select). */
+int iiv_encoder_profile(iiv_encoder *enc, int enable);
+int iiv_encoder_profile_read(iiv_encoder *enc, double ms[2], int64_t launches[2]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,56 @@
+"""CPU: the C-ABI library loads and exports every symbol include/iivision.h
+declares (no compute calls -- there is no GPU here), and the host layer refuses
+to run without a GPU instead of falling back."""
+
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "iivision.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(iiv_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_symbols_exported(native):
+    syms = _declared_symbols()
+    assert len(syms) >= 20
+    L = ctypes.CDLL(native.LIB_PATH)
+    for s in syms:
+        assert hasattr(L, s), "libiivision.so does not export %s" % s
+    assert set(syms) == set(native.SYMBOLS)
+
+
+def test_constants_without_gpu(native):
+    L = native.lib()
+    assert L.iiv_version().startswith(b"iivision")
+    assert (L.iiv_masked_bits(0), L.iiv_masked_bits(1)) == (14, 13)
+    assert (L.iiv_masked_dots(0), L.iiv_masked_dots(1)) == (18, 10)
+    assert (L.iiv_num_offsets(0), L.iiv_num_offsets(1)) == (2, 4)
+    assert L.iiv_table_entries(0) == 2 << 28 and L.iiv_table_entries(1) == 4 << 26
+    assert L.iiv_store_table_entries(0) == 2 << 22 and L.iiv_store_table_entries(1) == 4 << 20
+
+
+def test_no_cpu_fallback(native):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        native.cie2000_matrix([[0, 0, 0]] * 16)
+    with pytest.raises(RuntimeError):
+        native.build_table(1, [0] * 256)
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under ii-vision_amd/ may mention it."""
+    pkg = os.path.join(ROOT, "ii-vision_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, fn), errors="replace").read()
+                assert "import oracle" not in txt and "liboracle" not in txt and "iiv_oracle.h" not in txt, fn

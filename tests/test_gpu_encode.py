@@ -1,0 +1,183 @@
+"""GPU: video.Video.encode_frame (P3) through the C ABI.
+
+Bit-exact against (a) opcode streams / final state / RNG positions recorded from
+the imported reference (tests/golden/g3_encode_runs.npz) and (b) the oracle on
+fresh seeded inputs, including batches of independent streams."""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N = None
+
+
+def _tags(g3):
+    return sorted(set(k.split("/")[0] for k in g3.files))
+
+
+def _seed_states(O, seed_py, seed_np):
+    return O.mt_seed_py(seed_py).state_words(), O.mt_seed_np(seed_np).state_words()
+
+
+def _run_device(native, device_tables, mode, pal, frames_list, sched, seeds):
+    """frames_list: list (per stream) of (n_frames, banks, 32, 256) arrays."""
+    import torch
+    t, s = device_tables.get(mode, pal)
+    n = len(frames_list)
+    enc = native.Encoder(mode, t, s, n)
+    fr = np.stack(frames_list)
+    fm = torch.from_numpy(np.ascontiguousarray(fr[:, :, 0])).cuda()
+    fa = torch.from_numpy(np.ascontiguousarray(fr[:, :, 1])).cuda() if mode == 1 else None
+    for i, (py, npw) in enumerate(seeds):
+        enc.set_state(native.STATE_RNG_PY, py, i)
+        enc.set_state(native.STATE_RNG_NP, npw, i)
+    segs = [(int(f), int(a), 1, int(k)) for (f, a, k) in sched]
+    ops = enc.encode(fm, fa, segs)
+    enc.check()
+    return enc, ops.cpu().numpy()
+
+
+def _next_draws(O, words, n, high):
+    m = O.MT()
+    m.set_state_words(words)
+    L = O.lib()
+    f = L.orc_py_getrandbits8 if high else L.orc_np_randint256
+    return [f(C.byref(m)) for _ in range(n)]
+
+
+def test_golden_runs(native, O, golden, device_tables):
+    g3 = golden.g3_encode_runs
+    for tag in _tags(g3):
+        mode, pal, sp, sn = (int(x) for x in g3[tag + "/meta"])
+        frames, sched, ops = g3[tag + "/frames"], g3[tag + "/schedule"], g3[tag + "/ops"]
+        enc, got = _run_device(native, device_tables, mode, pal, [frames], sched, [_seed_states(O, sp, sn)])
+        bad = np.nonzero((got[0] != ops).any(axis=1))[0]
+        assert len(bad) == 0, "%s: first mismatch at op %d: got %s want %s" % (
+            tag, bad[0], got[0][bad[0]], ops[bad[0]])
+        assert (enc.get_state(native.STATE_MEM_MAIN) == g3[tag + "/mem_main"]).all(), tag
+        assert (enc.get_state(native.STATE_UP_MAIN) == g3[tag + "/up_main"]).all(), tag
+        assert (enc.get_state(native.STATE_PACKED) == g3[tag + "/packed"]).all(), tag
+        if mode == 1:
+            assert (enc.get_state(native.STATE_MEM_AUX) == g3[tag + "/mem_aux"]).all(), tag
+            assert (enc.get_state(native.STATE_UP_AUX) == g3[tag + "/up_aux"]).all(), tag
+        assert enc.get_state(native.STATE_OUT_OF_WORK).tolist() == g3[tag + "/out_of_work"].tolist(), tag
+        assert _next_draws(O, enc.get_state(native.STATE_RNG_PY), 4, True) == g3[tag + "/py_next"].tolist(), tag
+        assert _next_draws(O, enc.get_state(native.STATE_RNG_NP), 4, False) == g3[tag + "/np_next"].tolist(), tag
+        enc.close()
+
+
+def _synth(mode, n_frames, seed, coherent=False):
+    holes = (np.arange(256) & 127) >= 120
+    rng = np.random.default_rng(seed)
+    hi = 128 if mode == 1 else 256
+    banks = 2 if mode == 1 else 1
+    fr = np.zeros((n_frames, 2, 32, 256), np.uint8)
+    prev = None
+    for f in range(n_frames):
+        cur = []
+        for b in range(banks):
+            new = rng.integers(0, hi, (32, 256), dtype=np.uint8)
+            if coherent and prev is not None:
+                new = np.where(rng.random((32, 256)) < 0.9, prev[b], new)
+            new[:, holes] = 0
+            cur.append(new)
+        prev = cur
+        for b in range(banks):
+            fr[f, b] = cur[b]
+    return fr
+
+
+def _oracle_run(O, oracle_tables, mode, pal, frames, sched, sp, sn):
+    v = O.Video(mode, oracle_tables.get(mode, pal), seed_py=sp, seed_np=sn)
+    out = []
+    for fi, ia, n in sched:
+        v.encode_frame(frames[fi, 0], frames[fi, 1] if mode == 1 else None, ia)
+        out.append(v.next(int(n)))
+    return v, np.concatenate(out)
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_batch_of_independent_streams(native, O, oracle_tables, device_tables, mode):
+    """12 streams with different data / seeds / coherence in ONE launch sequence,
+    ragged segment lengths incl. bank flips; every stream equals its own oracle run."""
+    n = 12
+    sched = [(0, 0, 37), (0, 1 if mode == 1 else 0, 291), (1, 0, 200), (1, 1 if mode == 1 else 0, 1), (2, 0, 490)]
+    frames = [_synth(mode, 3, 100 + i, coherent=(i % 2 == 1)) for i in range(n)]
+    seeds = [(i + 1, 1000 + i) for i in range(n)]
+    enc, got = _run_device(native, device_tables, mode, 5, frames, sched,
+                           [_seed_states(O, a, b) for a, b in seeds])
+    for i in range(n):
+        v, exp = _oracle_run(O, oracle_tables, mode, 5, frames[i], sched, *seeds[i])
+        assert (got[i] == exp).all(), "stream %d" % i
+        assert (enc.get_state(native.STATE_MEM_MAIN, i) == v.memory(0)).all()
+        assert (enc.get_state(native.STATE_UP_MAIN, i) == v.update_priority(0)).all()
+        assert (enc.get_state(native.STATE_PACKED, i) == v.packed).all()
+        cnt = enc.get_state(native.STATE_COUNTERS, i)
+        assert (int(cnt[0]), int(cnt[1])) == v.draws()
+    enc.close()
+
+
+def test_continue_generator_and_lazy_segments(native, O, oracle_tables, device_tables):
+    """restart=0 continues the same generator; an n_ops=0 restart segment is lazy
+    (no side effects until the first next())."""
+    import torch
+    mode = 1
+    frames = _synth(mode, 2, 77)
+    t, s = device_tables.get(mode)
+    enc = native.Encoder(mode, t, s, 1)
+    py, npw = _seed_states(O, 3, 4)
+    enc.set_state(native.STATE_RNG_PY, py)
+    enc.set_state(native.STATE_RNG_NP, npw)
+    fm = torch.from_numpy(frames[None, :, 0].copy()).cuda()
+    fa = torch.from_numpy(frames[None, :, 1].copy()).cuda()
+    segs = [(0, 0, 1, 10), (0, 0, 0, 5), (0, 0, 0, 1), (1, 1, 1, 0), (1, 1, 0, 7), (1, 1, 0, 3)]
+    got = enc.encode(fm, fa, segs).cpu().numpy()[0]
+    enc.check()
+    v = O.Video(mode, oracle_tables.get(mode), seed_py=3, seed_np=4)
+    v.encode_frame(frames[0, 0], frames[0, 1], 0)
+    a = v.next(16)
+    v.encode_frame(frames[1, 0], frames[1, 1], 1)
+    b = v.next(10)
+    assert (got == np.concatenate([a, b])).all()
+    enc.close()
+
+
+def test_idempotent_when_converged(native, O, device_tables):
+    """Property: once a bank is exhausted, re-encoding the same target emits only
+    padding opcodes (32, target[0,0], 0,0,0,0) and changes nothing."""
+    import torch
+    mode = 0
+    frames = _synth(mode, 1, 5)
+    t, s = device_tables.get(mode)
+    enc = native.Encoder(mode, t, s, 1)
+    fm = torch.from_numpy(frames[None, :, 0].copy()).cuda()
+    enc.encode(fm, None, [(0, 0, 1, 7000)])
+    enc.check()
+    assert enc.get_state(native.STATE_OUT_OF_WORK)[0] == 1
+    mem = enc.get_state(native.STATE_MEM_MAIN).copy()
+    ops = enc.encode(fm, None, [(0, 0, 1, 50)]).cpu().numpy()[0]
+    assert (ops[:, 0] == 32).all() and (ops[:, 1] == frames[0, 0, 0, 0]).all() and (ops[:, 2:] == 0).all()
+    assert (enc.get_state(native.STATE_MEM_MAIN) == mem).all()
+    assert (enc.get_state(native.STATE_UP_MAIN) == 0).all()
+    enc.close()
+
+
+def test_reference_asserts_are_reported(native, device_tables):
+    """video.py:137: a DHGR content byte with the palette bit set is an error, not silent."""
+    import torch
+    t, s = device_tables.get(1)
+    enc = native.Encoder(1, t, s, 2)
+    fm = torch.zeros((2, 1, 32, 256), dtype=torch.uint8, device="cuda")
+    fa = torch.zeros((2, 1, 32, 256), dtype=torch.uint8, device="cuda")
+    fm[1, 0, 3, 5] = 0x85
+    enc.encode(fm, fa, [(0, 0, 1, 20)])
+    with pytest.raises(AssertionError):
+        enc.check()
+    enc.close()
+    enc = native.Encoder(1, t, s, 1)
+    with pytest.raises(native.IIVError):
+        enc.encode(fm[:1], fa[:1], [(0, 0, 0, 5)])  # continues a generator that does not exist
+    enc.close()

@@ -1,0 +1,91 @@
+"""GPU: make_data_tables kernels (P1) through the C ABI against the oracle and the
+golden vectors.  Integer outputs bit-exact; the float CIE2000 matrix within 1e-5
+(the tolerance BASELINE.json's north_star states)."""
+
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("pal", [5, 0])
+def test_cie2000_matrix(native, O, golden, pal):
+    f, i = native.cie2000_matrix(O.PALETTE_RGB[pal])
+    fo, io = O.cie2000_matrix(O.PALETTE_RGB[pal])
+    assert np.abs(f - fo).max() < 1e-5
+    assert (i == io).all()
+    assert (i == golden.g5_tables["dm_i_%d" % pal]).all()
+    assert np.abs(f - golden.g5_tables["dm_f_%d" % pal]).max() < 1e-5
+    # knife edge: black <-> white truncates to 99
+    assert i[0, 15] == 99
+
+
+@pytest.mark.parametrize("mode,name", [(0, "HGR"), (1, "DHGR")])
+def test_pixel_strings_all_values(native, golden, mode, name):
+    """K1 against the reference's to_dots + colour model for EVERY masked value."""
+    g = golden.g2_dots_pixels
+    dots, pix = native.pixel_strings(mode)
+    assert (dots.cpu().numpy().view(np.uint32) == g[name + "_dots"]).all()
+    assert (pix.cpu().numpy() == g[name + "_pixels"]).all()
+
+
+@pytest.mark.parametrize("mode,name", [(1, "DHGR"), (0, "HGR")])
+def test_full_table_bit_exact(native, oracle_tables, device_tables, mode, name):
+    """K2: the whole symmetric table (DHGR 4x2^26, HGR 2x2^28 u16) equals the oracle's."""
+    t, _ = device_tables.get(mode)
+    got = native.table_to_numpy(t)
+    exp = oracle_tables.get(mode)
+    assert got.shape == exp.shape
+    assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("mode,name,pal", [(1, "DHGR", 5), (0, "HGR", 5), (1, "DHGR", 0), (0, "HGR", 0)])
+def test_lower_triangle_file_format(native, golden, dms, mode, name, pal):
+    """symmetric=0 reproduces the array the reference stores in its .npz byte for
+    byte (sha256 + sum + 10^4 samples recorded by make_golden.py)."""
+    g5 = golden.g5_tables
+    t = native.table_to_numpy(native.build_table(mode, dms[pal], symmetric=False))
+    assert hashlib.sha256(t.tobytes()).digest() == g5["%s_%d_lower_sha256" % (name, pal)].tobytes()
+    assert int(t.astype(np.uint64).sum()) == int(g5["%s_%d_lower_sum" % (name, pal)][0])
+    o, idx = g5["%s_%d_sample_o" % (name, pal)], g5["%s_%d_sample_idx" % (name, pal)]
+    assert (t[o, idx] == g5["%s_%d_sample_val" % (name, pal)]).all()
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_store_table(native, oracle_tables, device_tables, mode):
+    """S[o][content][m] == table[o][(poke(m, content) << bits) + m] for every entry."""
+    _, s = device_tables.get(mode)
+    L = native.lib()
+    bits, noff = L.iiv_masked_bits(mode), L.iiv_num_offsets(mode)
+    cb = 7 if mode == 1 else 8
+    got = native.table_to_numpy(s).reshape(noff, 1 << cb, 1 << bits)
+    full = oracle_tables.get(mode)
+    m = np.arange(1 << bits, dtype=np.int64)
+    for o in range(noff):
+        for c in range(1 << cb):
+            if mode == 1:
+                pm = (m & ~(0x7f << 3)) | ((c & 0x7f) << 3)
+            elif o == 0:
+                pm = (m & ~(0xff << 3)) | (c << 3)
+            else:
+                pm = (m & ~(0xff << 3)) | ((((c & 0x7f) << 1) | (c >> 7)) << 3)
+            assert np.array_equal(got[o, c], full[o, (pm << bits) + m]), (o, c)
+
+
+def test_table_symmetry_properties(native, device_tables):
+    """Size-independent properties on the device table itself: symmetric, zero diagonal."""
+    import torch
+    t, _ = device_tables.get(1)
+    for o in range(4):
+        m = t[o].view(8192, 8192)
+        assert bool((m == m.T).all())
+        assert int(torch.diagonal(m).abs().sum()) == 0
+
+
+def test_rejects_bad_arguments(native):
+    with pytest.raises(native.IIVError):
+        native.build_table(1, np.full(256, 500, np.int32))  # 500*10 > 2047
+    with pytest.raises(native.IIVError):
+        native.build_table(7, np.zeros(256, np.int32))
