@@ -29,6 +29,7 @@
 // random.getrandbits(8) (high byte) and np.random.randint(0,256,n) (low byte)
 // advance them (video.py:178,265,291).
 #include "iiv_host.h"
+#include "iiv_edit.h"
 
 #include <stdlib.h>
 #include <vector>
@@ -59,20 +60,87 @@ enum { kErrNone = 0, kErrHoles = 1, kErrNegative = 2, kErrPaletteBit = 3, kErrPu
 
 constexpr int kProThreads = 1024;
 
-template <int MODE>
+// Bitonic sort of 8*NT u64 keys, 8 consecutive elements per thread.  Exchange
+// distances 1,2,4 stay inside a thread's registers, 8..256 are wave shuffles, and
+// only distances >= 512 (10 of the 91 stages at 8192 keys) go through LDS.
+__device__ static inline void cmpx(unsigned long long &lo, unsigned long long &hi, bool asc)
+{
+    bool sw = (lo > hi) == asc;
+    unsigned long long t = lo;
+    lo = sw ? hi : lo;
+    hi = sw ? t : hi;
+}
+
+template <int NT>
+__device__ static inline void bitonic_sort8(unsigned long long (&v)[8], unsigned long long *xbuf, int tid)
+{
+    constexpr int N = 8 * NT;
+#pragma unroll
+    for (int k = 2; k <= 8; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j >= 1; j >>= 1) {
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+                if ((r & j) == 0) cmpx(v[r], v[r | j], (((8 * tid + r) & k) == 0));
+        }
+    }
+    for (int k = 16; k <= N; k <<= 1) {
+        const bool asc = ((8 * tid) & k) == 0;
+        for (int j = k >> 1; j >= 8; j >>= 1) {
+            const int d = j >> 3;
+            const bool take_min = ((tid & d) == 0) == asc;
+            if (d < 64) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    unsigned long long p = __shfl_xor(v[r], d, 64);
+                    v[r] = take_min ? (p < v[r] ? p : v[r]) : (p > v[r] ? p : v[r]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; r++) xbuf[r * NT + tid] = v[r];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    unsigned long long p = xbuf[r * NT + (tid ^ d)];
+                    v[r] = take_min ? (p < v[r] ? p : v[r]) : (p > v[r] ? p : v[r]);
+                }
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int j = 4; j >= 1; j >>= 1) {
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+                if ((r & j) == 0) cmpx(v[r], v[r | j], asc);
+        }
+    }
+}
+
+// DP == false: diff weights are gathered from the precomputed table (one random
+// HBM line per screen byte).  DP == true: they are recomputed by running the
+// edit-distance recurrence on the two colour strings (an L2-resident 16 B LUT
+// entry each) -- bit-identical by construction (same recurrence that built the
+// table), and far cheaper than an HBM line fetch per byte.
+template <int MODE, bool DP>
 __global__ __launch_bounds__(kProThreads) void prologue_kernel(StreamState *__restrict__ states,
                                                                const uint8_t *__restrict__ frames_main,
                                                                const uint8_t *__restrict__ frames_aux, int n_frames,
                                                                int frame, int is_aux,
-                                                               const uint16_t *__restrict__ table)
+                                                               const uint16_t *__restrict__ table,
+                                                               const ulonglong2 *__restrict__ strings,
+                                                               const uint16_t *__restrict__ sub)
 {
     constexpr int BITS = ModeTraits<MODE>::kBits;
     constexpr int NB = ModeTraits<MODE>::kBanks;
-    __shared__ __attribute__((aligned(16))) uint8_t cur[NB][8192];
-    __shared__ __attribute__((aligned(16))) uint8_t tgt[NB][8192];
-    __shared__ unsigned long long keys[8192];
+    // One 64 KiB region, used first for the staged memory maps (cur | tgt), then --
+    // once every diff weight is in registers -- as the sort's exchange buffer.
+    __shared__ __attribute__((aligned(16))) unsigned char smem[65536];
+    uint8_t(*cur)[8192] = reinterpret_cast<uint8_t(*)[8192]>(smem);
+    uint8_t(*tgt)[8192] = reinterpret_cast<uint8_t(*)[8192]>(smem + NB * 8192);
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);
     __shared__ uint8_t nonce[8192];
     __shared__ uint32_t mtb[2][624];
+    __shared__ uint16_t lut[256];
     __shared__ uint32_t wsum[kProThreads / 64];
     __shared__ int flag_bad;
 
@@ -89,6 +157,7 @@ __global__ __launch_bounds__(kProThreads) void prologue_kernel(StreamState *__re
         reinterpret_cast<uint4 *>(tgt[b])[k] = reinterpret_cast<const uint4 *>(src)[k];
     }
     for (int i = tid; i < 624; i += kProThreads) mtb[0][i] = S.mt_np[i];
+    if (DP && tid < 256) lut[tid] = sub[tid];
     __syncthreads();
 
     // 8 consecutive bytes of one page row per thread (row-major, as nonzero() walks them)
@@ -122,8 +191,17 @@ __global__ __launch_bounds__(kProThreads) void prologue_kernel(StreamState *__re
         neighbours<MODE>(tgt_own, tgt_oth, y, is_aux, tp, tn);
         uint32_t cm = masked_window<MODE>(cp, cur_own[y], cn, odd);
         uint32_t tm = masked_window<MODE>(tp, tgt_own[y], tn, odd);
-        // screen.py:441-443: pair = (source << bits) + target
-        dwv[j] = table[((size_t)o << (2 * BITS)) + ((size_t)cm << BITS) + tm];
+        if (DP) {
+            dwv[j] = 0;
+            if (cm != tm) {
+                const ulonglong2 *Sg = strings + ((size_t)o << BITS);
+                ulonglong2 a = Sg[cm], b = Sg[tm];
+                dwv[j] = edit_distance<ModeTraits<MODE>::kDots>(a.x, (uint32_t)a.y, b.x, (uint32_t)b.y, lut);
+            }
+        } else {
+            // screen.py:441-443: pair = (source << bits) + target
+            dwv[j] = table[((size_t)o << (2 * BITS)) + ((size_t)cm << BITS) + tm];
+        }
     }
     uint32_t nzmask = 0;
 #pragma unroll
@@ -196,40 +274,31 @@ __global__ __launch_bounds__(kProThreads) void prologue_kernel(StreamState *__re
         }
     }
 
-    // keys (-priority, nonce, page, offset) -> ascending u64 (video.py:259-268)
+    // keys (-priority, nonce, page, offset) -> ascending u64 (video.py:259-268); bytes
+    // whose priority is zero get the all-ones key and sink to the end
+    unsigned long long kv[8];
     {
         int r = rank0;
 #pragma unroll
-        for (int j = 0; j < 8; j++)
+        for (int j = 0; j < 8; j++) {
+            kv[j] = ~0ull;
             if (nzmask & (1u << j)) {
-                unsigned long long k = ((unsigned long long)(0x7fffffffu - (uint32_t)upv[j]) << 21) |
-                                       ((unsigned long long)nonce[r] << 13) | (unsigned long long)(i0 + j);
-                keys[r] = k;
+                kv[j] = ((unsigned long long)(0x7fffffffu - (uint32_t)upv[j]) << 21) |
+                        ((unsigned long long)nonce[r] << 13) | (unsigned long long)(i0 + j);
                 r++;
             }
-    }
-    int N = 64;
-    while (N < n) N <<= 1;
-    __syncthreads();
-    for (int i = n + tid; i < N; i += kProThreads) keys[i] = ~0ull;
-    __syncthreads();
-    // bitonic sort of N keys in LDS
-    for (int k = 2; k <= N; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < (N >> 1); t += kProThreads) {
-                int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                int hi = lo | j;
-                unsigned long long a = keys[lo], b = keys[hi];
-                bool asc = (lo & k) == 0;
-                if ((a > b) == asc) {
-                    keys[lo] = b;
-                    keys[hi] = a;
-                }
-            }
-            __syncthreads();
         }
     }
-    for (int i = tid; i < n; i += kProThreads) S.order[i] = (uint16_t)(keys[i] & 0x1fff);
+    // (the scan's barrier above already separates the last read of cur/tgt from this reuse)
+    bitonic_sort8<kProThreads>(kv, keys, tid);
+    {
+        uint4 o;
+        o.x = (uint32_t)(kv[0] & 0x1fff) | ((uint32_t)(kv[1] & 0x1fff) << 16);
+        o.y = (uint32_t)(kv[2] & 0x1fff) | ((uint32_t)(kv[3] & 0x1fff) << 16);
+        o.z = (uint32_t)(kv[4] & 0x1fff) | ((uint32_t)(kv[5] & 0x1fff) << 16);
+        o.w = (uint32_t)(kv[6] & 0x1fff) | ((uint32_t)(kv[7] & 0x1fff) << 16);
+        *reinterpret_cast<uint4 *>(S.order + i0) = o;  // entries >= n are never read
+    }
     if (tid == 0) {
         S.n_sorted = n;
         S.head = 0;
@@ -260,7 +329,6 @@ __global__ __launch_bounds__(256) void greedy_kernel(StreamState *__restrict__ s
     constexpr uint32_t INF = 0xffffffffu;
     __shared__ __attribute__((aligned(16))) uint8_t tgt[NB][8192];  // [0] = bank being encoded, [1] = the other one
     __shared__ __attribute__((aligned(16))) uint16_t dwf[8192];     // diff_weight | (priority != 0) << 15
-    __shared__ __attribute__((aligned(16))) uint16_t order[8192];
     __shared__ uint32_t mt[2][624];
     __shared__ uint32_t xw_cnt[4];
     __shared__ uint32_t xw_key[8];
@@ -296,7 +364,6 @@ __global__ __launch_bounds__(256) void greedy_kernel(StreamState *__restrict__ s
         d.z |= (u1.x ? 0x8000u : 0u) | (u1.y ? 0x80000000u : 0u);
         d.w |= (u1.z ? 0x8000u : 0u) | (u1.w ? 0x80000000u : 0u);
         reinterpret_cast<uint4 *>(dwf)[i] = d;
-        reinterpret_cast<uint4 *>(order)[i] = reinterpret_cast<const uint4 *>(S.order)[i];
     }
     for (int i = tid; i < 624; i += 256) mt[0][i] = S.mt_py[i];
     __syncthreads();
@@ -347,7 +414,7 @@ __global__ __launch_bounds__(256) void greedy_kernel(StreamState *__restrict__ s
         __syncthreads();  // validity flags written by their owner lanes -> visible to the scan
         if (head < n_sorted) {
             int idx = head + lane;
-            uint32_t e = idx < n_sorted ? (uint32_t)order[idx] : 0u;
+            uint32_t e = idx < n_sorted ? (uint32_t)S.order[idx] : 0u;
             bool v = idx < n_sorted && (dwf[e] & 0x8000u);
             unsigned long long mask = __ballot(v);
             int window_end = head + 64 < n_sorted ? head + 64 : n_sorted;
@@ -568,6 +635,9 @@ struct Encoder {
     int n_streams;
     const uint16_t *d_table;
     const uint16_t *d_store;
+    ulonglong2 *d_strings;  // colour string of every masked value (recurrence mode)
+    uint16_t *d_sub;        // 16x16 substitute costs
+    int dw_mode;            // IIV_DW_TABLE / IIV_DW_RECURRENCE
     StreamState *d_states;
     // generator bookkeeping shared by all streams (same schedule)
     int gen_active, gen_is_aux, gen_frame;
@@ -604,9 +674,10 @@ static void seed_genrand(uint32_t mt[624], uint32_t s)
     for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
 }
 
-int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, int n_streams, Encoder **out)
+int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, const int32_t *dm, int n_streams,
+                   Encoder **out)
 {
-    if ((mode != kHGR && mode != kDHGR) || !d_table || !d_store || n_streams <= 0 || !out)
+    if ((mode != kHGR && mode != kDHGR) || (!d_table && !dm) || !d_store || n_streams <= 0 || !out)
         return set_error(IIV_ERR_INVALID, "iiv_encoder_create: bad argument");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -617,6 +688,9 @@ int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, i
     e->d_table = d_table;
     e->d_store = d_store;
     e->d_states = nullptr;
+    e->d_strings = nullptr;
+    e->d_sub = nullptr;
+    e->dw_mode = dm ? IIV_DW_RECURRENCE : IIV_DW_TABLE;
     e->gen_active = 0;
     e->gen_is_aux = 0;
     e->gen_frame = 0;
@@ -627,6 +701,14 @@ int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, i
     if (he != hipSuccess) {
         delete e;
         return hip_check(he, "hipMalloc(stream states)");
+    }
+    if (dm) {
+        int rc = build_strings(mode, dm, &e->d_strings, &e->d_sub, 0);
+        if (rc) {
+            (void)hipFree(e->d_states);
+            delete e;
+            return rc;
+        }
     }
     // Video.__init__ (video.py:21-62): blank screen, zero priorities.  RNG
     // streams default to random.seed(0) / np.random.seed(0).
@@ -654,7 +736,23 @@ void encoder_destroy(Encoder *e)
     if (!e) return;
     for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
     if (e->d_states) (void)hipFree(e->d_states);
+    if (e->d_strings) (void)hipFree(e->d_strings);
+    if (e->d_sub) (void)hipFree(e->d_sub);
     delete e;
+}
+
+int encoder_set_option(Encoder *e, int option, int value)
+{
+    if (!e) return set_error(IIV_ERR_INVALID, "set_option: null encoder");
+    if (option == IIV_OPT_DIFF_WEIGHTS) {
+        if (value == IIV_DW_TABLE && !e->d_table) return set_error(IIV_ERR_INVALID, "no table was given at creation");
+        if (value == IIV_DW_RECURRENCE && !e->d_strings)
+            return set_error(IIV_ERR_INVALID, "no diff matrix was given at creation");
+        if (value != IIV_DW_TABLE && value != IIV_DW_RECURRENCE) return set_error(IIV_ERR_INVALID, "bad value");
+        e->dw_mode = value;
+        return IIV_OK;
+    }
+    return set_error(IIV_ERR_INVALID, "unknown option %d", option);
 }
 
 static int state_item(int mode, int what, size_t &off, size_t &bytes, bool &writable)
@@ -825,12 +923,16 @@ int encode(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux, int n_frames
         size_t slot = 0;
         if (need_prologue) {
             if (e->profiling) { int prc = prof_begin(e, 0, st, slot); if (prc) return prc; }
-            if (e->mode == kDHGR)
-                hipLaunchKernelGGL(prologue_kernel<kDHGR>, dim3(e->n_streams), dim3(kProThreads), 0, st, e->d_states,
-                                   d_main, d_aux, n_frames, g.frame, g.is_aux, e->d_table);
-            else
-                hipLaunchKernelGGL(prologue_kernel<kHGR>, dim3(e->n_streams), dim3(kProThreads), 0, st, e->d_states,
-                                   d_main, d_aux, n_frames, g.frame, g.is_aux, e->d_table);
+            const bool dp = e->dw_mode == IIV_DW_RECURRENCE;
+#define IIV_PRO(M, D)                                                                                              \
+    hipLaunchKernelGGL((prologue_kernel<M, D>), dim3(e->n_streams), dim3(kProThreads), 0, st, e->d_states, d_main, \
+                       d_aux, n_frames, g.frame, g.is_aux, e->d_table, e->d_strings, e->d_sub)
+            if (e->mode == kDHGR) {
+                if (dp) IIV_PRO(kDHGR, true); else IIV_PRO(kDHGR, false);
+            } else {
+                if (dp) IIV_PRO(kHGR, true); else IIV_PRO(kHGR, false);
+            }
+#undef IIV_PRO
             IIV_HIP(hipGetLastError());
             if (e->profiling) { int prc = prof_end(e, slot, st); if (prc) return prc; }
         }
@@ -903,12 +1005,12 @@ struct iiv_encoder {
 
 extern "C" {
 
-int iiv_encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store_table, int n_streams,
-                       iiv_encoder **out)
+int iiv_encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store_table, const int32_t dm[256],
+                       int n_streams, iiv_encoder **out)
 {
     if (!out) return iiv::set_error(IIV_ERR_INVALID, "iiv_encoder_create: out is NULL");
     iiv::Encoder *impl = nullptr;
-    int rc = iiv::encoder_create(mode, d_table, d_store_table, n_streams, &impl);
+    int rc = iiv::encoder_create(mode, d_table, d_store_table, dm, n_streams, &impl);
     if (rc) return rc;
     *out = new iiv_encoder{impl};
     return IIV_OK;
@@ -919,6 +1021,12 @@ void iiv_encoder_destroy(iiv_encoder *enc)
     if (!enc) return;
     iiv::encoder_destroy(enc->impl);
     delete enc;
+}
+
+int iiv_encoder_set_option(iiv_encoder *enc, int option, int value)
+{
+    if (!enc) return iiv::set_error(IIV_ERR_INVALID, "null encoder");
+    return iiv::encoder_set_option(enc->impl, option, value);
 }
 
 int iiv_encoder_get_state(iiv_encoder *enc, int stream_index, int what, void *host_buf, size_t bytes)

@@ -26,6 +26,7 @@ int cie2000_matrix(const uint8_t rgb[48], double out_f[256], int32_t out_i[256],
 int pixel_strings(int mode, uint32_t *d_dots, uint8_t *d_pixels, ulonglong2 *d_strings, hipStream_t st);
 int build_table(int mode, const int32_t dm[256], uint16_t *d_out, int symmetric, hipStream_t st);
 int build_store_table(int mode, const int32_t dm[256], uint16_t *d_out, hipStream_t st);
+int build_strings(int mode, const int32_t dm[256], ulonglong2 **d_strings, uint16_t **d_sub, hipStream_t st);
 
 // iiv_bitmap.hip
 int pack(int mode, int n, const uint8_t *d_main, const uint8_t *d_aux, uint64_t *d_packed, hipStream_t st);

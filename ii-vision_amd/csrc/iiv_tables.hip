@@ -11,6 +11,7 @@
 // contiguous.  No MFMA: there is no contraction here, only a 10/18-step
 // min-plus recurrence per pair.
 #include "iiv_host.h"
+#include "iiv_edit.h"
 
 namespace iiv {
 
@@ -96,59 +97,6 @@ __global__ void cie2000_kernel(const uint8_t *rgb, double *out_f, int32_t *out_i
 
 // ------------------------------------------------------------------ colour strings
 
-// HGRBitmap._double_pixels (screen.py:712-739)
-__host__ __device__ static inline uint32_t double_pixels(uint32_t v)
-{
-    uint32_t r = 0;
-    for (int k = 0; k < 7; k++)
-        if (v & (1u << k)) r |= 3u << (2 * k);
-    if (v & 0x40) r |= 1u << 14;
-    return r;
-}
-
-// to_dots (screen.py:743-789; DHGR: identity, screen.py:983-990)
-template <int MODE> __host__ __device__ static inline uint32_t to_dots(uint32_t m, int o)
-{
-    if (MODE == kDHGR) return m;
-    uint32_t h = (m & 7) << 5;
-    uint32_t hp = (h & 0x80) >> 7;
-    uint32_t res = double_pixels(h & 0x7f) >> (11 - hp);
-    uint32_t b, bp;
-    if (o == 0) {
-        b = (m >> 3) & 0xff;
-        bp = (b & 0x80) >> 7;
-    } else {
-        bp = (m >> 3) & 1;
-        b = ((m >> 4) & 0x7f) ^ (bp << 7);
-    }
-    res &= ~(0x3fffu << (3 + bp));
-    res ^= double_pixels(b & 0x7f) << (3 + bp);
-    uint32_t f = ((m >> 12) & 3) ^ (((m >> 11) & 1) << 7);
-    uint32_t fp = (f & 0x80) >> 7;
-    res &= ~(0xfu << (17 + fp));
-    res ^= double_pixels(f & 0x7f) << (17 + fp);
-    return res & ((1u << 21) - 1);
-}
-
-// Colour value of pixel k = rol4(dots[k..k+3], (phase + k) & 3) (colours.py:100-134);
-// the string is returned as packed nibbles, pixel k in nibble k (lo: 0..15, hi: 16..).
-template <int MODE> __host__ __device__ static inline void colour_string(uint32_t m, int o, uint64_t &lo, uint32_t &hi)
-{
-    uint32_t dots = to_dots<MODE>(m, o);
-    int ph = phase_of(MODE, o);
-    lo = 0;
-    hi = 0;
-    for (int k = 0; k < ModeTraits<MODE>::kDots; k++) {
-        uint32_t w = (dots >> k) & 0xf;
-        int r = (ph + k) & 3;
-        uint32_t c = ((w << r) | (w >> (4 - r))) & 0xf;
-        if (k < 16)
-            lo |= (uint64_t)c << (4 * k);
-        else
-            hi |= c << (4 * (k - 16));
-    }
-}
-
 template <int MODE>
 __global__ void pixel_kernel(uint32_t *dots_out, uint8_t *pix_out, ulonglong2 *strings)
 {
@@ -167,47 +115,8 @@ __global__ void pixel_kernel(uint32_t *dots_out, uint8_t *pix_out, ulonglong2 *s
             pix_out[(size_t)idx * ND + k] = (uint8_t)(k < 16 ? (lo >> (4 * k)) & 0xf : (hi >> (4 * (k - 16))) & 0xf);
 }
 
-// ------------------------------------------------------------------ edit distance
 
-template <int K> __device__ static inline uint32_t nib(uint64_t lo, uint32_t hi)
-{
-    if (K < 8) return ((uint32_t)lo >> (4 * K)) & 0xf;
-    if (K < 16) return ((uint32_t)(lo >> 32) >> (4 * (K - 8))) & 0xf;
-    return (hi >> (4 * (K - 16))) & 0xf;
-}
-
-// weighted Damerau-Levenshtein between two equal-length colour strings with
-// insert/delete cost 1e5 and transpose cost 1 (make_data_tables.py:30-41,98-104)
-// reduces to E[k] = min(E[k-1] + sub(a_k,b_k), E[k-2] + 1 if a_{k-1}a_k == b_k b_{k-1}).
-// lut = 16x16 substitute costs (u16) in LDS.
-template <int N, int K> struct EditStep {
-    __device__ static inline void run(uint64_t alo, uint32_t ahi, uint64_t blo, uint32_t bhi,
-                                      const uint16_t *lut, uint32_t &e1, uint32_t &e2)
-    {
-        uint32_t a = nib<K>(alo, ahi), b = nib<K>(blo, bhi);
-        uint32_t s = (a == b) ? 0u : (uint32_t)lut[a * 16 + b];
-        uint32_t e = e1 + s;
-        if (K >= 1) {
-            uint32_t ap = nib<(K >= 1 ? K - 1 : 0)>(alo, ahi), bp = nib<(K >= 1 ? K - 1 : 0)>(blo, bhi);
-            uint32_t t = e2 + 1;
-            if (ap == b && a == bp && t < e) e = t;
-        }
-        e2 = e1;
-        e1 = e;
-        EditStep<N, K + 1>::run(alo, ahi, blo, bhi, lut, e1, e2);
-    }
-};
-template <int N> struct EditStep<N, N> {
-    __device__ static inline void run(uint64_t, uint32_t, uint64_t, uint32_t, const uint16_t *, uint32_t &, uint32_t &) {}
-};
-
-template <int N>
-__device__ static inline uint32_t edit_distance(uint64_t alo, uint32_t ahi, uint64_t blo, uint32_t bhi, const uint16_t *lut)
-{
-    uint32_t e1 = 0, e2 = 0;
-    EditStep<N, 0>::run(alo, ahi, blo, bhi, lut, e1, e2);
-    return e1;
-}
+// ------------------------------------------------------------------ edit distance tables
 
 constexpr int kTableRowsPerBlock = 32;
 constexpr int kTableColsPerThread = 8;
@@ -327,6 +236,19 @@ static int prepare_scratch(int mode, const int32_t dm[256], TableScratch &sc, hi
     IIV_HIP(hipMemcpyAsync(sc.sub, sub, sizeof(sub), hipMemcpyHostToDevice, st));
     IIV_HIP(hipStreamSynchronize(st));  // `sub` is a stack buffer
     return pixel_strings(mode, nullptr, nullptr, sc.strings, st);
+}
+
+int build_strings(int mode, const int32_t dm[256], ulonglong2 **d_strings, uint16_t **d_sub, hipStream_t st)
+{
+    TableScratch sc;
+    int rc = prepare_scratch(mode, dm, sc, st);
+    if (rc) return rc;
+    IIV_HIP(hipStreamSynchronize(st));
+    *d_strings = sc.strings;
+    *d_sub = sc.sub;
+    sc.strings = nullptr;  // ownership passes to the caller
+    sc.sub = nullptr;
+    return IIV_OK;
 }
 
 int build_table(int mode, const int32_t dm[256], uint16_t *d_out, int symmetric, hipStream_t st)

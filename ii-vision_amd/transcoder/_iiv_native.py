@@ -21,6 +21,7 @@ ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_ASSERT, ERR_OVERFLOW = -1, -2, -3, -4, 
 
 STATE_MEM_MAIN, STATE_MEM_AUX, STATE_UP_MAIN, STATE_UP_AUX = 0, 1, 2, 3
 STATE_RNG_PY, STATE_RNG_NP, STATE_OUT_OF_WORK, STATE_PACKED, STATE_COUNTERS = 4, 5, 6, 7, 8
+OPT_DIFF_WEIGHTS, DW_TABLE, DW_RECURRENCE = 1, 0, 1
 
 # every symbol include/iivision.h declares
 SYMBOLS = [
@@ -29,7 +30,7 @@ SYMBOLS = [
     "iiv_store_table_entries",
     "iiv_cie2000_matrix", "iiv_pixel_strings", "iiv_build_table", "iiv_build_store_table",
     "iiv_pack", "iiv_diff_weights", "iiv_compute_delta_pages",
-    "iiv_encoder_create", "iiv_encoder_destroy", "iiv_encoder_get_state", "iiv_encoder_set_state",
+    "iiv_encoder_create", "iiv_encoder_destroy", "iiv_encoder_set_option", "iiv_encoder_get_state", "iiv_encoder_set_state",
     "iiv_encode", "iiv_encoder_check", "iiv_encoder_profile", "iiv_encoder_profile_read",
 ]
 
@@ -82,7 +83,8 @@ def lib():
     L.iiv_pack.argtypes = [i32, i32, vp, vp, vp, vp]
     L.iiv_diff_weights.argtypes = [i32, vp, i32, vp, vp, i32, vp, vp]
     L.iiv_compute_delta_pages.argtypes = [i32, vp, i32, vp, vp, vp, vp, i32, vp, vp]
-    L.iiv_encoder_create.argtypes = [i32, vp, vp, i32, C.POINTER(vp)]
+    L.iiv_encoder_create.argtypes = [i32, vp, vp, vp, i32, C.POINTER(vp)]
+    L.iiv_encoder_set_option.argtypes = [vp, i32, i32]
     L.iiv_encoder_destroy.argtypes = [vp]
     L.iiv_encoder_destroy.restype = None
     L.iiv_encoder_get_state.argtypes = [vp, i32, i32, vp, sz]
@@ -222,15 +224,24 @@ def compute_delta_pages(mode, table, tgt_packed, pages, contents, dw_rows, is_au
 class Encoder:
     """n_streams independent video.Video states resident on the GPU."""
 
-    def __init__(self, mode, table, store_table, n_streams=1):
+    def __init__(self, mode, table, store_table, n_streams=1, dm=None):
+        """dm: the 16x16 int diff matrix the tables came from; if given, diff weights
+        are recomputed by recurrence instead of gathered from `table` (same values)."""
         _torch()
         self.mode = mode
         self.n_streams = int(n_streams)
         self._table = table            # keep the device tensors alive
         self._store = store_table
         h = C.c_void_p()
-        check(lib().iiv_encoder_create(mode, dptr(table), dptr(store_table), self.n_streams, C.byref(h)))
+        dmp = C.c_void_p(0)
+        if dm is not None:
+            self._dm = np.ascontiguousarray(dm, dtype=np.int32).reshape(256)
+            dmp = hptr(self._dm)
+        check(lib().iiv_encoder_create(mode, dptr(table), dptr(store_table), dmp, self.n_streams, C.byref(h)))
         self._h = h
+
+    def set_diff_weights_mode(self, recurrence):
+        check(lib().iiv_encoder_set_option(self._h, OPT_DIFF_WEIGHTS, DW_RECURRENCE if recurrence else DW_TABLE))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -124,8 +124,9 @@ class DeviceTable:
     """An edit-distance table resident in HBM, indexable like the (n_off, 2^(2*bits))
     uint16 array Bitmap.edit_distances() returns in the reference."""
 
-    def __init__(self, mode, table, store):
+    def __init__(self, mode, table, store, dm=None):
         self.mode = mode
+        self.dm = dm          # 16x16 int CIE2000 matrix the table was built from
         self.table = table    # torch int16 storage of the u16 values, (n_off, 2^(2*bits))
         self.store = store    # store sub-table (see iiv_build_store_table)
         self.shape = tuple(table.shape)
@@ -271,7 +272,7 @@ class Bitmap:
         dm = make_data_tables.compute_diff_matrix(pal.PALETTES[palette_id])
         table = native.build_table(cls.MODE, dm, symmetric=True)
         store = native.build_store_table(cls.MODE, dm)
-        return DeviceTable(cls.MODE, table, store)
+        return DeviceTable(cls.MODE, table, store, dm)
 
     @classmethod
     def mask_and_shift_data(cls, data: IntOrArray, byte_offset: int) -> IntOrArray:

@@ -1,0 +1,136 @@
+"""Many independent video streams encoded together on one GPU.
+
+The reference encodes one video per process; its per-frame driver is
+movie.Movie.encode / emit_stream (transcoder/movie.py:56-150), which pulls exactly
+one opcode per audio sample, starts a fresh encode_frame() generator at every new
+video frame, and (DHGR) flips between the MAIN and AUX banks whenever the output
+byte stream reaches the end of a 2 KiB socket frame.  `MovieClock` restates that
+control flow without audio as a list of segments, and `StreamBatch` runs the same
+schedule for S independent streams -- one workgroup per stream per launch -- through
+iiv_encode() (include/iivision.h).  Streams never exchange data.
+"""
+
+import numpy as np
+
+import _iiv_native as native
+
+TICK_OPCODE_BYTES = 7   # addr_hi, addr_lo, content, 4 offsets (opcodes.py tick opcodes)
+HEADER_BYTES = 7        # opcodes.Header
+ACK_BYTES = 4           # opcodes.Ack
+SOCKET_FRAME = 2048
+
+
+class MovieClock:
+    """movie.Movie.encode/emit_stream pacing (movie.py:56-150, video.py:64-70)."""
+
+    def __init__(self, dhgr, ticks_per_second=14700.0, input_frame_rate=30.0, every_n_video_frames=1):
+        self.dhgr = bool(dhgr)
+        self.ticks_per_frame = float(ticks_per_second) / float(input_frame_rate)
+        self.every_n = int(every_n_video_frames)
+        self.ticks = 0
+        self.frame_number = 0            # Video.frame_number
+        self.stream_pos = HEADER_BYTES   # Movie.stream_pos after the header opcode
+        self.aux_bank = False            # Movie.aux_memory_bank
+        self._last_bank = False
+        self._target = None              # frame index being encoded
+
+    def segments(self, n_video_frames):
+        """Segments (frame, is_aux, restart, n_ops) covering the next n_video_frames
+        input frames (each is encoded if (frame_number - 1) % every_n == 0)."""
+        segs = []
+        cur = None
+        end_frame = self.frame_number + n_video_frames
+        while True:
+            # would the next tick start frame `end_frame`?  then stop before it
+            nxt = self.ticks + 1
+            if nxt >= self.ticks_per_frame * self.frame_number and self.frame_number >= end_frame:
+                break
+            self.ticks = nxt
+            restart = False
+            if self.ticks >= self.ticks_per_frame * self.frame_number:   # Video.tick
+                self.frame_number += 1
+                if (self.frame_number - 1) % self.every_n == 0:
+                    self._target = self.frame_number - 1
+                    restart = True                                       # movie.py:94
+            if self.aux_bank != self._last_bank:                         # movie.py:98-102
+                self._last_bank = self.aux_bank
+                restart = True
+            if self._target is None:
+                continue
+            if restart or cur is None:
+                # every segment starts a fresh generator: a chunk boundary is always a
+                # frame boundary, and a new frame / bank flip restarts (movie.py:94,101)
+                cur = [self._target, int(self.aux_bank), 1, 0]
+                segs.append(cur)
+            cur[3] += 1
+            self.stream_pos += TICK_OPCODE_BYTES
+            if self.stream_pos % SOCKET_FRAME >= SOCKET_FRAME - ACK_BYTES:  # movie.py:139-148
+                if self.dhgr:
+                    self.aux_bank = not self.aux_bank
+                self.stream_pos += ACK_BYTES
+        return [tuple(s) for s in segs]
+
+
+def frame_budgets(mode_is_dhgr, n_frames, **kw):
+    clock = MovieClock(mode_is_dhgr, **kw)
+    return clock.segments(n_frames)
+
+
+def synth_frames_torch(n_streams, n_frames, dhgr, seed, coherent=False, device="cuda"):
+    """SURVEY 8(d) synthetic memory maps, generated on the device: S-iid (every byte
+    uniform in [0,128) DHGR / [0,256) HGR, screen holes zero) or S-coh (each byte
+    keeps its previous value with probability 0.9).  Returns (main, aux) uint8
+    tensors (n_streams, n_frames, 32, 256); aux is None for HGR."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    hi = 128 if dhgr else 256
+    holes = (torch.arange(256, device=device) & 127) >= 120
+    out = []
+    for _ in range(2 if dhgr else 1):
+        t = torch.randint(0, hi, (n_streams, n_frames, 32, 256), dtype=torch.uint8, device=device, generator=g)
+        if coherent:
+            for f in range(1, n_frames):
+                keep = torch.rand((n_streams, 32, 256), device=device, generator=g) < 0.9
+                t[:, f] = torch.where(keep, t[:, f - 1], t[:, f])
+        t[..., holes] = 0
+        out.append(t)
+    return out[0], (out[1] if dhgr else None)
+
+
+class StreamBatch:
+    """S independent video.Video encoders advanced in lock step on one GPU."""
+
+    def __init__(self, mode, table, store_table, n_streams, seeds=None, dm=None, **clock_kw):
+        self.mode = mode
+        self.n_streams = int(n_streams)
+        self.enc = native.Encoder(mode, table, store_table, self.n_streams, dm=dm)
+        self.clock = MovieClock(mode == native.DHGR, **clock_kw)
+        if seeds is not None:
+            self.seed(seeds)
+
+    def seed(self, seeds):
+        """seeds[i] = (random.seed value, np.random.seed value) of stream i."""
+        import random
+        keep_py, keep_np = random.getstate(), np.random.get_state()
+        try:
+            for i, (sp, sn) in enumerate(seeds):
+                random.seed(int(sp))
+                np.random.seed(int(sn))
+                st = np.random.get_state()
+                self.enc.set_state(native.STATE_RNG_PY, np.array(random.getstate()[1], dtype=np.uint32), i)
+                self.enc.set_state(native.STATE_RNG_NP, np.concatenate(
+                    [np.asarray(st[1], dtype=np.uint32), np.array([st[2]], dtype=np.uint32)]), i)
+        finally:
+            random.setstate(keep_py)
+            np.random.set_state(keep_np)
+
+    def encode_frames(self, frames_main, frames_aux, n_video_frames, ops_out=None):
+        """Advance every stream by n_video_frames input frames (targets are
+        frames_*[:, clock.frame_number ...]); returns (ops tensor, segments)."""
+        segs = self.clock.segments(n_video_frames)
+        ops = self.enc.encode(frames_main, frames_aux, segs, ops_out)
+        return ops, segs
+
+    def close(self):
+        self.enc.close()

@@ -72,7 +72,7 @@ class Video:
 
         tables = self.pixelmap.edit_distances(palette)
         self._mode_id = native.DHGR if mode == VideoMode.DHGR else native.HGR
-        self._enc = native.Encoder(self._mode_id, tables.table, tables.store, n_streams=1)
+        self._enc = native.Encoder(self._mode_id, tables.table, tables.store, n_streams=1, dm=tables.dm)
         self._live = None  # the generator whose state the device currently holds
 
     def tick(self, ticks: int) -> bool:

@@ -102,14 +102,24 @@ int iiv_compute_delta_pages(int mode, const uint16_t *d_table, int n, const uint
 typedef struct iiv_encoder iiv_encoder;
 
 /* One encoder = n_streams independent Video objects of one (mode, palette),
- * all state resident in HBM.  d_table = full symmetric table, d_store_table =
- * iiv_build_store_table output; both must outlive the encoder.
+ * all state resident in HBM.  d_table = full symmetric table (iiv_build_table),
+ * d_store_table = iiv_build_store_table output; both must outlive the encoder.
+ * dm = the 16x16 int CIE2000 matrix the tables were built from, or NULL.
+ *   dm != NULL (default mode IIV_DW_RECURRENCE): Bitmap.diff_weights values are
+ *     recomputed on the fly with the same recurrence that built the table
+ *     (bit-identical, no HBM table traffic); d_table may then be NULL.
+ *   dm == NULL (IIV_DW_TABLE): they are gathered from d_table (screen.py:436-443).
  * Initial state = Video.__init__ (video.py:21-62): blank screen, zero
  * priorities; both RNG streams seeded as random.seed(0) / np.random.seed(0)
  * until set with iiv_encoder_set_state. */
 int iiv_encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store_table,
-                       int n_streams, iiv_encoder **out);
+                       const int32_t dm[256], int n_streams, iiv_encoder **out);
 void iiv_encoder_destroy(iiv_encoder *enc);
+
+#define IIV_OPT_DIFF_WEIGHTS 1 /* how the prologue obtains Bitmap.diff_weights */
+#define IIV_DW_TABLE 0         /*   gather from the precomputed table           */
+#define IIV_DW_RECURRENCE 1    /*   run the edit-distance recurrence            */
+int iiv_encoder_set_option(iiv_encoder *enc, int option, int value);
 
 /* state items, per stream */
 #define IIV_STATE_MEM_MAIN 0 /* Video.memory_map.page_offset        u8  [32][256] */

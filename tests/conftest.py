@@ -67,13 +67,14 @@ def native():
 
 class _DeviceTables:
     def __init__(self, native, dms):
-        self.native, self.dms, self.cache = native, dms, {}
+        self.native, self.dms, self.cache, self.dm = native, dms, {}, {}
 
     def get(self, mode, pal=5):
         key = (mode, pal)
         if key not in self.cache:
             self.cache[key] = (self.native.build_table(mode, self.dms[pal], True),
                                self.native.build_store_table(mode, self.dms[pal]))
+            self.dm[key] = self.dms[pal]
         return self.cache[key]
 
 

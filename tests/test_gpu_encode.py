@@ -22,12 +22,12 @@ def _seed_states(O, seed_py, seed_np):
     return O.mt_seed_py(seed_py).state_words(), O.mt_seed_np(seed_np).state_words()
 
 
-def _run_device(native, device_tables, mode, pal, frames_list, sched, seeds):
+def _run_device(native, device_tables, mode, pal, frames_list, sched, seeds, recurrence=True):
     """frames_list: list (per stream) of (n_frames, banks, 32, 256) arrays."""
     import torch
     t, s = device_tables.get(mode, pal)
     n = len(frames_list)
-    enc = native.Encoder(mode, t, s, n)
+    enc = native.Encoder(mode, t, s, n, dm=device_tables.dm[(mode, pal)] if recurrence else None)
     fr = np.stack(frames_list)
     fm = torch.from_numpy(np.ascontiguousarray(fr[:, :, 0])).cuda()
     fa = torch.from_numpy(np.ascontiguousarray(fr[:, :, 1])).cuda() if mode == 1 else None
@@ -48,12 +48,16 @@ def _next_draws(O, words, n, high):
     return [f(C.byref(m)) for _ in range(n)]
 
 
-def test_golden_runs(native, O, golden, device_tables):
+@pytest.mark.parametrize("recurrence", [True, False])
+def test_golden_runs(native, O, golden, device_tables, recurrence):
+    """recurrence=True: diff weights recomputed in the prologue; False: gathered from
+    the HBM table.  Both must reproduce the reference bit for bit."""
     g3 = golden.g3_encode_runs
     for tag in _tags(g3):
         mode, pal, sp, sn = (int(x) for x in g3[tag + "/meta"])
         frames, sched, ops = g3[tag + "/frames"], g3[tag + "/schedule"], g3[tag + "/ops"]
-        enc, got = _run_device(native, device_tables, mode, pal, [frames], sched, [_seed_states(O, sp, sn)])
+        enc, got = _run_device(native, device_tables, mode, pal, [frames], sched, [_seed_states(O, sp, sn)],
+                               recurrence=recurrence)
         bad = np.nonzero((got[0] != ops).any(axis=1))[0]
         assert len(bad) == 0, "%s: first mismatch at op %d: got %s want %s" % (
             tag, bad[0], got[0][bad[0]], ops[bad[0]])
@@ -127,7 +131,7 @@ def test_continue_generator_and_lazy_segments(native, O, oracle_tables, device_t
     mode = 1
     frames = _synth(mode, 2, 77)
     t, s = device_tables.get(mode)
-    enc = native.Encoder(mode, t, s, 1)
+    enc = native.Encoder(mode, t, s, 1, dm=device_tables.dm[(mode, 5)])
     py, npw = _seed_states(O, 3, 4)
     enc.set_state(native.STATE_RNG_PY, py)
     enc.set_state(native.STATE_RNG_NP, npw)
