@@ -472,8 +472,7 @@ __global__ __launch_bounds__(256) void greedy_kernel(StreamState *__restrict__ s
         uint32_t ndv[kChunk];
 #pragma unroll
         for (int m = 0; m < kChunk; m++) {
-            ndv[m] = 0;
-            if (m < cnt) {
+            {   // branch-free: see greedy_wave_kernel
                 int p = ent[m] >> 8;
                 uint32_t c = tgt[0][ent[m]];
                 const uint8_t *own_row = tgt[0] + p * 256;
@@ -484,6 +483,8 @@ __global__ __launch_bounds__(256) void greedy_kernel(StreamState *__restrict__ s
                 ndv[m] = store_o[((size_t)(c & ((1u << CB) - 1)) << BITS) + win];
             }
         }
+
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see greedy_wave_kernel
 
         // ---- process the chunk sequentially
         uint32_t dead = 0;
@@ -626,6 +627,365 @@ __global__ __launch_bounds__(256) void greedy_kernel(StreamState *__restrict__ s
     }
 }
 
+// ------------------------------------------------------------------------- greedy, one wave per stream
+//
+// Same algorithm, one 64-lane wave per stream: lane l owns page bytes 4l..4l+3.
+// Everything that is uniform per opcode (pop, validity, candidate counts, the two
+// winners, RNG cursor, opcode emission) is computed once per stream instead of
+// once per wave of a 4-wave workgroup; there is no workgroup barrier and no LDS
+// exchange in the loop: candidate ranks come from four ballots + mbcnt, the two
+// smallest keys from a DPP butterfly inside each row of 16 lanes and four
+// v_readlane pairs.  LDS accesses of one wave execute in order, which is all the
+// cross-lane ordering the loop needs.
+
+template <int CTRL> __device__ static inline uint32_t dpp_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+
+// merge this lane's sorted pair (k1 <= k2) with the pair held by its DPP partner
+template <int CTRL> __device__ static inline void top2_step(uint32_t &k1, uint32_t &k2)
+{
+    uint32_t o1 = dpp_u32<CTRL>(k1), o2 = dpp_u32<CTRL>(k2);
+    uint32_t lo = k1 < o1 ? k1 : o1, hi = k1 < o1 ? o1 : k1;
+    uint32_t m2 = k2 < o2 ? k2 : o2;
+    k1 = lo;
+    k2 = hi < m2 ? hi : m2;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void greedy_wave_kernel(StreamState *__restrict__ states,
+                                                         const uint8_t *__restrict__ frames_main,
+                                                         const uint8_t *__restrict__ frames_aux, int n_frames,
+                                                         int frame, int is_aux, int n_ops,
+                                                         const uint16_t *__restrict__ store,
+                                                         uint8_t *__restrict__ ops_out, size_t ops_stride,
+                                                         size_t ops_base)
+{
+    constexpr int BITS = ModeTraits<MODE>::kBits;
+    constexpr int CB = ModeTraits<MODE>::kContentBits;
+    constexpr int NB = ModeTraits<MODE>::kBanks;
+    constexpr uint32_t INF = 0xffffffffu;
+    constexpr int M = kChunk;
+    __shared__ __attribute__((aligned(16))) uint8_t tgt[NB][8192];  // [0] = bank being encoded, [NB-1] = the other
+    __shared__ __attribute__((aligned(16))) uint16_t dwf[8192];     // diff_weight | (priority != 0) << 15
+    __shared__ uint32_t mt[2 * 624];                                // two consecutive MT19937 blocks
+
+    const int lane = threadIdx.x;
+    StreamState &S = states[blockIdx.x];
+    const size_t fbase = ((size_t)blockIdx.x * n_frames + frame) * 8192;
+    uint8_t *out = ops_out + (size_t)blockIdx.x * ops_stride + ops_base;
+
+    if (!S.gen_active || S.error) {
+        if (lane == 0 && !S.error) S.error = kErrNoGenerator;
+        return;
+    }
+
+    for (int i = lane; i < 512 * NB; i += 64) {
+        int b = i >> 9, k = i & 511;
+        const uint8_t *src;
+        if (MODE == kDHGR)
+            src = ((b == 0) == (is_aux != 0) ? frames_aux : frames_main) + fbase;
+        else
+            src = frames_main + fbase;
+        reinterpret_cast<uint4 *>(tgt[b])[k] = reinterpret_cast<const uint4 *>(src)[k];
+    }
+    for (int i = lane; i < 1024; i += 64) {
+        uint4 d = reinterpret_cast<const uint4 *>(S.dw)[i];
+        const int4 *up = reinterpret_cast<const int4 *>(S.up[is_aux] + i * 8);
+        int4 u0 = up[0], u1 = up[1];
+        d.x |= (u0.x ? 0x8000u : 0u) | (u0.y ? 0x80000000u : 0u);
+        d.y |= (u0.z ? 0x8000u : 0u) | (u0.w ? 0x80000000u : 0u);
+        d.z |= (u1.x ? 0x8000u : 0u) | (u1.y ? 0x80000000u : 0u);
+        d.w |= (u1.z ? 0x8000u : 0u) | (u1.w ? 0x80000000u : 0u);
+        reinterpret_cast<uint4 *>(dwf)[i] = d;
+    }
+    for (int i = lane; i < 624; i += 64) mt[i] = S.mt_py[i];
+    __syncthreads();
+    int cb = 0;  // block cb (mt + 624*cb) is current, the other one follows it
+    mt_twist<64>(mt, mt + 624, lane);
+    int mt_idx = S.mt_py_idx;
+    if (mt_idx >= 624) {
+        mt_twist<64>(mt + 624, mt, lane);
+        cb = 1;
+        mt_idx -= 624;
+    }
+
+    const int n_sorted = S.n_sorted;
+    int head = S.head, n_pushed = S.n_pushed, exhausted = S.exhausted;
+    int done = 0, err = 0;
+    unsigned long long draws = 0, pad_ops = 0;
+    // store-table bases for this lane's even (r = 0,2) and odd (r = 1,3) bytes
+    const uint16_t *store_e = store + ((size_t)byte_offset<MODE>(0, is_aux) << (CB + BITS));
+    const uint16_t *store_d = store + ((size_t)byte_offset<MODE>(1, is_aux) << (CB + BITS));
+
+    int guard = n_ops + 8192 + 2 * kPushedCap + 64;
+    while (done < n_ops && !err) {
+        if (--guard < 0) {
+            err = kErrGuard;
+            break;
+        }
+        if (exhausted) {
+            uint32_t c0 = tgt[0][0];  // video.py:249-251
+            for (int i = done + lane; i < n_ops; i += 64) {
+                uint8_t *q = out + (size_t)i * 6;
+                q[0] = 32; q[1] = (uint8_t)c0; q[2] = 0; q[3] = 0; q[4] = 0; q[5] = 0;
+            }
+            pad_ops += (unsigned long long)(n_ops - done);
+            done = n_ops;
+            break;
+        }
+
+        // ---- form a chunk
+        uint32_t ent[M];
+        int pos[M];
+        int cnt = 0, chunk_end = head;
+        bool from_pushed = false;
+        if (head < n_sorted) {
+            int idx = head + lane;
+            uint32_t e = idx < n_sorted ? (uint32_t)S.order[idx] : 0u;
+            bool v = idx < n_sorted && (dwf[e] & 0x8000u);
+            unsigned long long mask = __ballot(v);
+            int window_end = head + 64 < n_sorted ? head + 64 : n_sorted;
+            if (mask == 0) {
+                head = window_end;
+                continue;
+            }
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                ent[m] = 0;
+                pos[m] = 0;
+                if (mask) {
+                    int l = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    ent[m] = __builtin_amdgcn_readlane(e, l);
+                    pos[m] = head + l;
+                    cnt = m + 1;
+                }
+            }
+            chunk_end = mask ? pos[M - 1] + 1 : window_end;
+        } else {
+            from_pushed = true;
+            unsigned long long best = ~0ull;
+            for (int i = lane; i < n_pushed; i += 64) {
+                unsigned long long k = ((unsigned long long)S.pushed[i] << 32) | (unsigned)i;
+                best = k < best ? k : best;
+            }
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                unsigned long long other = __shfl_xor(best, d, 64);
+                best = other < best ? other : best;
+            }
+            uint32_t bk = (uint32_t)(best >> 32);
+            if (bk == INF) {
+                exhausted = 1;  // video.py:189
+                continue;
+            }
+            if (lane == 0) S.pushed[(uint32_t)best] = INF;
+            __builtin_amdgcn_s_waitcnt(0);  // the store above precedes the next scan of pushed[]
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                ent[m] = 0;
+                pos[m] = 0;
+            }
+            ent[0] = bk & 0x1fff;
+            cnt = 1;
+        }
+
+        // ---- gather the store-table rows of the chunk (all in flight together)
+        uint32_t ndv[M][4];
+        // (branch-free on purpose: slots beyond cnt hold entry 0 and gather a harmless
+        // row; a branch here makes the compiler wait for each slot's loads in turn)
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            {
+                const int p = ent[m] >> 8;
+                const uint32_t c = tgt[0][ent[m]];
+                const uint8_t *own_row = tgt[0] + p * 256;
+                const uint8_t *oth_row = tgt[NB - 1] + p * 256;
+                const uint32_t own4 = *reinterpret_cast<const uint32_t *>(own_row + 4 * lane);
+                // `seq` holds the neighbour bytes of this lane's four bytes in dot order
+                unsigned long long seq;
+                int nshift;  // next(r) = byte (r + nshift) of seq, prev(r) = byte r
+                if (MODE == kDHGR) {
+                    const uint32_t oth4 = *reinterpret_cast<const uint32_t *>(oth_row + 4 * lane);
+                    if (is_aux) {  // prev = main[y-1], next = main[y]
+                        uint32_t before = lane > 0 ? oth_row[4 * lane - 1] : 0u;
+                        seq = (unsigned long long)before | ((unsigned long long)oth4 << 8);
+                    } else {       // prev = aux[y], next = aux[y+1]
+                        uint32_t after = lane < 63 ? oth_row[4 * lane + 4] : 0u;
+                        seq = (unsigned long long)oth4 | ((unsigned long long)after << 32);
+                    }
+                    nshift = 1;
+                } else {           // prev = main[y-1], next = main[y+1]
+                    uint32_t before = lane > 0 ? own_row[4 * lane - 1] : 0u;
+                    uint32_t after = lane < 63 ? own_row[4 * lane + 4] : 0u;
+                    seq = (unsigned long long)before | ((unsigned long long)own4 << 8) |
+                          ((unsigned long long)after << 40);
+                    nshift = 2;
+                }
+                const size_t cbase = (size_t)(c & ((1u << CB) - 1)) << BITS;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    uint32_t pv = (uint32_t)(seq >> (8 * r)) & 0xff;
+                    uint32_t nx = (uint32_t)(seq >> (8 * (r + nshift))) & 0xff;
+                    uint32_t ob = (own4 >> (8 * r)) & 0xff;
+                    uint32_t win = masked_window<MODE>(pv, ob, nx, r & 1);
+                    ndv[m][r] = ((r & 1) ? store_d : store_e)[cbase + win];
+                }
+            }
+        }
+
+        // vmcnt is one in-order counter for loads AND stores: retire the chunk's gathers
+        // here, once, before the steps below start issuing stores -- otherwise the first
+        // use of a late entry's row would also wait for every store issued before it.
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+
+        // ---- process the chunk
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            if (m >= cnt || done >= n_ops || err) break;
+            // video.py:130 -- a byte resolved since the chunk was formed is skipped
+            const uint32_t fl = __builtin_amdgcn_readfirstlane((uint32_t)dwf[ent[m]]);
+            if (!(fl & 0x8000u)) {
+                if (!from_pushed) head = pos[m] + 1;
+                continue;
+            }
+            const int p = ent[m] >> 8, x = ent[m] & 255;
+            const uint32_t c = __builtin_amdgcn_readfirstlane((uint32_t)tgt[0][ent[m]]);  // video.py:134
+            if (MODE == kDHGR && c >= 0x80) {  // video.py:137
+                err = kErrPaletteBit;
+                break;
+            }
+            const unsigned long long w4 = *reinterpret_cast<const unsigned long long *>(dwf + p * 256 + 4 * lane);
+            uint32_t w[4];
+            int d[4];
+            bool cand[4], nzy[4];
+            unsigned long long bal[4];
+            int below = 0, C = 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int y = 4 * lane + r;
+                w[r] = (uint32_t)(w4 >> (16 * r)) & 0xffffu;
+                const uint32_t dwy = (y == x) ? 0u : (w[r] & 0x7fffu);   // video.py:141
+                nzy[r] = (w[r] & 0x8000u) && (y != x);                   // video.py:140
+                d[r] = (int)ndv[m][r] - (int)dwy;                        // screen.py:547
+                cand[r] = d[r] < 0;                                      // video.py:283
+                bal[r] = __ballot(cand[r]);
+                below += prefix_popc(bal[r]);
+                C += (int)__popcll(bal[r]);
+            }
+            // one random.getrandbits(8) per candidate in ascending offset (video.py:290-293)
+            uint32_t key[4];
+            int run = mt_idx + cb * 624 + below;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                key[r] = INF;
+                if (cand[r]) {
+                    int fj = run >= 1248 ? run - 1248 : run;
+                    run++;
+                    uint32_t nonce = mt_temper(mt[fj]) >> 24;
+                    if (nzy[r])  // video.py:159
+                        key[r] = ((uint32_t)(d[r] + 2048) << 17) | (nonce << 9) | ((uint32_t)(4 * lane + r) << 1) |
+                                 (ndv[m][r] != 0 ? 1u : 0u);
+                }
+            }
+            // two smallest (delta, nonce, offset): lane, row of 16 (DPP), wave (readlane)
+            uint32_t a0 = key[0] < key[1] ? key[0] : key[1], b0 = key[0] < key[1] ? key[1] : key[0];
+            uint32_t a1 = key[2] < key[3] ? key[2] : key[3], b1 = key[2] < key[3] ? key[3] : key[2];
+            uint32_t k1 = a0 < a1 ? a0 : a1;
+            uint32_t hi01 = a0 < a1 ? a1 : a0, mb = b0 < b1 ? b0 : b1;
+            uint32_t k2 = hi01 < mb ? hi01 : mb;
+            top2_step<0xB1>(k1, k2);   // quad_perm [1,0,3,2]
+            top2_step<0x4E>(k1, k2);   // quad_perm [2,3,0,1]
+            top2_step<0x141>(k1, k2);  // row_half_mirror
+            top2_step<0x140>(k1, k2);  // row_mirror
+            uint32_t K1 = INF, K2 = INF;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t r1 = __builtin_amdgcn_readlane(k1, 16 * q), r2 = __builtin_amdgcn_readlane(k2, 16 * q);
+                // merge sorted pair (r1 <= r2) into (K1 <= K2)
+                uint32_t lo = K1 < r1 ? K1 : r1, hi = K1 < r1 ? r1 : K1;
+                uint32_t m2 = K2 < r2 ? K2 : r2;
+                K1 = lo;
+                K2 = hi < m2 ? hi : m2;
+            }
+            const int y1 = K1 != INF ? (int)((K1 >> 1) & 255) : -1;
+            const int f1 = K1 != INF ? (int)(K1 & 1) : 0;
+            const int y2 = K2 != INF ? (int)((K2 >> 1) & 255) : -1;
+            const int f2 = K2 != INF ? (int)(K2 & 1) : 0;
+            if (n_pushed + f1 + f2 > kPushedCap) {
+                err = kErrPushedOverflow;
+                break;
+            }
+
+            // ---- apply (video.py:140-144, 170-178; screen.py:256-293)
+            if (lane == 0) {
+                dwf[p * 256 + x] = 0;
+                S.up[is_aux][p * 256 + x] = 0;
+                S.mem[is_aux][p * 256 + x] = (uint8_t)c;
+                uint8_t *q = out + (size_t)done * 6;
+                q[0] = (uint8_t)(p + 32);
+                q[1] = (uint8_t)c;
+                q[2] = (uint8_t)x;
+                q[3] = (uint8_t)(y1 >= 0 ? y1 : x);  // video.py:185-186
+                q[4] = (uint8_t)(y2 >= 0 ? y2 : x);
+                q[5] = (uint8_t)x;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+                const int ys = s2 ? y2 : y1;
+                if (ys >= 0 && (ys >> 2) == lane) {
+                    const int r = ys & 3;
+                    const uint32_t nd = r == 0 ? ndv[m][0] : r == 1 ? ndv[m][1] : r == 2 ? ndv[m][2] : ndv[m][3];
+                    const uint32_t wv = r == 0 ? w[0] : r == 1 ? w[1] : r == 2 ? w[2] : w[3];
+                    S.up[is_aux][p * 256 + ys] = (int32_t)nd;  // byte_pair_difference == nd (screen.py:383-398)
+                    S.mem[is_aux][p * 256 + ys] = (uint8_t)c;
+                    dwf[p * 256 + ys] = (uint16_t)((wv & 0x7fffu) | (nd ? 0x8000u : 0u));
+                    if (nd) {
+                        int j = mt_idx + cb * 624 + C + (s2 ? f1 : 0);
+                        if (j >= 1248) j -= 1248;
+                        uint32_t nonce = mt_temper(mt[j]) >> 24;  // video.py:178
+                        S.pushed[n_pushed + (s2 ? f1 : 0)] =
+                            ((2047u - nd) << 21) | (nonce << 13) | ((uint32_t)p << 8) | (uint32_t)ys;
+                    }
+                }
+            }
+            mt_idx += C + f1 + f2;
+            draws += (unsigned long long)(C + f1 + f2);
+            n_pushed += f1 + f2;
+            done++;
+            if (!from_pushed) head = pos[m] + 1;
+            if (mt_idx >= 624) {
+                __syncthreads();
+                mt_twist<64>(mt + 624 * (cb ^ 1), mt + 624 * cb, lane);
+                cb ^= 1;
+                mt_idx -= 624;
+            }
+        }
+        if (!from_pushed && !err && done < n_ops) head = chunk_end > head ? chunk_end : head;
+    }
+
+    __syncthreads();
+    for (int i = lane; i < 1024; i += 64) {
+        uint4 d = reinterpret_cast<const uint4 *>(dwf)[i];
+        d.x &= 0x7fff7fffu; d.y &= 0x7fff7fffu; d.z &= 0x7fff7fffu; d.w &= 0x7fff7fffu;
+        reinterpret_cast<uint4 *>(S.dw)[i] = d;
+    }
+    for (int i = lane; i < 624; i += 64) S.mt_py[i] = mt[624 * cb + i];
+    if (lane == 0) {
+        S.mt_py_idx = mt_idx;
+        S.head = head;
+        S.n_pushed = n_pushed;
+        S.exhausted = exhausted;
+        if (exhausted) S.out_of_work[is_aux] = 1;
+        S.draws_py += draws;
+        S.ops += (unsigned long long)done;
+        S.pad_ops += pad_ops;
+        if (err && S.error == 0) S.error = err;
+    }
+}
+
 // stand-alone packed view of the current screen for IIV_STATE_PACKED: reuse iiv_bitmap's pack
 
 // ------------------------------------------------------------------------- host object
@@ -638,6 +998,7 @@ struct Encoder {
     ulonglong2 *d_strings;  // colour string of every masked value (recurrence mode)
     uint16_t *d_sub;        // 16x16 substitute costs
     int dw_mode;            // IIV_DW_TABLE / IIV_DW_RECURRENCE
+    int greedy_mode;        // IIV_GREEDY_WAVE / IIV_GREEDY_WORKGROUP
     StreamState *d_states;
     // generator bookkeeping shared by all streams (same schedule)
     int gen_active, gen_is_aux, gen_frame;
@@ -691,6 +1052,7 @@ int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, c
     e->d_strings = nullptr;
     e->d_sub = nullptr;
     e->dw_mode = dm ? IIV_DW_RECURRENCE : IIV_DW_TABLE;
+    e->greedy_mode = IIV_GREEDY_WORKGROUP;
     e->gen_active = 0;
     e->gen_is_aux = 0;
     e->gen_frame = 0;
@@ -750,6 +1112,11 @@ int encoder_set_option(Encoder *e, int option, int value)
             return set_error(IIV_ERR_INVALID, "no diff matrix was given at creation");
         if (value != IIV_DW_TABLE && value != IIV_DW_RECURRENCE) return set_error(IIV_ERR_INVALID, "bad value");
         e->dw_mode = value;
+        return IIV_OK;
+    }
+    if (option == IIV_OPT_GREEDY_KERNEL) {
+        if (value != IIV_GREEDY_WAVE && value != IIV_GREEDY_WORKGROUP) return set_error(IIV_ERR_INVALID, "bad value");
+        e->greedy_mode = value;
         return IIV_OK;
     }
     return set_error(IIV_ERR_INVALID, "unknown option %d", option);
@@ -940,12 +1307,15 @@ int encode(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux, int n_frames
         e->gen_is_aux = g.is_aux;
         e->gen_frame = g.frame;
         if (e->profiling) { int prc = prof_begin(e, 1, st, slot); if (prc) return prc; }
-        if (e->mode == kDHGR)
-            hipLaunchKernelGGL(greedy_kernel<kDHGR>, dim3(e->n_streams), dim3(256), 0, st, e->d_states, d_main, d_aux,
-                               n_frames, g.frame, g.is_aux, g.n_ops, e->d_store, d_ops, stride, done * 6);
-        else
-            hipLaunchKernelGGL(greedy_kernel<kHGR>, dim3(e->n_streams), dim3(256), 0, st, e->d_states, d_main, d_aux,
-                               n_frames, g.frame, g.is_aux, g.n_ops, e->d_store, d_ops, stride, done * 6);
+#define IIV_GREEDY(K, T)                                                                                        \
+    hipLaunchKernelGGL(K, dim3(e->n_streams), dim3(T), 0, st, e->d_states, d_main, d_aux, n_frames, g.frame,       \
+                       g.is_aux, g.n_ops, e->d_store, d_ops, stride, done * 6)
+        if (e->greedy_mode == IIV_GREEDY_WAVE) {
+            if (e->mode == kDHGR) IIV_GREEDY(greedy_wave_kernel<kDHGR>, 64); else IIV_GREEDY(greedy_wave_kernel<kHGR>, 64);
+        } else {
+            if (e->mode == kDHGR) IIV_GREEDY(greedy_kernel<kDHGR>, 256); else IIV_GREEDY(greedy_kernel<kHGR>, 256);
+        }
+#undef IIV_GREEDY
         IIV_HIP(hipGetLastError());
         if (e->profiling) { int prc = prof_end(e, slot, st); if (prc) return prc; }
         done += (size_t)g.n_ops;

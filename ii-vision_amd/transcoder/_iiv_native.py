@@ -22,6 +22,7 @@ ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_ASSERT, ERR_OVERFLOW = -1, -2, -3, -4, 
 STATE_MEM_MAIN, STATE_MEM_AUX, STATE_UP_MAIN, STATE_UP_AUX = 0, 1, 2, 3
 STATE_RNG_PY, STATE_RNG_NP, STATE_OUT_OF_WORK, STATE_PACKED, STATE_COUNTERS = 4, 5, 6, 7, 8
 OPT_DIFF_WEIGHTS, DW_TABLE, DW_RECURRENCE = 1, 0, 1
+OPT_GREEDY_KERNEL, GREEDY_WAVE, GREEDY_WORKGROUP = 2, 0, 1
 
 # every symbol include/iivision.h declares
 SYMBOLS = [
@@ -239,6 +240,10 @@ class Encoder:
             dmp = hptr(self._dm)
         check(lib().iiv_encoder_create(mode, dptr(table), dptr(store_table), dmp, self.n_streams, C.byref(h)))
         self._h = h
+
+    def set_greedy_kernel(self, wave_per_stream):
+        check(lib().iiv_encoder_set_option(self._h, OPT_GREEDY_KERNEL,
+                                           GREEDY_WAVE if wave_per_stream else GREEDY_WORKGROUP))
 
     def set_diff_weights_mode(self, recurrence):
         check(lib().iiv_encoder_set_option(self._h, OPT_DIFF_WEIGHTS, DW_RECURRENCE if recurrence else DW_TABLE))

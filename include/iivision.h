@@ -119,6 +119,9 @@ void iiv_encoder_destroy(iiv_encoder *enc);
 #define IIV_OPT_DIFF_WEIGHTS 1 /* how the prologue obtains Bitmap.diff_weights */
 #define IIV_DW_TABLE 0         /*   gather from the precomputed table           */
 #define IIV_DW_RECURRENCE 1    /*   run the edit-distance recurrence            */
+#define IIV_OPT_GREEDY_KERNEL 2 /* shape of the greedy-selection kernel         */
+#define IIV_GREEDY_WAVE 0       /*   one 64-lane wave per stream                 */
+#define IIV_GREEDY_WORKGROUP 1  /*   one 256-thread workgroup per stream (default) */
 int iiv_encoder_set_option(iiv_encoder *enc, int option, int value);
 
 /* state items, per stream */

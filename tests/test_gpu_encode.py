@@ -22,12 +22,13 @@ def _seed_states(O, seed_py, seed_np):
     return O.mt_seed_py(seed_py).state_words(), O.mt_seed_np(seed_np).state_words()
 
 
-def _run_device(native, device_tables, mode, pal, frames_list, sched, seeds, recurrence=True):
+def _run_device(native, device_tables, mode, pal, frames_list, sched, seeds, recurrence=True, wave=True):
     """frames_list: list (per stream) of (n_frames, banks, 32, 256) arrays."""
     import torch
     t, s = device_tables.get(mode, pal)
     n = len(frames_list)
     enc = native.Encoder(mode, t, s, n, dm=device_tables.dm[(mode, pal)] if recurrence else None)
+    enc.set_greedy_kernel(wave)
     fr = np.stack(frames_list)
     fm = torch.from_numpy(np.ascontiguousarray(fr[:, :, 0])).cuda()
     fa = torch.from_numpy(np.ascontiguousarray(fr[:, :, 1])).cuda() if mode == 1 else None
@@ -48,16 +49,17 @@ def _next_draws(O, words, n, high):
     return [f(C.byref(m)) for _ in range(n)]
 
 
-@pytest.mark.parametrize("recurrence", [True, False])
-def test_golden_runs(native, O, golden, device_tables, recurrence):
+@pytest.mark.parametrize("recurrence,wave", [(True, True), (False, True), (True, False)])
+def test_golden_runs(native, O, golden, device_tables, recurrence, wave):
     """recurrence=True: diff weights recomputed in the prologue; False: gathered from
-    the HBM table.  Both must reproduce the reference bit for bit."""
+    the HBM table.  wave=True: one wave per stream; False: one 256-thread workgroup
+    per stream.  Every combination must reproduce the reference bit for bit."""
     g3 = golden.g3_encode_runs
     for tag in _tags(g3):
         mode, pal, sp, sn = (int(x) for x in g3[tag + "/meta"])
         frames, sched, ops = g3[tag + "/frames"], g3[tag + "/schedule"], g3[tag + "/ops"]
         enc, got = _run_device(native, device_tables, mode, pal, [frames], sched, [_seed_states(O, sp, sn)],
-                               recurrence=recurrence)
+                               recurrence=recurrence, wave=wave)
         bad = np.nonzero((got[0] != ops).any(axis=1))[0]
         assert len(bad) == 0, "%s: first mismatch at op %d: got %s want %s" % (
             tag, bad[0], got[0][bad[0]], ops[bad[0]])
@@ -103,8 +105,8 @@ def _oracle_run(O, oracle_tables, mode, pal, frames, sched, sp, sn):
     return v, np.concatenate(out)
 
 
-@pytest.mark.parametrize("mode", [1, 0])
-def test_batch_of_independent_streams(native, O, oracle_tables, device_tables, mode):
+@pytest.mark.parametrize("mode,wave", [(1, True), (0, True), (1, False)])
+def test_batch_of_independent_streams(native, O, oracle_tables, device_tables, mode, wave):
     """12 streams with different data / seeds / coherence in ONE launch sequence,
     ragged segment lengths incl. bank flips; every stream equals its own oracle run."""
     n = 12
@@ -112,7 +114,7 @@ def test_batch_of_independent_streams(native, O, oracle_tables, device_tables, m
     frames = [_synth(mode, 3, 100 + i, coherent=(i % 2 == 1)) for i in range(n)]
     seeds = [(i + 1, 1000 + i) for i in range(n)]
     enc, got = _run_device(native, device_tables, mode, 5, frames, sched,
-                           [_seed_states(O, a, b) for a, b in seeds])
+                           [_seed_states(O, a, b) for a, b in seeds], wave=wave)
     for i in range(n):
         v, exp = _oracle_run(O, oracle_tables, mode, 5, frames[i], sched, *seeds[i])
         assert (got[i] == exp).all(), "stream %d" % i
