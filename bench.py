@@ -65,7 +65,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("IIV_BENCH_STREAMS", "1024")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("IIV_BENCH_STREAMS", "4096")),
                     help="independent clips per GPU")
     ap.add_argument("--frames-per-step", type=int, default=50)
     ap.add_argument("--mode", choices=["DHGR", "HGR"], default="DHGR")
@@ -74,8 +74,9 @@ def parse_args():
     ap.add_argument("--cpu-frames", type=int, default=600, help="frames of stream 0 the CPU baseline encodes")
     ap.add_argument("--dw-table", action="store_true",
                     help="gather diff weights from the HBM table instead of recomputing them (same values)")
-    ap.add_argument("--greedy", choices=["wave", "workgroup"], default="workgroup",
-                    help="greedy kernel shape: one 256-thread workgroup per stream (default) or one wave")
+    ap.add_argument("--greedy", choices=["auto", "wave", "workgroup"], default="auto",
+                    help="greedy kernel shape: one wave per stream, one 256-thread workgroup per stream, or auto")
+    ap.add_argument("--full-sort", action="store_true", help="disable the prologue's prefix sort")
     ap.add_argument("--single-stream", action="store_true", help="also time one clip alone (latency-bound rate)")
     return ap.parse_args()
 
@@ -119,7 +120,9 @@ def main():
     batch = stream_batch.StreamBatch(mode, table, store, S, seeds=seeds, dm=dm)
     if args.dw_table:
         batch.enc.set_diff_weights_mode(False)
-    batch.enc.set_greedy_kernel(args.greedy == "wave")
+    batch.enc.set_greedy_kernel(None if args.greedy == "auto" else args.greedy == "wave")
+    if args.full_sort:
+        batch.enc.set_prefix_sort(False)
     ops_buf = torch.empty((S, F * OPS_PER_FRAME, 6), dtype=torch.uint8, device="cuda")
 
     def barrier():
@@ -189,7 +192,7 @@ def main():
         greedy_bytes = float(op_count) * S * BYTES_PER_OPCODE       # all launches of the timed region
         achieved = greedy_bytes / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
         out["roofline"] = {
-            "kernel": "greedy_wave_kernel" if args.greedy == "wave" else "greedy_kernel",
+            "kernel": "greedy_wave_kernel" if (args.greedy == "wave" or (args.greedy == "auto" and S >= 1536)) else "greedy_kernel",
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
@@ -238,7 +241,7 @@ def _single_stream(native, stream_batch, mode, table, store, dm, dhgr, args):
     import torch
     fm, fa = stream_batch.synth_frames_torch(1, 60, dhgr, seed=99, coherent=args.coherent)
     b = stream_batch.StreamBatch(mode, table, store, 1, seeds=[(1, 1)], dm=dm)
-    b.enc.set_greedy_kernel(args.greedy == "wave")
+    b.enc.set_greedy_kernel(None if args.greedy == "auto" else args.greedy == "wave")
     b.encode_frames(fm, fa, 10)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -41,8 +41,10 @@ constexpr int kPushedCap = 16384;  // >= 2 pushes x 7680 non-hole bytes
 struct StreamState {
     uint8_t mem[2][8192];     // [is_aux] Video.memory_map / aux_memory_map
     int32_t up[2][8192];      // [is_aux] Video.update_priority / aux_update_priority
-    uint16_t dw[8192];        // diff_weights of the live generator
-    uint16_t order[8192];     // sorted initial entries: page << 8 | offset
+    uint32_t wd[8192];        // live generator, per byte of its bank: target window | diff_weight << 16
+    uint32_t order[8192];     // sorted initial entries: page << 8 | offset | target content << 16
+    uint32_t nzbits[256];     // bit = update_priority != 0 (as left by the last launch)
+    uint32_t pdone[256];      // bit = byte was a primary in the live generator (its diff weight is 0)
     uint32_t pushed[kPushedCap];  // (2047-p) << 21 | nonce << 13 | page << 8 | offset; ~0 = popped
     uint32_t mt_py[624];      // random's MT19937 block
     uint32_t mt_np[624];      // np.random's MT19937 block
@@ -50,11 +52,12 @@ struct StreamState {
     int32_t n_sorted, head, n_pushed, exhausted;
     int32_t gen_active, gen_is_aux, gen_frame, error;
     int32_t out_of_work[2];
-    int32_t pad_[2];
+    int32_t pad_content;      // target[0,0] of the live generator's bank (video.py:249)
+    int32_t truncated;        // order[] holds only the top of the list (prefix sort)
     unsigned long long draws_py, draws_np, ops, pad_ops;
 };
 
-enum { kErrNone = 0, kErrHoles = 1, kErrNegative = 2, kErrPaletteBit = 3, kErrPushedOverflow = 4, kErrNoGenerator = 5, kErrGuard = 6 };
+enum { kErrNone = 0, kErrHoles = 1, kErrNegative = 2, kErrPaletteBit = 3, kErrPushedOverflow = 4, kErrNoGenerator = 5, kErrGuard = 6, kErrSortBudget = 7 };
 
 // ------------------------------------------------------------------------- prologue
 
@@ -71,10 +74,12 @@ __device__ static inline void cmpx(unsigned long long &lo, unsigned long long &h
     hi = sw ? t : hi;
 }
 
-template <int NT>
-__device__ static inline void bitonic_sort8(unsigned long long (&v)[8], unsigned long long *xbuf, int tid)
+// All threads of the workgroup must call this (it contains workgroup barriers); only
+// threads tid < nt hold keys, N = 8 * nt keys are sorted.
+__device__ static inline void bitonic_sort8(unsigned long long (&v)[8], unsigned long long *xbuf, int tid, int nt)
 {
-    constexpr int N = 8 * NT;
+    const int N = 8 * nt;
+    const bool active = tid < nt;
 #pragma unroll
     for (int k = 2; k <= 8; k <<= 1) {
 #pragma unroll
@@ -96,13 +101,17 @@ __device__ static inline void bitonic_sort8(unsigned long long (&v)[8], unsigned
                     v[r] = take_min ? (p < v[r] ? p : v[r]) : (p > v[r] ? p : v[r]);
                 }
             } else {
+                if (active) {
 #pragma unroll
-                for (int r = 0; r < 8; r++) xbuf[r * NT + tid] = v[r];
+                    for (int r = 0; r < 8; r++) xbuf[r * nt + tid] = v[r];
+                }
                 __syncthreads();
+                if (active) {
 #pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    unsigned long long p = xbuf[r * NT + (tid ^ d)];
-                    v[r] = take_min ? (p < v[r] ? p : v[r]) : (p > v[r] ? p : v[r]);
+                    for (int r = 0; r < 8; r++) {
+                        unsigned long long p = xbuf[r * nt + (tid ^ d)];
+                        v[r] = take_min ? (p < v[r] ? p : v[r]) : (p > v[r] ? p : v[r]);
+                    }
                 }
                 __syncthreads();
             }
@@ -116,19 +125,44 @@ __device__ static inline void bitonic_sort8(unsigned long long (&v)[8], unsigned
     }
 }
 
+// exclusive prefix sum of one int per thread over the workgroup (row-major thread order)
+template <int NT> __device__ static inline int block_scan_excl(int v, int tid, uint32_t *wsum, int &total)
+{
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int o = __shfl_up(incl, d, 64);
+        if ((tid & 63) >= d) incl += o;
+    }
+    __syncthreads();  // wsum may still be read from a previous use
+    if ((tid & 63) == 63) wsum[tid >> 6] = (uint32_t)incl;
+    __syncthreads();
+    int wbase = 0;
+    total = 0;
+    for (int w = 0; w < NT / 64; w++) {
+        int x = (int)wsum[w];
+        if (w < (tid >> 6)) wbase += x;
+        total += x;
+    }
+    return wbase + incl - v;
+}
+
+constexpr int kSelNeedMax = 2048;  // partial sort is used when 3 * opcode budget <= this
+constexpr int kSelCap = 4096;      // ... and the threshold bucket does not push the selection past this
+
 // DP == false: diff weights are gathered from the precomputed table (one random
 // HBM line per screen byte).  DP == true: they are recomputed by running the
 // edit-distance recurrence on the two colour strings (an L2-resident 16 B LUT
 // entry each) -- bit-identical by construction (same recurrence that built the
 // table), and far cheaper than an HBM line fetch per byte.
 template <int MODE, bool DP>
-__global__ __launch_bounds__(kProThreads) void prologue_kernel(StreamState *__restrict__ states,
+__global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *__restrict__ states,
                                                                const uint8_t *__restrict__ frames_main,
                                                                const uint8_t *__restrict__ frames_aux, int n_frames,
                                                                int frame, int is_aux,
                                                                const uint16_t *__restrict__ table,
                                                                const ulonglong2 *__restrict__ strings,
-                                                               const uint16_t *__restrict__ sub)
+                                                               const uint16_t *__restrict__ sub, int need)
 {
     constexpr int BITS = ModeTraits<MODE>::kBits;
     constexpr int NB = ModeTraits<MODE>::kBanks;
@@ -160,6 +194,7 @@ __global__ __launch_bounds__(kProThreads) void prologue_kernel(StreamState *__re
     if (DP && tid < 256) lut[tid] = sub[tid];
     __syncthreads();
 
+    const int tgt_first = tgt[(MODE == kDHGR && is_aux) ? 1 : 0][0];
     // 8 consecutive bytes of one page row per thread (row-major, as nonzero() walks them)
     const int i0 = tid * 8;
     const int page = i0 >> 8;
@@ -174,11 +209,13 @@ __global__ __launch_bounds__(kProThreads) void prologue_kernel(StreamState *__re
         upv[0] = a.x; upv[1] = a.y; upv[2] = a.z; upv[3] = a.w;
         upv[4] = b.x; upv[5] = b.y; upv[6] = b.z; upv[7] = b.w;
     }
-    uint32_t dwv[8];
+    uint32_t dwv[8], tmv[8], cv[8];
     int bad = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         int y = (i0 & 255) + j;
+        tmv[j] = 0;
+        cv[j] = tgt_own[y];
         if (is_hole(y)) {
             dwv[j] = 0;  // video.py:111
             if (cur_own[y] != 0) bad = kErrHoles;  // video.py:87
@@ -191,6 +228,7 @@ __global__ __launch_bounds__(kProThreads) void prologue_kernel(StreamState *__re
         neighbours<MODE>(tgt_own, tgt_oth, y, is_aux, tp, tn);
         uint32_t cm = masked_window<MODE>(cp, cur_own[y], cn, odd);
         uint32_t tm = masked_window<MODE>(tp, tgt_own[y], tn, odd);
+        tmv[j] = tm;
         if (DP) {
             dwv[j] = 0;
             if (cm != tm) {
@@ -217,33 +255,73 @@ __global__ __launch_bounds__(kProThreads) void prologue_kernel(StreamState *__re
         int4 *p = reinterpret_cast<int4 *>(S.up[is_aux] + i0);
         p[0] = make_int4(upv[0], upv[1], upv[2], upv[3]);
         p[1] = make_int4(upv[4], upv[5], upv[6], upv[7]);
-        uint4 d;
-        d.x = dwv[0] | (dwv[1] << 16);
-        d.y = dwv[2] | (dwv[3] << 16);
-        d.z = dwv[4] | (dwv[5] << 16);
-        d.w = dwv[6] | (dwv[7] << 16);
-        *reinterpret_cast<uint4 *>(S.dw + i0) = d;
+        uint4 *q = reinterpret_cast<uint4 *>(S.wd + i0);
+        q[0] = make_uint4(tmv[0] | (dwv[0] << 16), tmv[1] | (dwv[1] << 16), tmv[2] | (dwv[2] << 16),
+                          tmv[3] | (dwv[3] << 16));
+        q[1] = make_uint4(tmv[4] | (dwv[4] << 16), tmv[5] | (dwv[5] << 16), tmv[6] | (dwv[6] << 16),
+                          tmv[7] | (dwv[7] << 16));
+        reinterpret_cast<uint8_t *>(S.nzbits)[tid] = (uint8_t)nzmask;  // bit j of byte tid = byte 8*tid+j
+        if (tid < 256) S.pdone[tid] = 0;
     }
     if (bad) flag_bad = bad;
 
-    // exclusive scan of per-thread non-zero counts (row-major rank of each entry)
-    const int cnt = __popc(nzmask);
-    int incl = cnt;
+    // row-major rank of each non-zero entry (its index into the nonce draw, video.py:259-265)
+    int n;
+    const int rank0 = block_scan_excl<kProThreads>(__popc(nzmask), tid, wsum, n);
+
+    // ---- optional prefix selection.  A generator that will be asked for at most B
+    // opcodes consumes at most 3B list entries (one primary and at most two
+    // secondaries resolved to zero per opcode), so when the host knows B (`need` = 3B)
+    // only the `need` highest priorities have to be ordered.  Selection is by a
+    // 1024-bucket histogram of the priorities; every entry of the boundary bucket is
+    // kept, so the kept set is a superset of the true top-`need`.
+    uint32_t selmask = nzmask;
+    int n_sel = n;
+    bool partial = need > 0 && need <= kSelNeedMax;
+    if (partial && n > need) {
+        uint32_t *hist = reinterpret_cast<uint32_t *>(nonce);  // 4 KiB of the (not yet used) nonce buffer
+        int mx = 0;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int v = __shfl_up(incl, d, 64);
-        if (lane_id() >= d) incl += v;
+        for (int j = 0; j < 8; j++) mx = upv[j] > mx ? upv[j] : mx;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int o = __shfl_xor(mx, d, 64);
+            mx = o > mx ? o : mx;
+        }
+        hist[tid] = 0;
+        __syncthreads();  // (also orders the previous wsum reads before this write)
+        if ((tid & 63) == 0) wsum[tid >> 6] = (uint32_t)mx;
+        __syncthreads();
+        for (int w = 0; w < kProThreads / 64; w++) mx = (int)wsum[w] > mx ? (int)wsum[w] : mx;
+        const int sh = mx < 1024 ? 0 : (32 - __clz(mx)) - 10;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (nzmask & (1u << j)) atomicAdd(&hist[upv[j] >> sh], 1u);
+        __syncthreads();
+        // thread t looks at bucket 1023 - t: cumulative count from the top bucket down
+        const int c = (int)hist[1023 - tid];
+        int total_unused;
+        const int before = block_scan_excl<kProThreads>(c, tid, wsum, total_unused);
+        __shared__ int sel_bucket, sel_count;
+        if (before < need && before + c >= need) {
+            sel_bucket = 1023 - tid;
+            sel_count = before + c;
+        }
+        __syncthreads();
+        n_sel = sel_count;
+        if (n_sel <= kSelCap) {
+            selmask = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if ((nzmask & (1u << j)) && (upv[j] >> sh) >= sel_bucket) selmask |= 1u << j;
+        } else {
+            partial = false;  // degenerate priority distribution: order everything
+            n_sel = n;
+        }
+        __syncthreads();  // hist (aliasing nonce[]) is dead from here on
+    } else if (partial && n > kSelCap) {
+        partial = false;
     }
-    if (lane_id() == 63) wsum[tid >> 6] = (uint32_t)incl;
-    __syncthreads();
-    int wbase = 0, total = 0;
-    for (int w = 0; w < kProThreads / 64; w++) {
-        int v = (int)wsum[w];
-        if (w < (tid >> 6)) wbase += v;
-        total += v;
-    }
-    const int rank0 = wbase + incl - cnt;
-    const int n = total;
 
     // n draws of np.random.randint(0, 256): low byte of the next n MT outputs (video.py:265)
     int idx = S.mt_np_idx;
@@ -275,7 +353,7 @@ __global__ __launch_bounds__(kProThreads) void prologue_kernel(StreamState *__re
     }
 
     // keys (-priority, nonce, page, offset) -> ascending u64 (video.py:259-268); bytes
-    // whose priority is zero get the all-ones key and sink to the end
+    // whose priority is zero (or that were not selected) get the all-ones key and sink
     unsigned long long kv[8];
     {
         int r = rank0;
@@ -283,30 +361,53 @@ __global__ __launch_bounds__(kProThreads) void prologue_kernel(StreamState *__re
         for (int j = 0; j < 8; j++) {
             kv[j] = ~0ull;
             if (nzmask & (1u << j)) {
-                kv[j] = ((unsigned long long)(0x7fffffffu - (uint32_t)upv[j]) << 21) |
-                        ((unsigned long long)nonce[r] << 13) | (unsigned long long)(i0 + j);
+                // the content byte rides in the low bits (offsets are unique, so it never
+                // takes part in the ordering)
+                if (selmask & (1u << j))
+                    kv[j] = ((unsigned long long)(0x7fffffffu - (uint32_t)upv[j]) << 29) |
+                            ((unsigned long long)nonce[r] << 21) | ((unsigned long long)(i0 + j) << 8) |
+                            (unsigned long long)cv[j];
                 r++;
             }
         }
     }
-    // (the scan's barrier above already separates the last read of cur/tgt from this reuse)
-    bitonic_sort8<kProThreads>(kv, keys, tid);
-    {
-        uint4 o;
-        o.x = (uint32_t)(kv[0] & 0x1fff) | ((uint32_t)(kv[1] & 0x1fff) << 16);
-        o.y = (uint32_t)(kv[2] & 0x1fff) | ((uint32_t)(kv[3] & 0x1fff) << 16);
-        o.z = (uint32_t)(kv[4] & 0x1fff) | ((uint32_t)(kv[5] & 0x1fff) << 16);
-        o.w = (uint32_t)(kv[6] & 0x1fff) | ((uint32_t)(kv[7] & 0x1fff) << 16);
-        *reinterpret_cast<uint4 *>(S.order + i0) = o;  // entries >= n are never read
+    int nt = kProThreads;
+    if (partial) {
+        // compact the selected keys into LDS, then let the first n_pad/8 threads sort them
+        int tot;
+        int pos = block_scan_excl<kProThreads>(__popc(selmask), tid, wsum, tot);
+        const int n_pad = tot <= 2048 ? 2048 : 4096;
+        nt = n_pad / 8;
+        for (int i = tot + tid; i < n_pad; i += kProThreads) keys[i] = ~0ull;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (selmask & (1u << j)) keys[pos++] = kv[j];
+        __syncthreads();
+        if (tid < nt) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) kv[j] = keys[8 * tid + j];
+        }
+        __syncthreads();
+    }
+    bitonic_sort8(kv, keys, tid, nt);
+    if (tid < nt) {
+        uint32_t o[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = ((uint32_t)(kv[j] >> 8) & 0x1fffu) | (((uint32_t)kv[j] & 0xffu) << 16);
+        uint4 *q = reinterpret_cast<uint4 *>(S.order + i0);  // entries >= n_sel are never read
+        q[0] = make_uint4(o[0], o[1], o[2], o[3]);
+        q[1] = make_uint4(o[4], o[5], o[6], o[7]);
     }
     if (tid == 0) {
-        S.n_sorted = n;
+        S.n_sorted = n_sel;
+        S.truncated = n_sel < n ? 1 : 0;
         S.head = 0;
         S.n_pushed = 0;
         S.exhausted = 0;
         S.gen_active = 1;
         S.gen_is_aux = is_aux;
         S.gen_frame = frame;
+        S.pad_content = tgt_first;
         if (flag_bad && S.error == 0) S.error = flag_bad;
     }
 }
@@ -355,15 +456,10 @@ __global__ __launch_bounds__(256) void greedy_kernel(StreamState *__restrict__ s
             src = frames_main + fbase;
         reinterpret_cast<uint4 *>(tgt[b])[k] = reinterpret_cast<const uint4 *>(src)[k];
     }
-    for (int i = tid; i < 1024; i += 256) {
-        uint4 d = reinterpret_cast<const uint4 *>(S.dw)[i];
-        const int4 *up = reinterpret_cast<const int4 *>(S.up[is_aux] + i * 8);
-        int4 u0 = up[0], u1 = up[1];
-        d.x |= (u0.x ? 0x8000u : 0u) | (u0.y ? 0x80000000u : 0u);
-        d.y |= (u0.z ? 0x8000u : 0u) | (u0.w ? 0x80000000u : 0u);
-        d.z |= (u1.x ? 0x8000u : 0u) | (u1.y ? 0x80000000u : 0u);
-        d.w |= (u1.z ? 0x8000u : 0u) | (u1.w ? 0x80000000u : 0u);
-        reinterpret_cast<uint4 *>(dwf)[i] = d;
+    for (int i = tid; i < 8192; i += 256) {
+        uint32_t bit = (S.nzbits[i >> 5] >> (i & 31)) & 1u;
+        uint32_t dn = (S.pdone[i >> 5] >> (i & 31)) & 1u;
+        dwf[i] = (uint16_t)((dn ? 0u : (S.wd[i] >> 16)) | (bit << 15));
     }
     for (int i = tid; i < 624; i += 256) mt[0][i] = S.mt_py[i];
     __syncthreads();
@@ -414,7 +510,7 @@ __global__ __launch_bounds__(256) void greedy_kernel(StreamState *__restrict__ s
         __syncthreads();  // validity flags written by their owner lanes -> visible to the scan
         if (head < n_sorted) {
             int idx = head + lane;
-            uint32_t e = idx < n_sorted ? (uint32_t)S.order[idx] : 0u;
+            uint32_t e = idx < n_sorted ? (S.order[idx] & 0x1fffu) : 0u;
             bool v = idx < n_sorted && (dwf[e] & 0x8000u);
             unsigned long long mask = __ballot(v);
             int window_end = head + 64 < n_sorted ? head + 64 : n_sorted;
@@ -436,6 +532,10 @@ __global__ __launch_bounds__(256) void greedy_kernel(StreamState *__restrict__ s
             }
             chunk_end = mask ? pos[kChunk - 1] + 1 : window_end;
         } else {
+            if (S.truncated) {  // more initial entries exist than were ordered: host budget bug
+                err = kErrSortBudget;
+                break;
+            }
             // pop-min over the pushed bag
             from_pushed = true;
             unsigned long long best = ~0ull;
@@ -606,12 +706,18 @@ __global__ __launch_bounds__(256) void greedy_kernel(StreamState *__restrict__ s
         if (!from_pushed && !err && done < n_ops) head = chunk_end > head ? chunk_end : head;
     }
 
-    // ---- write the generator back
+    // ---- write the generator back (flags as bitmaps; diff weights themselves are immutable)
     __syncthreads();
-    for (int i = tid; i < 1024; i += 256) {
-        uint4 d = reinterpret_cast<const uint4 *>(dwf)[i];
-        d.x &= 0x7fff7fffu; d.y &= 0x7fff7fffu; d.z &= 0x7fff7fffu; d.w &= 0x7fff7fffu;
-        reinterpret_cast<uint4 *>(S.dw)[i] = d;
+    for (int wi = tid; wi < 256; wi += 256) {
+        uint32_t nzw = 0, pdw = S.pdone[wi];
+        for (int b = 0; b < 32; b++) {
+            uint32_t v = dwf[wi * 32 + b];
+            nzw |= ((v >> 15) & 1u) << b;
+            // a byte whose diff weight was non-zero at the prologue and is zero now was a primary
+            if ((v & 0x7fffu) == 0 && (S.wd[wi * 32 + b] >> 16) != 0) pdw |= 1u << b;
+        }
+        S.nzbits[wi] = nzw;
+        S.pdone[wi] = pdw;
     }
     for (int i = tid; i < 624; i += 256) S.mt_py[i] = mt[cb][i];
     if (tid == 0) {
@@ -654,7 +760,7 @@ template <int CTRL> __device__ static inline void top2_step(uint32_t &k1, uint32
 }
 
 template <int MODE>
-__global__ __launch_bounds__(64) void greedy_wave_kernel(StreamState *__restrict__ states,
+__global__ __launch_bounds__(64, 4) void greedy_wave_kernel(StreamState *__restrict__ states,
                                                          const uint8_t *__restrict__ frames_main,
                                                          const uint8_t *__restrict__ frames_aux, int n_frames,
                                                          int frame, int is_aux, int n_ops,
@@ -664,41 +770,28 @@ __global__ __launch_bounds__(64) void greedy_wave_kernel(StreamState *__restrict
 {
     constexpr int BITS = ModeTraits<MODE>::kBits;
     constexpr int CB = ModeTraits<MODE>::kContentBits;
-    constexpr int NB = ModeTraits<MODE>::kBanks;
     constexpr uint32_t INF = 0xffffffffu;
     constexpr int M = kChunk;
-    __shared__ __attribute__((aligned(16))) uint8_t tgt[NB][8192];  // [0] = bank being encoded, [NB-1] = the other
-    __shared__ __attribute__((aligned(16))) uint16_t dwf[8192];     // diff_weight | (priority != 0) << 15
-    __shared__ uint32_t mt[2 * 624];                                // two consecutive MT19937 blocks
+    // LDS per stream: two 1 KiB bitmaps + two MT19937 blocks (~7 KiB), so residency is
+    // set by registers (4 waves per SIMD), not by LDS.  The per-byte rows a step needs
+    // (target window | diff weight, written once by the prologue and immutable while
+    // the generator lives) are fetched from L2 for a whole chunk at a time.
+    __shared__ uint32_t nz[256];     // update_priority != 0
+    __shared__ uint32_t pdone[256];  // byte already emitted as a primary (its diff weight counts as 0)
+    __shared__ uint32_t mt[2 * 624];
 
     const int lane = threadIdx.x;
     StreamState &S = states[blockIdx.x];
-    const size_t fbase = ((size_t)blockIdx.x * n_frames + frame) * 8192;
     uint8_t *out = ops_out + (size_t)blockIdx.x * ops_stride + ops_base;
+    (void)frames_main; (void)frames_aux; (void)n_frames; (void)frame;
 
     if (!S.gen_active || S.error) {
         if (lane == 0 && !S.error) S.error = kErrNoGenerator;
         return;
     }
-
-    for (int i = lane; i < 512 * NB; i += 64) {
-        int b = i >> 9, k = i & 511;
-        const uint8_t *src;
-        if (MODE == kDHGR)
-            src = ((b == 0) == (is_aux != 0) ? frames_aux : frames_main) + fbase;
-        else
-            src = frames_main + fbase;
-        reinterpret_cast<uint4 *>(tgt[b])[k] = reinterpret_cast<const uint4 *>(src)[k];
-    }
-    for (int i = lane; i < 1024; i += 64) {
-        uint4 d = reinterpret_cast<const uint4 *>(S.dw)[i];
-        const int4 *up = reinterpret_cast<const int4 *>(S.up[is_aux] + i * 8);
-        int4 u0 = up[0], u1 = up[1];
-        d.x |= (u0.x ? 0x8000u : 0u) | (u0.y ? 0x80000000u : 0u);
-        d.y |= (u0.z ? 0x8000u : 0u) | (u0.w ? 0x80000000u : 0u);
-        d.z |= (u1.x ? 0x8000u : 0u) | (u1.y ? 0x80000000u : 0u);
-        d.w |= (u1.z ? 0x8000u : 0u) | (u1.w ? 0x80000000u : 0u);
-        reinterpret_cast<uint4 *>(dwf)[i] = d;
+    for (int i = lane; i < 256; i += 64) {
+        nz[i] = S.nzbits[i];
+        pdone[i] = S.pdone[i];
     }
     for (int i = lane; i < 624; i += 64) mt[i] = S.mt_py[i];
     __syncthreads();
@@ -715,9 +808,10 @@ __global__ __launch_bounds__(64) void greedy_wave_kernel(StreamState *__restrict
     int head = S.head, n_pushed = S.n_pushed, exhausted = S.exhausted;
     int done = 0, err = 0;
     unsigned long long draws = 0, pad_ops = 0;
-    // store-table bases for this lane's even (r = 0,2) and odd (r = 1,3) bytes
     const uint16_t *store_e = store + ((size_t)byte_offset<MODE>(0, is_aux) << (CB + BITS));
     const uint16_t *store_d = store + ((size_t)byte_offset<MODE>(1, is_aux) << (CB + BITS));
+    const uint32_t pad_content = S.pad_content;
+    const int bshift = (4 * lane) & 31;  // this lane's 4 bits inside a bitmap word
 
     int guard = n_ops + 8192 + 2 * kPushedCap + 64;
     while (done < n_ops && !err) {
@@ -726,25 +820,25 @@ __global__ __launch_bounds__(64) void greedy_wave_kernel(StreamState *__restrict
             break;
         }
         if (exhausted) {
-            uint32_t c0 = tgt[0][0];  // video.py:249-251
-            for (int i = done + lane; i < n_ops; i += 64) {
+            for (int i = done + lane; i < n_ops; i += 64) {  // video.py:249-251
                 uint8_t *q = out + (size_t)i * 6;
-                q[0] = 32; q[1] = (uint8_t)c0; q[2] = 0; q[3] = 0; q[4] = 0; q[5] = 0;
+                q[0] = 32; q[1] = (uint8_t)pad_content; q[2] = 0; q[3] = 0; q[4] = 0; q[5] = 0;
             }
             pad_ops += (unsigned long long)(n_ops - done);
             done = n_ops;
             break;
         }
 
-        // ---- form a chunk
-        uint32_t ent[M];
+        // ---- form a chunk: next <= M entries whose priority is still non-zero
+        uint32_t ent[M];  // page << 8 | offset | content << 16
         int pos[M];
         int cnt = 0, chunk_end = head;
         bool from_pushed = false;
         if (head < n_sorted) {
             int idx = head + lane;
-            uint32_t e = idx < n_sorted ? (uint32_t)S.order[idx] : 0u;
-            bool v = idx < n_sorted && (dwf[e] & 0x8000u);
+            uint32_t e = idx < n_sorted ? S.order[idx] : 0u;
+            uint32_t loc = e & 0x1fffu;
+            bool v = idx < n_sorted && ((nz[loc >> 5] >> (loc & 31)) & 1u);
             unsigned long long mask = __ballot(v);
             int window_end = head + 64 < n_sorted ? head + 64 : n_sorted;
             if (mask == 0) {
@@ -765,6 +859,10 @@ __global__ __launch_bounds__(64) void greedy_wave_kernel(StreamState *__restrict
             }
             chunk_end = mask ? pos[M - 1] + 1 : window_end;
         } else {
+            if (S.truncated) {  // more initial entries exist than were ordered: host budget bug
+                err = kErrSortBudget;
+                break;
+            }
             from_pushed = true;
             unsigned long long best = ~0ull;
             for (int i = lane; i < n_pushed; i += 64) {
@@ -782,83 +880,58 @@ __global__ __launch_bounds__(64) void greedy_wave_kernel(StreamState *__restrict
                 continue;
             }
             if (lane == 0) S.pushed[(uint32_t)best] = INF;
-            __builtin_amdgcn_s_waitcnt(0);  // the store above precedes the next scan of pushed[]
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // that store precedes the next scan of pushed[]
 #pragma unroll
             for (int m = 0; m < M; m++) {
                 ent[m] = 0;
                 pos[m] = 0;
             }
-            ent[0] = bk & 0x1fff;
+            // pushed keys do not carry the content byte: it is the target byte of that offset
+            uint32_t loc = bk & 0x1fffu;
+            uint32_t c = (MODE == kDHGR && is_aux ? frames_aux : frames_main)[((size_t)blockIdx.x * n_frames + frame) * 8192 + loc];
+            ent[0] = loc | (c << 16);
             cnt = 1;
         }
 
-        // ---- gather the store-table rows of the chunk (all in flight together)
+        // ---- fetch the chunk's rows: (window | diff weight) x4 per lane, then the store-table values.
+        // Branch-free on purpose (slots beyond cnt repeat entry 0): a branch makes the compiler
+        // retire each slot's loads before issuing the next slot's.
+        uint4 wdv[M];
+#pragma unroll
+        for (int m = 0; m < M; m++)
+            wdv[m] = reinterpret_cast<const uint4 *>(S.wd + ((ent[m] >> 8) & 31) * 256)[lane];
         uint32_t ndv[M][4];
-        // (branch-free on purpose: slots beyond cnt hold entry 0 and gather a harmless
-        // row; a branch here makes the compiler wait for each slot's loads in turn)
 #pragma unroll
         for (int m = 0; m < M; m++) {
-            {
-                const int p = ent[m] >> 8;
-                const uint32_t c = tgt[0][ent[m]];
-                const uint8_t *own_row = tgt[0] + p * 256;
-                const uint8_t *oth_row = tgt[NB - 1] + p * 256;
-                const uint32_t own4 = *reinterpret_cast<const uint32_t *>(own_row + 4 * lane);
-                // `seq` holds the neighbour bytes of this lane's four bytes in dot order
-                unsigned long long seq;
-                int nshift;  // next(r) = byte (r + nshift) of seq, prev(r) = byte r
-                if (MODE == kDHGR) {
-                    const uint32_t oth4 = *reinterpret_cast<const uint32_t *>(oth_row + 4 * lane);
-                    if (is_aux) {  // prev = main[y-1], next = main[y]
-                        uint32_t before = lane > 0 ? oth_row[4 * lane - 1] : 0u;
-                        seq = (unsigned long long)before | ((unsigned long long)oth4 << 8);
-                    } else {       // prev = aux[y], next = aux[y+1]
-                        uint32_t after = lane < 63 ? oth_row[4 * lane + 4] : 0u;
-                        seq = (unsigned long long)oth4 | ((unsigned long long)after << 32);
-                    }
-                    nshift = 1;
-                } else {           // prev = main[y-1], next = main[y+1]
-                    uint32_t before = lane > 0 ? own_row[4 * lane - 1] : 0u;
-                    uint32_t after = lane < 63 ? own_row[4 * lane + 4] : 0u;
-                    seq = (unsigned long long)before | ((unsigned long long)own4 << 8) |
-                          ((unsigned long long)after << 40);
-                    nshift = 2;
-                }
-                const size_t cbase = (size_t)(c & ((1u << CB) - 1)) << BITS;
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    uint32_t pv = (uint32_t)(seq >> (8 * r)) & 0xff;
-                    uint32_t nx = (uint32_t)(seq >> (8 * (r + nshift))) & 0xff;
-                    uint32_t ob = (own4 >> (8 * r)) & 0xff;
-                    uint32_t win = masked_window<MODE>(pv, ob, nx, r & 1);
-                    ndv[m][r] = ((r & 1) ? store_d : store_e)[cbase + win];
-                }
-            }
+            const size_t cbase = (size_t)((ent[m] >> 16) & ((1u << CB) - 1)) << BITS;
+            ndv[m][0] = store_e[cbase + (wdv[m].x & 0xffffu)];
+            ndv[m][1] = store_d[cbase + (wdv[m].y & 0xffffu)];
+            ndv[m][2] = store_e[cbase + (wdv[m].z & 0xffffu)];
+            ndv[m][3] = store_d[cbase + (wdv[m].w & 0xffffu)];
         }
-
-        // vmcnt is one in-order counter for loads AND stores: retire the chunk's gathers
-        // here, once, before the steps below start issuing stores -- otherwise the first
-        // use of a late entry's row would also wait for every store issued before it.
+        // vmcnt is one in-order counter for loads AND stores: retire the gathers once, here,
+        // before the steps below start issuing stores.
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 
         // ---- process the chunk
 #pragma unroll
         for (int m = 0; m < M; m++) {
             if (m >= cnt || done >= n_ops || err) break;
-            // video.py:130 -- a byte resolved since the chunk was formed is skipped
-            const uint32_t fl = __builtin_amdgcn_readfirstlane((uint32_t)dwf[ent[m]]);
-            if (!(fl & 0x8000u)) {
+            const int p = (ent[m] >> 8) & 31, x = ent[m] & 255;
+            const uint32_t c = (ent[m] >> 16) & 0xffu;  // video.py:134
+            // video.py:130 -- skip a byte whose priority was cleared since the chunk was formed
+            const uint32_t xw = __builtin_amdgcn_readfirstlane(nz[p * 8 + (x >> 5)]);
+            if (!((xw >> (x & 31)) & 1u)) {
                 if (!from_pushed) head = pos[m] + 1;
                 continue;
             }
-            const int p = ent[m] >> 8, x = ent[m] & 255;
-            const uint32_t c = __builtin_amdgcn_readfirstlane((uint32_t)tgt[0][ent[m]]);  // video.py:134
             if (MODE == kDHGR && c >= 0x80) {  // video.py:137
                 err = kErrPaletteBit;
                 break;
             }
-            const unsigned long long w4 = *reinterpret_cast<const unsigned long long *>(dwf + p * 256 + 4 * lane);
-            uint32_t w[4];
+            const uint32_t nz4 = (nz[p * 8 + (lane >> 3)] >> bshift) & 0xfu;
+            const uint32_t pd4 = (pdone[p * 8 + (lane >> 3)] >> bshift) & 0xfu;
+            const uint32_t wdr[4] = {wdv[m].x, wdv[m].y, wdv[m].z, wdv[m].w};
             int d[4];
             bool cand[4], nzy[4];
             unsigned long long bal[4];
@@ -866,11 +939,11 @@ __global__ __launch_bounds__(64) void greedy_wave_kernel(StreamState *__restrict
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int y = 4 * lane + r;
-                w[r] = (uint32_t)(w4 >> (16 * r)) & 0xffffu;
-                const uint32_t dwy = (y == x) ? 0u : (w[r] & 0x7fffu);   // video.py:141
-                nzy[r] = (w[r] & 0x8000u) && (y != x);                   // video.py:140
-                d[r] = (int)ndv[m][r] - (int)dwy;                        // screen.py:547
-                cand[r] = d[r] < 0;                                      // video.py:283
+                const bool gone = ((pd4 >> r) & 1u) || (y == x);          // video.py:141
+                const uint32_t dwy = gone ? 0u : (wdr[r] >> 16);
+                nzy[r] = ((nz4 >> r) & 1u) && (y != x);                   // video.py:140
+                d[r] = (int)ndv[m][r] - (int)dwy;                         // screen.py:547
+                cand[r] = d[r] < 0;                                       // video.py:283
                 bal[r] = __ballot(cand[r]);
                 below += prefix_popc(bal[r]);
                 C += (int)__popcll(bal[r]);
@@ -904,7 +977,6 @@ __global__ __launch_bounds__(64) void greedy_wave_kernel(StreamState *__restrict
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 uint32_t r1 = __builtin_amdgcn_readlane(k1, 16 * q), r2 = __builtin_amdgcn_readlane(k2, 16 * q);
-                // merge sorted pair (r1 <= r2) into (K1 <= K2)
                 uint32_t lo = K1 < r1 ? K1 : r1, hi = K1 < r1 ? r1 : K1;
                 uint32_t m2 = K2 < r2 ? K2 : r2;
                 K1 = lo;
@@ -920,8 +992,19 @@ __global__ __launch_bounds__(64) void greedy_wave_kernel(StreamState *__restrict
             }
 
             // ---- apply (video.py:140-144, 170-178; screen.py:256-293)
+            if (lane < 8) {
+                // lane w owns word w of page p in both bitmaps
+                uint32_t clr = 0, setp = 0;
+                if ((x >> 5) == lane) {
+                    clr |= 1u << (x & 31);
+                    setp |= 1u << (x & 31);
+                }
+                if (y1 >= 0 && !f1 && (y1 >> 5) == lane) clr |= 1u << (y1 & 31);
+                if (y2 >= 0 && !f2 && (y2 >> 5) == lane) clr |= 1u << (y2 & 31);
+                if (clr) nz[p * 8 + lane] &= ~clr;
+                if (setp) pdone[p * 8 + lane] |= setp;
+            }
             if (lane == 0) {
-                dwf[p * 256 + x] = 0;
                 S.up[is_aux][p * 256 + x] = 0;
                 S.mem[is_aux][p * 256 + x] = (uint8_t)c;
                 uint8_t *q = out + (size_t)done * 6;
@@ -938,10 +1021,8 @@ __global__ __launch_bounds__(64) void greedy_wave_kernel(StreamState *__restrict
                 if (ys >= 0 && (ys >> 2) == lane) {
                     const int r = ys & 3;
                     const uint32_t nd = r == 0 ? ndv[m][0] : r == 1 ? ndv[m][1] : r == 2 ? ndv[m][2] : ndv[m][3];
-                    const uint32_t wv = r == 0 ? w[0] : r == 1 ? w[1] : r == 2 ? w[2] : w[3];
                     S.up[is_aux][p * 256 + ys] = (int32_t)nd;  // byte_pair_difference == nd (screen.py:383-398)
                     S.mem[is_aux][p * 256 + ys] = (uint8_t)c;
-                    dwf[p * 256 + ys] = (uint16_t)((wv & 0x7fffu) | (nd ? 0x8000u : 0u));
                     if (nd) {
                         int j = mt_idx + cb * 624 + C + (s2 ? f1 : 0);
                         if (j >= 1248) j -= 1248;
@@ -967,10 +1048,9 @@ __global__ __launch_bounds__(64) void greedy_wave_kernel(StreamState *__restrict
     }
 
     __syncthreads();
-    for (int i = lane; i < 1024; i += 64) {
-        uint4 d = reinterpret_cast<const uint4 *>(dwf)[i];
-        d.x &= 0x7fff7fffu; d.y &= 0x7fff7fffu; d.z &= 0x7fff7fffu; d.w &= 0x7fff7fffu;
-        reinterpret_cast<uint4 *>(S.dw)[i] = d;
+    for (int i = lane; i < 256; i += 64) {
+        S.nzbits[i] = nz[i];
+        S.pdone[i] = pdone[i];
     }
     for (int i = lane; i < 624; i += 64) S.mt_py[i] = mt[624 * cb + i];
     if (lane == 0) {
@@ -999,6 +1079,7 @@ struct Encoder {
     uint16_t *d_sub;        // 16x16 substitute costs
     int dw_mode;            // IIV_DW_TABLE / IIV_DW_RECURRENCE
     int greedy_mode;        // IIV_GREEDY_WAVE / IIV_GREEDY_WORKGROUP
+    int partial_sort;       // allow the prologue's prefix sort when the budget is known
     StreamState *d_states;
     // generator bookkeeping shared by all streams (same schedule)
     int gen_active, gen_is_aux, gen_frame;
@@ -1052,7 +1133,8 @@ int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, c
     e->d_strings = nullptr;
     e->d_sub = nullptr;
     e->dw_mode = dm ? IIV_DW_RECURRENCE : IIV_DW_TABLE;
-    e->greedy_mode = IIV_GREEDY_WORKGROUP;
+    e->greedy_mode = IIV_GREEDY_AUTO;
+    e->partial_sort = 1;
     e->gen_active = 0;
     e->gen_is_aux = 0;
     e->gen_frame = 0;
@@ -1114,8 +1196,13 @@ int encoder_set_option(Encoder *e, int option, int value)
         e->dw_mode = value;
         return IIV_OK;
     }
+    if (option == IIV_OPT_PREFIX_SORT) {
+        e->partial_sort = value ? 1 : 0;
+        return IIV_OK;
+    }
     if (option == IIV_OPT_GREEDY_KERNEL) {
-        if (value != IIV_GREEDY_WAVE && value != IIV_GREEDY_WORKGROUP) return set_error(IIV_ERR_INVALID, "bad value");
+        if (value != IIV_GREEDY_WAVE && value != IIV_GREEDY_WORKGROUP && value != IIV_GREEDY_AUTO)
+            return set_error(IIV_ERR_INVALID, "bad value");
         e->greedy_mode = value;
         return IIV_OK;
     }
@@ -1288,12 +1375,28 @@ int encode(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux, int n_frames
             if (e->gen_active == 2) need_prologue = true;
         }
         size_t slot = 0;
+        int need = 0;
+        if (need_prologue && e->partial_sort) {
+            // opcodes this generator can be asked for = n_ops of this segment and of the
+            // restart == 0 segments that follow it -- known only if another restart comes
+            // later in this call (otherwise a later call might continue the generator)
+            long budget = g.n_ops;
+            bool closed = false;
+            for (int k = i + 1; k < n_segs; k++) {
+                if (segs[k].restart) {
+                    closed = true;
+                    break;
+                }
+                budget += segs[k].n_ops;
+            }
+            if (closed && 3 * budget <= kSelNeedMax) need = (int)(3 * budget);
+        }
         if (need_prologue) {
             if (e->profiling) { int prc = prof_begin(e, 0, st, slot); if (prc) return prc; }
             const bool dp = e->dw_mode == IIV_DW_RECURRENCE;
 #define IIV_PRO(M, D)                                                                                              \
     hipLaunchKernelGGL((prologue_kernel<M, D>), dim3(e->n_streams), dim3(kProThreads), 0, st, e->d_states, d_main, \
-                       d_aux, n_frames, g.frame, g.is_aux, e->d_table, e->d_strings, e->d_sub)
+                       d_aux, n_frames, g.frame, g.is_aux, e->d_table, e->d_strings, e->d_sub, need)
             if (e->mode == kDHGR) {
                 if (dp) IIV_PRO(kDHGR, true); else IIV_PRO(kDHGR, false);
             } else {
@@ -1310,7 +1413,11 @@ int encode(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux, int n_frames
 #define IIV_GREEDY(K, T)                                                                                        \
     hipLaunchKernelGGL(K, dim3(e->n_streams), dim3(T), 0, st, e->d_states, d_main, d_aux, n_frames, g.frame,       \
                        g.is_aux, g.n_ops, e->d_store, d_ops, stride, done * 6)
-        if (e->greedy_mode == IIV_GREEDY_WAVE) {
+        // few streams: the 4-wave workgroup has the shorter dependent chain per opcode;
+        // many streams: the one-wave kernel keeps 16 streams resident per CU instead of 4
+        const bool use_wave = e->greedy_mode == IIV_GREEDY_WAVE ||
+                              (e->greedy_mode == IIV_GREEDY_AUTO && e->n_streams >= 1536);
+        if (use_wave) {
             if (e->mode == kDHGR) IIV_GREEDY(greedy_wave_kernel<kDHGR>, 64); else IIV_GREEDY(greedy_wave_kernel<kHGR>, 64);
         } else {
             if (e->mode == kDHGR) IIV_GREEDY(greedy_kernel<kDHGR>, 256); else IIV_GREEDY(greedy_kernel<kHGR>, 256);
@@ -1359,10 +1466,11 @@ int encoder_check(Encoder *e, int *bad_stream, hipStream_t st)
                                   "DHGR content byte has the palette bit set (video.py:137)",
                                   "pushed-entry capacity exceeded",
                                   "next() on a stream with no generator",
-                                  "internal: greedy loop guard tripped"};
+                                  "internal: greedy loop guard tripped",
+                                  "internal: prefix sort exhausted before the opcode budget"};
     int is_overflow = code == kErrPushedOverflow;
     return set_error(is_overflow ? IIV_ERR_OVERFLOW : IIV_ERR_ASSERT, "stream %d: %s", first,
-                     (code > 0 && code < 7) ? names[code] : "unknown error");
+                     (code > 0 && code < 8) ? names[code] : "unknown error");
 }
 
 }  // namespace iiv

@@ -22,13 +22,15 @@ def _seed_states(O, seed_py, seed_np):
     return O.mt_seed_py(seed_py).state_words(), O.mt_seed_np(seed_np).state_words()
 
 
-def _run_device(native, device_tables, mode, pal, frames_list, sched, seeds, recurrence=True, wave=True):
+def _run_device(native, device_tables, mode, pal, frames_list, sched, seeds, recurrence=True, wave=True,
+                prefix_sort=True):
     """frames_list: list (per stream) of (n_frames, banks, 32, 256) arrays."""
     import torch
     t, s = device_tables.get(mode, pal)
     n = len(frames_list)
     enc = native.Encoder(mode, t, s, n, dm=device_tables.dm[(mode, pal)] if recurrence else None)
     enc.set_greedy_kernel(wave)
+    enc.set_prefix_sort(prefix_sort)
     fr = np.stack(frames_list)
     fm = torch.from_numpy(np.ascontiguousarray(fr[:, :, 0])).cuda()
     fa = torch.from_numpy(np.ascontiguousarray(fr[:, :, 1])).cuda() if mode == 1 else None
@@ -105,8 +107,8 @@ def _oracle_run(O, oracle_tables, mode, pal, frames, sched, sp, sn):
     return v, np.concatenate(out)
 
 
-@pytest.mark.parametrize("mode,wave", [(1, True), (0, True), (1, False)])
-def test_batch_of_independent_streams(native, O, oracle_tables, device_tables, mode, wave):
+@pytest.mark.parametrize("mode,wave,prefix", [(1, True, True), (0, True, True), (1, False, True), (1, True, False)])
+def test_batch_of_independent_streams(native, O, oracle_tables, device_tables, mode, wave, prefix):
     """12 streams with different data / seeds / coherence in ONE launch sequence,
     ragged segment lengths incl. bank flips; every stream equals its own oracle run."""
     n = 12
@@ -114,7 +116,7 @@ def test_batch_of_independent_streams(native, O, oracle_tables, device_tables, m
     frames = [_synth(mode, 3, 100 + i, coherent=(i % 2 == 1)) for i in range(n)]
     seeds = [(i + 1, 1000 + i) for i in range(n)]
     enc, got = _run_device(native, device_tables, mode, 5, frames, sched,
-                           [_seed_states(O, a, b) for a, b in seeds], wave=wave)
+                           [_seed_states(O, a, b) for a, b in seeds], wave=wave, prefix_sort=prefix)
     for i in range(n):
         v, exp = _oracle_run(O, oracle_tables, mode, 5, frames[i], sched, *seeds[i])
         assert (got[i] == exp).all(), "stream %d" % i
