@@ -79,14 +79,16 @@ __device__ static inline void cmpx(unsigned long long &lo, unsigned long long &h
 __device__ static inline void bitonic_sort8(unsigned long long (&v)[8], unsigned long long *xbuf, int tid, int nt)
 {
     const int N = 8 * nt;
-    const bool active = tid < nt;
+    const bool active = tid < nt;  // whole waves (nt is a multiple of 64)
+    if (active) {
 #pragma unroll
-    for (int k = 2; k <= 8; k <<= 1) {
+        for (int k = 2; k <= 8; k <<= 1) {
 #pragma unroll
-        for (int j = k >> 1; j >= 1; j >>= 1) {
+            for (int j = k >> 1; j >= 1; j >>= 1) {
 #pragma unroll
-            for (int r = 0; r < 8; r++)
-                if ((r & j) == 0) cmpx(v[r], v[r | j], (((8 * tid + r) & k) == 0));
+                for (int r = 0; r < 8; r++)
+                    if ((r & j) == 0) cmpx(v[r], v[r | j], (((8 * tid + r) & k) == 0));
+            }
         }
     }
     for (int k = 16; k <= N; k <<= 1) {
@@ -95,10 +97,12 @@ __device__ static inline void bitonic_sort8(unsigned long long (&v)[8], unsigned
             const int d = j >> 3;
             const bool take_min = ((tid & d) == 0) == asc;
             if (d < 64) {
+                if (active) {
 #pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    unsigned long long p = __shfl_xor(v[r], d, 64);
-                    v[r] = take_min ? (p < v[r] ? p : v[r]) : (p > v[r] ? p : v[r]);
+                    for (int r = 0; r < 8; r++) {
+                        unsigned long long p = __shfl_xor(v[r], d, 64);
+                        v[r] = take_min ? (p < v[r] ? p : v[r]) : (p > v[r] ? p : v[r]);
+                    }
                 }
             } else {
                 if (active) {
@@ -116,11 +120,13 @@ __device__ static inline void bitonic_sort8(unsigned long long (&v)[8], unsigned
                 __syncthreads();
             }
         }
+        if (active) {
 #pragma unroll
-        for (int j = 4; j >= 1; j >>= 1) {
+            for (int j = 4; j >= 1; j >>= 1) {
 #pragma unroll
-            for (int r = 0; r < 8; r++)
-                if ((r & j) == 0) cmpx(v[r], v[r | j], asc);
+                for (int r = 0; r < 8; r++)
+                    if ((r & j) == 0) cmpx(v[r], v[r | j], asc);
+            }
         }
     }
 }
@@ -209,13 +215,14 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
         upv[0] = a.x; upv[1] = a.y; upv[2] = a.z; upv[3] = a.w;
         upv[4] = b.x; upv[5] = b.y; upv[6] = b.z; upv[7] = b.w;
     }
-    uint32_t dwv[8], tmv[8], cv[8];
+    uint32_t dwv[8], tmv[8];
+    uint32_t cpk[2] = {0, 0};  // the 8 target bytes, packed (needed again when the keys are built)
     int bad = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         int y = (i0 & 255) + j;
         tmv[j] = 0;
-        cv[j] = tgt_own[y];
+        cpk[j >> 2] |= (uint32_t)tgt_own[y] << (8 * (j & 3));
         if (is_hole(y)) {
             dwv[j] = 0;  // video.py:111
             if (cur_own[y] != 0) bad = kErrHoles;  // video.py:87
@@ -236,6 +243,9 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
                 ulonglong2 a = Sg[cm], b = Sg[tm];
                 dwv[j] = edit_distance<ModeTraits<MODE>::kDots>(a.x, (uint32_t)a.y, b.x, (uint32_t)b.y, lut);
             }
+            // keep the eight recurrences from being interleaved: that costs more registers
+            // than the 64 a 2-workgroups-per-CU launch allows
+            __builtin_amdgcn_sched_barrier(0);
         } else {
             // screen.py:441-443: pair = (source << bits) + target
             dwv[j] = table[((size_t)o << (2 * BITS)) + ((size_t)cm << BITS) + tm];
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
                 if (selmask & (1u << j))
                     kv[j] = ((unsigned long long)(0x7fffffffu - (uint32_t)upv[j]) << 29) |
                             ((unsigned long long)nonce[r] << 21) | ((unsigned long long)(i0 + j) << 8) |
-                            (unsigned long long)cv[j];
+                            (unsigned long long)((cpk[j >> 2] >> (8 * (j & 3))) & 0xffu);
                 r++;
             }
         }
