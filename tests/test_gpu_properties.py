@@ -1,0 +1,180 @@
+"""GPU: edge cases and size-independent properties of the encode path, checked
+against the oracle where it finishes in seconds and through invariants at full
+batch size."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HOLES = (np.arange(256) & 127) >= 120
+
+
+def _seed_states(O, a, b):
+    return O.mt_seed_py(a).state_words(), O.mt_seed_np(b).state_words()
+
+
+def _encode(native, device_tables, mode, frames, sched, seeds, O, wave=None, prefix=True, init=None):
+    """frames: (n_streams, n_frames, 2, 32, 256)."""
+    import torch
+    t, s = device_tables.get(mode)
+    n = frames.shape[0]
+    enc = native.Encoder(mode, t, s, n, dm=device_tables.dm[(mode, 5)])
+    enc.set_greedy_kernel(wave)
+    enc.set_prefix_sort(prefix)
+    for i, (a, b) in enumerate(seeds):
+        py, npw = _seed_states(O, a, b)
+        enc.set_state(native.STATE_RNG_PY, py, i)
+        enc.set_state(native.STATE_RNG_NP, npw, i)
+    if init:
+        init(enc)
+    fm = torch.from_numpy(np.ascontiguousarray(frames[:, :, 0])).cuda()
+    fa = torch.from_numpy(np.ascontiguousarray(frames[:, :, 1])).cuda() if mode == 1 else None
+    ops = enc.encode(fm, fa, sched)
+    enc.check()
+    return enc, ops.cpu().numpy()
+
+
+def _oracle(O, oracle_tables, mode, frames1, sched, seed, init=None):
+    v = O.Video(mode, oracle_tables.get(mode), seed_py=seed[0], seed_np=seed[1])
+    if init:
+        init(v)
+    out = []
+    for (f, ia, restart, n) in sched:
+        if restart:
+            v.encode_frame(frames1[f, 0], frames1[f, 1] if mode == 1 else None, ia)
+        if n:
+            out.append(v.next(n))
+    return v, (np.concatenate(out) if out else np.zeros((0, 6), np.uint8))
+
+
+@pytest.mark.parametrize("wave", [True, False])
+def test_blank_target_on_blank_screen(native, O, device_tables, wave):
+    """Nothing to do: no RNG draw, out_of_work at once, only padding opcodes."""
+    frames = np.zeros((1, 1, 2, 32, 256), np.uint8)
+    enc, ops = _encode(native, device_tables, 1, frames, [(0, 0, 1, 5), (0, 1, 1, 3)], [(1, 1)], O, wave=wave)
+    assert (ops[0][:, 0] == 32).all() and (ops[0][:, 1:] == 0).all()
+    assert enc.get_state(native.STATE_OUT_OF_WORK).tolist() == [1, 1]
+    assert enc.get_state(native.STATE_COUNTERS)[:2].tolist() == [0, 0]
+
+
+@pytest.mark.parametrize("mode,wave", [(1, True), (0, True), (1, False)])
+def test_constant_target_degenerate_priorities(native, O, oracle_tables, device_tables, mode, wave):
+    """Every byte has the same priority (one histogram bucket): the prefix selection
+    must fall back to ordering everything; ties are broken by nonce/page/offset only."""
+    fr = np.zeros((1, 2, 2, 32, 256), np.uint8)
+    fr[0, 0, :, :, :] = 0x55
+    fr[0, 1, :, :, :] = 0x2a
+    fr[..., HOLES] = 0
+    sched = [(0, 0, 1, 200), (0, 1 if mode == 1 else 0, 1, 250), (1, 0, 1, 100), (1, 0, 1, 0)]
+    enc, ops = _encode(native, device_tables, mode, fr, sched, [(3, 4)], O, wave=wave)
+    v, exp = _oracle(O, oracle_tables, mode, fr[0], sched, (3, 4))
+    assert (ops[0] == exp).all()
+    assert (enc.get_state(native.STATE_UP_MAIN) == v.update_priority(0)).all()
+
+
+@pytest.mark.parametrize("wave", [True, False])
+def test_few_changes_and_tiny_lists(native, O, oracle_tables, device_tables, wave):
+    """Targets that differ from the screen in 0..70 bytes: lists shorter than one scan
+    window, shorter than the opcode budget, exhaustion mid-segment, then padding."""
+    rng = np.random.default_rng(11)
+    n = 6
+    fr = np.zeros((n, 2, 2, 32, 256), np.uint8)
+    for i in range(n):
+        k = [0, 1, 2, 7, 33, 70][i]
+        for f in range(2):
+            idx = rng.integers(0, 8192, k)
+            for b in range(2):
+                flat = fr[i, f, b].reshape(-1)
+                flat[idx] = rng.integers(1, 128, k)
+        fr[i][..., HOLES] = 0
+    sched = [(0, 0, 1, 40), (0, 1, 1, 40), (1, 0, 1, 90), (1, 1, 1, 10), (1, 0, 1, 0)]
+    seeds = [(i + 5, i + 50) for i in range(n)]
+    enc, ops = _encode(native, device_tables, 1, fr, sched, seeds, O, wave=wave)
+    for i in range(n):
+        v, exp = _oracle(O, oracle_tables, 1, fr[i], sched, seeds[i])
+        assert (ops[i] == exp).all(), i
+        assert (enc.get_state(native.STATE_MEM_AUX, i) == v.memory(1)).all()
+        cnt = enc.get_state(native.STATE_COUNTERS, i)
+        assert (int(cnt[0]), int(cnt[1])) == v.draws()
+
+
+def test_priorities_beyond_16_bits(native, O, oracle_tables, device_tables):
+    """update_priority accumulates across calls and outgrows 16 bits: the
+    64-bit keys must still order it, and the prefix selection must bucket it."""
+    rng = np.random.default_rng(2)
+    big = rng.integers(0, 300000, (32, 256)).astype(np.int32)
+    big[:, HOLES] = 0
+    fr = rng.integers(0, 128, (1, 1, 2, 32, 256), dtype=np.uint8)
+    fr[..., HOLES] = 0
+    sched = [(0, 0, 1, 300), (0, 1, 1, 120), (0, 0, 1, 0)]
+
+    def init_dev(enc):
+        enc.set_state(native.STATE_UP_MAIN, big)
+
+    def init_orc(v):
+        v.update_priority(0)[...] = big
+
+    for wave in (True, False):
+        enc, ops = _encode(native, device_tables, 1, fr, sched, [(8, 9)], O, wave=wave, init=init_dev)
+        v, exp = _oracle(O, oracle_tables, 1, fr[0], sched, (8, 9), init=init_orc)
+        assert (ops[0] == exp).all()
+        assert (enc.get_state(native.STATE_UP_MAIN) == v.update_priority(0)).all()
+
+
+def test_prefix_sort_boundary_budgets(native, O, oracle_tables, device_tables):
+    """Opcode budgets right at the prefix-sort limit (3 x 682 = 2046 <= 2048 < 3 x 683)
+    and a continued generator whose total is only known from the segment list."""
+    rng = np.random.default_rng(4)
+    fr = rng.integers(0, 256, (2, 3, 2, 32, 256), dtype=np.uint8)
+    fr[..., HOLES] = 0
+    sched = [(0, 0, 1, 682), (1, 0, 1, 683), (2, 0, 1, 300), (2, 0, 0, 382), (2, 0, 1, 1)]
+    seeds = [(1, 2), (3, 4)]
+    enc, ops = _encode(native, device_tables, 0, fr, sched, seeds, O, wave=True)
+    for i in range(2):
+        v, exp = _oracle(O, oracle_tables, 0, fr[i], sched, seeds[i])
+        assert (ops[i] == exp).all()
+
+
+def test_full_size_batch_properties(native, O, oracle_tables, device_tables):
+    """4096 streams x 3 frames (the bench's batch shape).  Size-independent checks:
+    replaying each opcode stream onto a blank screen reproduces the device's memory
+    maps; every store lands on a non-hole byte with the target's content; the batch is
+    deterministic; and sampled streams equal their stand-alone oracle runs."""
+    import torch
+    import stream_batch
+    S, F = 4096, 3
+    t, s = device_tables.get(1)
+    fm, fa = stream_batch.synth_frames_torch(S, F, True, seed=123)
+    seeds = [(i + 1, i + 7) for i in range(S)]
+    runs = []
+    for rep in range(2):
+        b = stream_batch.StreamBatch(1, t, s, S, seeds=seeds, dm=device_tables.dm[(1, 5)])
+        ops, segs = b.encode_frames(fm, fa, F)
+        b.enc.check()
+        runs.append(ops.cpu().numpy())
+        if rep == 0:
+            mem_main = np.stack([b.enc.get_state(native.STATE_MEM_MAIN, i) for i in range(0, S, 97)])
+            mem_aux = np.stack([b.enc.get_state(native.STATE_MEM_AUX, i) for i in range(0, S, 97)])
+        b.close()
+    assert np.array_equal(runs[0], runs[1])          # deterministic
+    ops = runs[0]
+    assert ops.shape == (S, sum(g[3] for g in segs), 6)
+    assert (ops[:, :, 0] >= 32).all() and (ops[:, :, 0] < 64).all()
+    assert not HOLES[ops[:, :, 2:6]].any()            # no store into a screen hole
+    tm, ta = fm.cpu().numpy(), fa.cpu().numpy()
+    for k, i in enumerate(range(0, S, 97)):
+        cur = [np.zeros((32, 256), np.uint8), np.zeros((32, 256), np.uint8)]
+        pos = 0
+        for (f, ia, _, n) in segs:
+            tgt = ta[i, f] if ia else tm[i, f]
+            o = ops[i, pos:pos + n]
+            assert (o[:, 1] == tgt[o[:, 0] - 32, o[:, 2]]).all()   # content = target byte of the primary
+            bank = cur[ia]
+            for row in o:                                          # in order: a byte can be stored
+                bank[row[0] - 32, row[2:6]] = row[1]               # again later with another content
+            pos += n
+        assert np.array_equal(cur[0], mem_main[k]) and np.array_equal(cur[1], mem_aux[k])
+    for i in (0, 1500, 4095):
+        v, exp = _oracle(O, oracle_tables, 1, np.stack([tm[i], ta[i]], axis=1), segs, seeds[i])
+        assert np.array_equal(ops[i], exp), i
