@@ -55,6 +55,7 @@ struct StreamState {
     int32_t pad_content;      // target[0,0] of the live generator's bank (video.py:249)
     int32_t truncated;        // order[] holds only the top of the list (prefix sort)
     unsigned long long draws_py, draws_np, ops, pad_ops;
+    unsigned long long stamps[16];  // diagnostic builds only (-DIIV_STAMPS): s_memtime at phase boundaries
 };
 
 enum { kErrNone = 0, kErrHoles = 1, kErrNegative = 2, kErrPaletteBit = 3, kErrPushedOverflow = 4, kErrNoGenerator = 5, kErrGuard = 6, kErrSortBudget = 7 };
@@ -62,6 +63,16 @@ enum { kErrNone = 0, kErrHoles = 1, kErrNegative = 2, kErrPaletteBit = 3, kErrPu
 // ------------------------------------------------------------------------- prologue
 
 constexpr int kProThreads = 1024;
+
+#ifdef IIV_STAMPS
+#define IIV_STAMP(i)                                                        \
+    do {                                                                    \
+        __syncthreads();                                                    \
+        if (threadIdx.x == 0) S.stamps[i] = __builtin_amdgcn_s_memtime();   \
+    } while (0)
+#else
+#define IIV_STAMP(i) do { } while (0)
+#endif
 
 // Bitonic sort of 8*NT u64 keys, 8 consecutive elements per thread.  Exchange
 // distances 1,2,4 stay inside a thread's registers, 8..256 are wave shuffles, and
@@ -74,60 +85,66 @@ __device__ static inline void cmpx(unsigned long long &lo, unsigned long long &h
     hi = sw ? t : hi;
 }
 
-// All threads of the workgroup must call this (it contains workgroup barriers); only
-// threads tid < nt hold keys, N = 8 * nt keys are sorted.
-__device__ static inline void bitonic_sort8(unsigned long long (&v)[8], unsigned long long *xbuf, int tid, int nt)
+// Bitonic sort of KPT * NT u64 keys held KPT consecutive keys per thread by all NT
+// threads of the workgroup.  Exchange distances below KPT stay in registers, up to
+// 32 * KPT they are wave shuffles, and only larger ones go through LDS (xbuf).
+template <int KPT, int NT>
+__device__ static inline void bitonic_sort(unsigned long long (&v)[KPT], unsigned long long *xbuf, int tid)
 {
-    const int N = 8 * nt;
-    const bool active = tid < nt;  // whole waves (nt is a multiple of 64)
-    if (active) {
+    constexpr int N = KPT * NT;
 #pragma unroll
-        for (int k = 2; k <= 8; k <<= 1) {
+    for (int k = 2; k <= KPT; k <<= 1) {
 #pragma unroll
-            for (int j = k >> 1; j >= 1; j >>= 1) {
+        for (int j = k >> 1; j >= 1; j >>= 1) {
 #pragma unroll
-                for (int r = 0; r < 8; r++)
-                    if ((r & j) == 0) cmpx(v[r], v[r | j], (((8 * tid + r) & k) == 0));
-            }
+            for (int r = 0; r < KPT; r++)
+                if ((r & j) == 0) cmpx(v[r], v[r | j], (((KPT * tid + r) & k) == 0));
         }
     }
-    for (int k = 16; k <= N; k <<= 1) {
-        const bool asc = ((8 * tid) & k) == 0;
-        for (int j = k >> 1; j >= 8; j >>= 1) {
-            const int d = j >> 3;
+    for (int k = 2 * KPT; k <= N; k <<= 1) {
+        const bool asc = ((KPT * tid) & k) == 0;
+        for (int j = k >> 1; j >= KPT; j >>= 1) {
+            const int d = j / KPT;
             const bool take_min = ((tid & d) == 0) == asc;
             if (d < 64) {
-                if (active) {
 #pragma unroll
-                    for (int r = 0; r < 8; r++) {
-                        unsigned long long p = __shfl_xor(v[r], d, 64);
-                        v[r] = take_min ? (p < v[r] ? p : v[r]) : (p > v[r] ? p : v[r]);
-                    }
+                for (int r = 0; r < KPT; r++) {
+                    unsigned long long p = __shfl_xor(v[r], d, 64);
+                    v[r] = take_min ? (p < v[r] ? p : v[r]) : (p > v[r] ? p : v[r]);
                 }
             } else {
-                if (active) {
 #pragma unroll
-                    for (int r = 0; r < 8; r++) xbuf[r * nt + tid] = v[r];
-                }
+                for (int r = 0; r < KPT; r++) xbuf[r * NT + tid] = v[r];
                 __syncthreads();
-                if (active) {
 #pragma unroll
-                    for (int r = 0; r < 8; r++) {
-                        unsigned long long p = xbuf[r * nt + (tid ^ d)];
-                        v[r] = take_min ? (p < v[r] ? p : v[r]) : (p > v[r] ? p : v[r]);
-                    }
+                for (int r = 0; r < KPT; r++) {
+                    unsigned long long p = xbuf[r * NT + (tid ^ d)];
+                    v[r] = take_min ? (p < v[r] ? p : v[r]) : (p > v[r] ? p : v[r]);
                 }
                 __syncthreads();
             }
         }
-        if (active) {
 #pragma unroll
-            for (int j = 4; j >= 1; j >>= 1) {
+        for (int j = KPT >> 1; j >= 1; j >>= 1) {
 #pragma unroll
-                for (int r = 0; r < 8; r++)
-                    if ((r & j) == 0) cmpx(v[r], v[r | j], asc);
-            }
+            for (int r = 0; r < KPT; r++)
+                if ((r & j) == 0) cmpx(v[r], v[r | j], asc);
         }
+    }
+}
+
+// sorted keys -> order[] entries (page << 8 | offset | content << 16)
+template <int KPT> __device__ static inline void write_order(uint32_t *order, const unsigned long long (&v)[KPT], int tid)
+{
+    uint32_t o[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; j++) o[j] = ((uint32_t)(v[j] >> 8) & 0x1fffu) | (((uint32_t)v[j] & 0xffu) << 16);
+    if (KPT == 2) {
+        *reinterpret_cast<uint2 *>(order + 2 * tid) = make_uint2(o[0], o[1]);
+    } else {
+        uint4 *q = reinterpret_cast<uint4 *>(order + KPT * tid);
+#pragma unroll
+        for (int j = 0; j < KPT / 4; j++) q[j] = make_uint4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
     }
 }
 
@@ -154,7 +171,7 @@ template <int NT> __device__ static inline int block_scan_excl(int v, int tid, u
 }
 
 constexpr int kSelNeedMax = 2048;  // partial sort is used when 3 * opcode budget <= this
-constexpr int kSelCap = 4096;      // ... and the threshold bucket does not push the selection past this
+constexpr int kBucketMax = 96;      // buckets larger than this fall back to the bitonic sort
 
 // DP == false: diff weights are gathered from the precomputed table (one random
 // HBM line per screen byte).  DP == true: they are recomputed by running the
@@ -188,6 +205,7 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
     StreamState &S = states[blockIdx.x];
     const size_t fbase = ((size_t)blockIdx.x * n_frames + frame) * 8192;
 
+    IIV_STAMP(0);
     if (tid == 0) flag_bad = 0;
     // stage current screen and target memory maps (16 B per lane per load)
     for (int i = tid; i < 512 * NB; i += kProThreads) {
@@ -200,6 +218,7 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
     if (DP && tid < 256) lut[tid] = sub[tid];
     __syncthreads();
 
+    IIV_STAMP(1);
     const int tgt_first = tgt[(MODE == kDHGR && is_aux) ? 1 : 0][0];
     // 8 consecutive bytes of one page row per thread (row-major, as nonzero() walks them)
     const int i0 = tid * 8;
@@ -239,9 +258,19 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
         if (DP) {
             dwv[j] = 0;
             if (cm != tm) {
-                const ulonglong2 *Sg = strings + ((size_t)o << BITS);
-                ulonglong2 a = Sg[cm], b = Sg[tm];
-                dwv[j] = edit_distance<ModeTraits<MODE>::kDots>(a.x, (uint32_t)a.y, b.x, (uint32_t)b.y, lut);
+                if (MODE == kDHGR) {
+                    // DHGR windows are already dot strings (screen.py:983-990): ten rotates are
+                    // cheaper than two dependent L2 loads
+                    uint64_t alo, blo;
+                    uint32_t ahi, bhi;
+                    colour_string<MODE>(cm, o, alo, ahi);
+                    colour_string<MODE>(tm, o, blo, bhi);
+                    dwv[j] = edit_distance<ModeTraits<MODE>::kDots>(alo, ahi, blo, bhi, lut);
+                } else {
+                    const ulonglong2 *Sg = strings + ((size_t)o << BITS);
+                    ulonglong2 a = Sg[cm], b = Sg[tm];
+                    dwv[j] = edit_distance<ModeTraits<MODE>::kDots>(a.x, (uint32_t)a.y, b.x, (uint32_t)b.y, lut);
+                }
             }
             // keep the eight recurrences from being interleaved: that costs more registers
             // than the 64 a 2-workgroups-per-CU launch allows
@@ -275,21 +304,23 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
     }
     if (bad) flag_bad = bad;
 
+    IIV_STAMP(2);
     // row-major rank of each non-zero entry (its index into the nonce draw, video.py:259-265)
     int n;
     const int rank0 = block_scan_excl<kProThreads>(__popc(nzmask), tid, wsum, n);
 
-    // ---- optional prefix selection.  A generator that will be asked for at most B
-    // opcodes consumes at most 3B list entries (one primary and at most two
+    // ---- bucket the priorities: 1024 buckets over [0, max].  This is a counting sort
+    // (bucket starts = cumulative counts from the top bucket down) whose tiny buckets
+    // (~7 entries) are finished below by ranking each entry inside its own bucket; it
+    // replaces ~65 dependent bitonic stages by four barriers.
+    // It also yields the optional prefix selection: a generator that will be asked for
+    // at most B opcodes consumes at most 3B list entries (one primary and at most two
     // secondaries resolved to zero per opcode), so when the host knows B (`need` = 3B)
-    // only the `need` highest priorities have to be ordered.  Selection is by a
-    // 1024-bucket histogram of the priorities; every entry of the boundary bucket is
-    // kept, so the kept set is a superset of the true top-`need`.
-    uint32_t selmask = nzmask;
-    int n_sel = n;
-    bool partial = need > 0 && need <= kSelNeedMax;
-    if (partial && n > need) {
-        uint32_t *hist = reinterpret_cast<uint32_t *>(nonce);  // 4 KiB of the (not yet used) nonce buffer
+    // only the buckets holding the `need` highest priorities are ordered at all (every
+    // entry of the boundary bucket is kept: a superset of the true top-`need`).
+    uint32_t *hist = reinterpret_cast<uint32_t *>(nonce);  // 4 KiB of the (not yet used) nonce buffer
+    int sh;
+    {
         int mx = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) mx = upv[j] > mx ? upv[j] : mx;
@@ -303,36 +334,40 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
         if ((tid & 63) == 0) wsum[tid >> 6] = (uint32_t)mx;
         __syncthreads();
         for (int w = 0; w < kProThreads / 64; w++) mx = (int)wsum[w] > mx ? (int)wsum[w] : mx;
-        const int sh = mx < 1024 ? 0 : (32 - __clz(mx)) - 10;
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            if (nzmask & (1u << j)) atomicAdd(&hist[upv[j] >> sh], 1u);
-        __syncthreads();
-        // thread t looks at bucket 1023 - t: cumulative count from the top bucket down
-        const int c = (int)hist[1023 - tid];
-        int total_unused;
-        const int before = block_scan_excl<kProThreads>(c, tid, wsum, total_unused);
-        __shared__ int sel_bucket, sel_count;
-        if (before < need && before + c >= need) {
-            sel_bucket = 1023 - tid;
-            sel_count = before + c;
-        }
-        __syncthreads();
-        n_sel = sel_count;
-        if (n_sel <= kSelCap) {
-            selmask = 0;
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-                if ((nzmask & (1u << j)) && (upv[j] >> sh) >= sel_bucket) selmask |= 1u << j;
-        } else {
-            partial = false;  // degenerate priority distribution: order everything
-            n_sel = n;
-        }
-        __syncthreads();  // hist (aliasing nonce[]) is dead from here on
-    } else if (partial && n > kSelCap) {
-        partial = false;
+        sh = mx < 1024 ? 0 : (32 - __clz(mx)) - 10;
     }
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        if (nzmask & (1u << j)) atomicAdd(&hist[upv[j] >> sh], 1u);
+    __syncthreads();
+    // thread t owns bucket 1023 - t; bstart = number of entries in higher buckets
+    const int bcount = (int)hist[1023 - tid];
+    int total_unused;
+    const int bstart = block_scan_excl<kProThreads>(bcount, tid, wsum, total_unused);
+    __shared__ int sel_bucket, sel_count, big_bucket;
+    if (tid == 0) {
+        sel_bucket = 0;
+        sel_count = n;
+        big_bucket = 0;
+    }
+    __syncthreads();
+    const bool want_prefix = need > 0 && need <= kSelNeedMax && n > need;
+    if (want_prefix && bstart < need && bstart + bcount >= need) {
+        sel_bucket = 1023 - tid;
+        sel_count = bstart + bcount;
+    }
+    __syncthreads();
+    const int n_sel = sel_count;
+    const int first_bucket = sel_bucket;  // buckets >= this are ordered
+    if (bcount > kBucketMax && (1023 - tid) >= first_bucket) big_bucket = 1;
+    uint32_t selmask = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        if ((nzmask & (1u << j)) && (upv[j] >> sh) >= first_bucket) selmask |= 1u << j;
+    __syncthreads();  // hist (aliasing nonce[]) is dead from here on; big_bucket is final
+    const bool by_buckets = big_bucket == 0;
 
+    IIV_STAMP(3);
     // n draws of np.random.randint(0, 256): low byte of the next n MT outputs (video.py:265)
     int idx = S.mt_np_idx;
     {
@@ -360,8 +395,10 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
             S.mt_np_idx = first + n - blk * 624;
             S.draws_np += (unsigned long long)n;
         }
+        __syncthreads();  // mtb is reused below
     }
 
+    IIV_STAMP(4);
     // keys (-priority, nonce, page, offset) -> ascending u64 (video.py:259-268); bytes
     // whose priority is zero (or that were not selected) get the all-ones key and sink
     unsigned long long kv[8];
@@ -381,33 +418,59 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
             }
         }
     }
-    int nt = kProThreads;
-    if (partial) {
-        // compact the selected keys into LDS, then let the first n_pad/8 threads sort them
+    IIV_STAMP(5);
+    if (by_buckets) {
+        // counting sort: scatter every selected key into its bucket's slot range, then
+        // rank it among the (few) keys of the same bucket
+        uint32_t *cursor = reinterpret_cast<uint32_t *>(nonce);   // nonces now live in the keys
+        uint32_t *start = reinterpret_cast<uint32_t *>(mtb);      // MT state is back in HBM
+        __syncthreads();
+        cursor[1023 - tid] = (uint32_t)bstart;
+        start[1023 - tid] = (uint32_t)bstart;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (selmask & (1u << j)) keys[atomicAdd(&cursor[upv[j] >> sh], 1u)] = kv[j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (selmask & (1u << j)) {
+                const int bk = upv[j] >> sh;
+                const int s0 = (int)start[bk];
+                const int e0 = bk == 0 ? n : (int)start[bk - 1];
+                int below = 0;
+                for (int i = s0; i < e0; i++) below += keys[i] < kv[j] ? 1 : 0;
+                S.order[s0 + below] = ((uint32_t)(kv[j] >> 8) & 0x1fffu) | (((uint32_t)kv[j] & 0xffu) << 16);
+            }
+    } else if (n_sel <= 4 * kProThreads && n_sel < n) {
+        // degenerate buckets, prefix selection still small: compact + bitonic
         int tot;
         int pos = block_scan_excl<kProThreads>(__popc(selmask), tid, wsum, tot);
-        const int n_pad = tot <= 2048 ? 2048 : 4096;
-        nt = n_pad / 8;
+        const bool small = tot <= 2 * kProThreads;
+        const int n_pad = small ? 2 * kProThreads : 4 * kProThreads;
         for (int i = tot + tid; i < n_pad; i += kProThreads) keys[i] = ~0ull;
 #pragma unroll
         for (int j = 0; j < 8; j++)
             if (selmask & (1u << j)) keys[pos++] = kv[j];
         __syncthreads();
-        if (tid < nt) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) kv[j] = keys[8 * tid + j];
+        if (small) {
+            unsigned long long v2[2] = {keys[2 * tid], keys[2 * tid + 1]};
+            __syncthreads();
+            bitonic_sort<2, kProThreads>(v2, keys, tid);
+            write_order<2>(S.order, v2, tid);
+        } else {
+            unsigned long long v4[4] = {keys[4 * tid], keys[4 * tid + 1], keys[4 * tid + 2], keys[4 * tid + 3]};
+            __syncthreads();
+            bitonic_sort<4, kProThreads>(v4, keys, tid);
+            write_order<4>(S.order, v4, tid);
         }
-        __syncthreads();
+    } else {
+        // order everything with the bitonic network (keys not selected sink to the end)
+        bitonic_sort<8, kProThreads>(kv, keys, tid);
+        write_order<8>(S.order, kv, tid);  // entries >= n_sel are never read
     }
-    bitonic_sort8(kv, keys, tid, nt);
-    if (tid < nt) {
-        uint32_t o[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) o[j] = ((uint32_t)(kv[j] >> 8) & 0x1fffu) | (((uint32_t)kv[j] & 0xffu) << 16);
-        uint4 *q = reinterpret_cast<uint4 *>(S.order + i0);  // entries >= n_sel are never read
-        q[0] = make_uint4(o[0], o[1], o[2], o[3]);
-        q[1] = make_uint4(o[4], o[5], o[6], o[7]);
-    }
+    IIV_STAMP(6);
+    IIV_STAMP(7);
     if (tid == 0) {
         S.n_sorted = n_sel;
         S.truncated = n_sel < n ? 1 : 0;
@@ -594,7 +657,10 @@ __global__ __launch_bounds__(256) void greedy_kernel(StreamState *__restrict__ s
             }
         }
 
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see greedy_wave_kernel
+        __builtin_amdgcn_sched_barrier(0);  // retire the gathers here: see greedy_wave_kernel
+#pragma unroll
+        for (int m = 0; m < kChunk; m++) asm volatile("" : "+v"(ndv[m]));
+        __builtin_amdgcn_sched_barrier(0);
 
         // ---- process the chunk sequentially
         uint32_t dead = 0;
@@ -921,7 +987,16 @@ __global__ __launch_bounds__(64, 4) void greedy_wave_kernel(StreamState *__restr
         }
         // vmcnt is one in-order counter for loads AND stores: retire the gathers once, here,
         // before the steps below start issuing stores.
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        // (hipcc does not track a builtin s_waitcnt in its scoreboard, so the loaded
+        // registers are passed through empty asm statements: the compiler then places its
+        // own, accurate waits here and treats the values as plain registers afterwards)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            asm volatile("" : "+v"(wdv[m].x), "+v"(wdv[m].y), "+v"(wdv[m].z), "+v"(wdv[m].w));
+            asm volatile("" : "+v"(ndv[m][0]), "+v"(ndv[m][1]), "+v"(ndv[m][2]), "+v"(ndv[m][3]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
 
         // ---- process the chunk
 #pragma unroll
@@ -959,19 +1034,18 @@ __global__ __launch_bounds__(64, 4) void greedy_wave_kernel(StreamState *__restr
                 C += (int)__popcll(bal[r]);
             }
             // one random.getrandbits(8) per candidate in ascending offset (video.py:290-293)
+            // (branch-free: every lane reads a nonce slot for each of its bytes; only
+            // candidates keep it, and only candidates advance the running index)
             uint32_t key[4];
             int run = mt_idx + cb * 624 + below;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                key[r] = INF;
-                if (cand[r]) {
-                    int fj = run >= 1248 ? run - 1248 : run;
-                    run++;
-                    uint32_t nonce = mt_temper(mt[fj]) >> 24;
-                    if (nzy[r])  // video.py:159
-                        key[r] = ((uint32_t)(d[r] + 2048) << 17) | (nonce << 9) | ((uint32_t)(4 * lane + r) << 1) |
-                                 (ndv[m][r] != 0 ? 1u : 0u);
-                }
+                int fj = run >= 1248 ? run - 1248 : run;
+                run += cand[r] ? 1 : 0;
+                uint32_t nonce = mt_temper(mt[fj]) >> 24;
+                uint32_t k = ((uint32_t)(d[r] + 2048) << 17) | (nonce << 9) | ((uint32_t)(4 * lane + r) << 1) |
+                             (ndv[m][r] != 0 ? 1u : 0u);
+                key[r] = (cand[r] && nzy[r]) ? k : INF;  // video.py:159
             }
             // two smallest (delta, nonce, offset): lane, row of 16 (DPP), wave (readlane)
             uint32_t a0 = key[0] < key[1] ? key[0] : key[1], b0 = key[0] < key[1] ? key[1] : key[0];
@@ -1233,6 +1307,7 @@ static int state_item(int mode, int what, size_t &off, size_t &bytes, bool &writ
         off = offsetof(StreamState, up[1]); bytes = 8192 * 4; return 0;
     case IIV_STATE_OUT_OF_WORK: off = offsetof(StreamState, out_of_work); bytes = 8; return 0;
     case IIV_STATE_COUNTERS: off = offsetof(StreamState, draws_py); bytes = 32; writable = false; return 0;
+    case 100: off = offsetof(StreamState, stamps); bytes = 128; writable = false; return 0;  // diagnostic
     default: return -1;
     }
 }

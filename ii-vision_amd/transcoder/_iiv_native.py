@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libiivision.so")
+LIB_PATH = os.environ.get("IIV_LIB") or os.path.join(os.path.dirname(_HERE), "libiivision.so")
 
 HGR = 0
 DHGR = 1
@@ -270,6 +270,7 @@ class Encoder:
         STATE_RNG_PY: ((625,), np.uint32), STATE_RNG_NP: ((625,), np.uint32),
         STATE_OUT_OF_WORK: ((2,), np.int32), STATE_PACKED: ((32, 128), np.uint64),
         STATE_COUNTERS: ((4,), np.uint64),
+        100: ((16,), np.uint64),  # phase stamps of diagnostic (-DIIV_STAMPS) builds
     }
 
     def get_state(self, what, stream=0, out=None):
