@@ -428,14 +428,18 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
         cursor[1023 - tid] = (uint32_t)bstart;
         start[1023 - tid] = (uint32_t)bstart;
         __syncthreads();
+        // (the bucket is recovered from the key, so the priorities need not stay in registers)
 #pragma unroll
         for (int j = 0; j < 8; j++)
-            if (selmask & (1u << j)) keys[atomicAdd(&cursor[upv[j] >> sh], 1u)] = kv[j];
+            if (kv[j] != ~0ull) {
+                const uint32_t bk = (0x7fffffffu - (uint32_t)(kv[j] >> 29)) >> sh;
+                keys[atomicAdd(&cursor[bk], 1u)] = kv[j];
+            }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 8; j++)
-            if (selmask & (1u << j)) {
-                const int bk = upv[j] >> sh;
+            if (kv[j] != ~0ull) {
+                const int bk = (int)((0x7fffffffu - (uint32_t)(kv[j] >> 29)) >> sh);
                 const int s0 = (int)start[bk];
                 const int e0 = bk == 0 ? n : (int)start[bk - 1];
                 int below = 0;
@@ -445,13 +449,16 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
     } else if (n_sel <= 4 * kProThreads && n_sel < n) {
         // degenerate buckets, prefix selection still small: compact + bitonic
         int tot;
-        int pos = block_scan_excl<kProThreads>(__popc(selmask), tid, wsum, tot);
+        int nsel_mine = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) nsel_mine += kv[j] != ~0ull ? 1 : 0;
+        int pos = block_scan_excl<kProThreads>(nsel_mine, tid, wsum, tot);
         const bool small = tot <= 2 * kProThreads;
         const int n_pad = small ? 2 * kProThreads : 4 * kProThreads;
         for (int i = tot + tid; i < n_pad; i += kProThreads) keys[i] = ~0ull;
 #pragma unroll
         for (int j = 0; j < 8; j++)
-            if (selmask & (1u << j)) keys[pos++] = kv[j];
+            if (kv[j] != ~0ull) keys[pos++] = kv[j];
         __syncthreads();
         if (small) {
             unsigned long long v2[2] = {keys[2 * tid], keys[2 * tid + 1]};

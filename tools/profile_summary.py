@@ -1,0 +1,95 @@
+"""Collect rocprofv3 kernel stats + PMC counters for bench.py and write compact
+summaries (the raw traces are tens of MB and stay on the GPU box).
+
+    python tools/profile_summary.py OUTDIR [bench args...]
+
+Runs, each as its own rocprofv3 invocation (counters are never combined with
+tracing domains other than --kernel-trace):
+  1. --kernel-trace --stats
+  2-5. four --pmc passes (SQ instruction mix, SQ waits, FETCH_SIZE, WRITE_SIZE/TCC)
+and writes OUTDIR/kernel_stats.csv, OUTDIR/pmc_summary.txt, OUTDIR/pmc_latest.json.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PASSES = [
+    "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR",
+    "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM",
+    "FETCH_SIZE GRBM_GUI_ACTIVE",
+    "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum",
+]
+
+
+def run(cmd, cwd):
+    subprocess.run(cmd, cwd=cwd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+
+
+def short(name):
+    for k in ("greedy_wave_kernel", "greedy_kernel", "prologue_kernel", "table_kernel", "store_kernel"):
+        if k in name:
+            return k + ("<DHGR>" if "<1" in name else "<HGR>" if "<0" in name else "")
+    return None
+
+
+def main():
+    out = os.path.abspath(sys.argv[1])
+    bench_args = sys.argv[2:] or ["--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    os.makedirs(out, exist_ok=True)
+    tmp = "/tmp/iiv_prof"
+    subprocess.run(["rm", "-rf", tmp])
+    os.makedirs(tmp)
+    bench = ["python3", os.path.join(ROOT, "bench.py")] + bench_args
+    run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp + "/stats", "--"] + bench, "/tmp")
+    f = glob.glob(tmp + "/stats/*/*kernel_stats.csv")
+    if f:
+        rows = list(csv.reader(open(f[0])))
+        with open(os.path.join(out, "kernel_stats.csv"), "w") as g:
+            w = csv.writer(g)
+            w.writerow(rows[0])
+            for r in rows[1:]:
+                w.writerow([r[0] if len(r[0]) <= 160 else r[0][:157] + "..."] + r[1:])
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.defaultdict(lambda: collections.defaultdict(set))
+    for i, p in enumerate(PASSES):
+        d = "%s/pmc%d" % (tmp, i)
+        run(["rocprofv3", "--pmc"] + p.split() + ["--kernel-trace", "--output-format", "csv", "-d", d, "--"] + bench, "/tmp")
+        for f in glob.glob(d + "/*/*counter_collection.csv"):
+            for r in csv.DictReader(open(f)):
+                k = short(r["Kernel_Name"])
+                if k:
+                    agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+                    cnt[k][r["Counter_Name"]].add(r["Dispatch_Id"])
+    with open(os.path.join(out, "pmc_summary.txt"), "w") as g:
+        g.write("rocprofv3 --pmc, %d separate passes with --kernel-trace only; bench args: %s\n" % (len(PASSES), " ".join(bench_args)))
+        g.write("values are means per dispatch; FETCH_SIZE / WRITE_SIZE in KiB as reported\n\n")
+        for k in sorted(agg):
+            g.write("%s\n" % k)
+            for c in sorted(agg[k]):
+                n = max(len(cnt[k][c]), 1)
+                g.write("   %-24s %.5g   (%d dispatches)\n" % (c, agg[k][c] / n, n))
+            g.write("\n")
+    main_k = "greedy_wave_kernel<DHGR>" if "greedy_wave_kernel<DHGR>" in agg else None
+    if main_k:
+        a = agg[main_k]
+        fetch = a["FETCH_SIZE"] / max(len(cnt[main_k]["FETCH_SIZE"]), 1)
+        write = a["WRITE_SIZE"] / max(len(cnt[main_k]["WRITE_SIZE"]), 1)
+        json.dump({
+            "source": "tools/profile_summary.py (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+            "kernel": main_k,
+            "bench_args": bench_args,
+            "fetch_size_kib_per_launch_raw": fetch,
+            "write_size_kib_per_launch_raw": write,
+            "correction": "FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads, "
+                          "MI355X_MICROARCH.md HBM section; uncalibrated for 2-byte gathers); WRITE_SIZE as reported",
+            "greedy_kernel_hbm_bytes_per_launch": (2 * fetch + write) * 1024,
+        }, open(os.path.join(out, "pmc_latest.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
