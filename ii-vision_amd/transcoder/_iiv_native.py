@@ -34,6 +34,7 @@ SYMBOLS = [
     "iiv_pack", "iiv_diff_weights", "iiv_compute_delta_pages",
     "iiv_encoder_create", "iiv_encoder_destroy", "iiv_encoder_set_option", "iiv_encoder_get_state", "iiv_encoder_set_state",
     "iiv_encode", "iiv_encoder_check", "iiv_encoder_profile", "iiv_encoder_profile_read",
+    "iiv_emit_stream",
 ]
 
 
@@ -95,6 +96,8 @@ def lib():
     L.iiv_encoder_check.argtypes = [vp, C.POINTER(i32), vp]
     L.iiv_encoder_profile.argtypes = [vp, i32]
     L.iiv_encoder_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.iiv_emit_stream.argtypes = [i32, i32, C.c_long, vp, vp, vp, C.c_uint16, C.c_uint16, C.c_long, vp, sz,
+                                  C.POINTER(sz), vp]
     for name in SYMBOLS:
         getattr(L, name)  # AttributeError if the library lacks a declared symbol
     _lib = L
@@ -313,3 +316,27 @@ class Encoder:
         n = (C.c_int64 * 2)()
         check(lib().iiv_encoder_profile_read(self._h, ms, n))
         return {"prologue_ms": ms[0], "greedy_ms": ms[1], "prologue_launches": n[0], "greedy_launches": n[1]}
+
+
+# ---- f2: byte emission -------------------------------------------------------------
+
+def emit_stream_size(mode, n_ops, tick_addr, ack_addr, terminate_addr, max_bytes_out=None):
+    ta = np.ascontiguousarray(tick_addr, dtype=np.uint16).reshape(1024)
+    n = C.c_size_t(0)
+    check(lib().iiv_emit_stream(mode, 1, int(n_ops), None, None, hptr(ta), int(ack_addr), int(terminate_addr),
+                                int(max_bytes_out or 0), None, 0, C.byref(n), None))
+    return int(n.value)
+
+
+def emit_stream(mode, ops, ticks, tick_addr, ack_addr, terminate_addr, max_bytes_out=None):
+    """ops: CUDA uint8 (S, n, 6); ticks: CUDA uint8 (S, n) -> CUDA uint8 (S, length)."""
+    torch = _torch()
+    S, n = int(ops.shape[0]), int(ops.shape[1])
+    ta = np.ascontiguousarray(tick_addr, dtype=np.uint16).reshape(1024)
+    length = emit_stream_size(mode, n, ta, ack_addr, terminate_addr, max_bytes_out)
+    out = torch.empty((S, length), dtype=torch.uint8, device="cuda")
+    got = C.c_size_t(0)
+    check(lib().iiv_emit_stream(mode, S, n, dptr(ops.contiguous()), dptr(ticks.contiguous()), hptr(ta), int(ack_addr),
+                                int(terminate_addr), int(max_bytes_out or 0), dptr(out), length, C.byref(got),
+                                stream_ptr()))
+    return out

@@ -178,6 +178,26 @@ int iiv_encoder_check(iiv_encoder *enc, int *bad_stream, void *stream);
 int iiv_encoder_profile(iiv_encoder *enc, int enable);
 int iiv_encoder_profile_read(iiv_encoder *enc, double ms[2], int64_t launches[2]);
 
+/* ==== f2: byte emission of the opcode stream (".a2m") ====================== */
+
+/* movie.Movie.emit_stream + done (transcoder/movie.py:113-161) with
+ * opcodes.Header / tick opcodes / Ack / Terminate (opcodes.py:64-139) for
+ * n_streams independent opcode streams at once:
+ *   7-byte header (0xff x6, mode); per opcode [addr_hi, addr_lo, content, o0..o3]
+ *   with addr = tick_addr[((tick - 4) / 2) * 32 + page - 32]; a 4-byte ACK
+ *   [ack_hi, ack_lo, 0x54|0x55, 0xff] whenever the position reaches 2044 mod 2048
+ *   (DHGR: the bank flips at each ACK); then Terminate + zero padding to 2 KiB.
+ * d_ops   [n_streams][n_ops][6]  as produced by iiv_encode
+ * d_ticks [n_streams][n_ops]     speaker duty cycle of each opcode: 4, 6, ... 66
+ * tick_addr / ack_addr / terminate_addr: opcode entry points from the player's
+ *   symbol table (player/iivision.dbg; opcodes.py:168-217) -- host memory.
+ * max_bytes_out: Movie.max_bytes_out, 0 = unlimited.
+ * *out_len receives the stream length (same for every stream); with d_out == NULL
+ * nothing is written (size query).  Synchronises. */
+int iiv_emit_stream(int mode, int n_streams, long n_ops, const uint8_t *d_ops, const uint8_t *d_ticks,
+                    const uint16_t tick_addr[1024], uint16_t ack_addr, uint16_t terminate_addr,
+                    long max_bytes_out, uint8_t *d_out, size_t out_stride, size_t *out_len, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

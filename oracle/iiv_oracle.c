@@ -1112,3 +1112,47 @@ int orc_video_next_structured(orc_video *v, int k, uint8_t *ops_out)
 {
     return video_next(v, k, ops_out, FORM_STRUCT);
 }
+
+/* ------------------------------------------------------------------------- */
+/* byte emission (f2): movie.Movie.emit_stream / done (movie.py:113-161),      */
+/* opcodes.Header / BaseTick / Ack / Terminate (opcodes.py:64-139),            */
+/* machine.Machine.emit (machine.py:11-25)                                     */
+/* ------------------------------------------------------------------------- */
+
+/* ops: n x 6 (page+32, content, 4 offsets); ticks: n values 4..66 (even);
+ * tick_addr[(tick-4)/2 * 32 + page-32], ack / terminate = opcode start addresses
+ * (from the player's symbol table).  Returns the number of bytes written. */
+size_t orc_emit_stream(int mode, int n_ops, const uint8_t *ops, const uint8_t *ticks,
+                       const uint16_t tick_addr[1024], uint16_t ack_addr, uint16_t terminate_addr,
+                       long max_bytes_out, uint8_t *out)
+{
+    size_t pos = 0;
+    int aux = 0;
+    /* Header: no command bytes, 6 x 0xff + mode (opcodes.py:64-90) */
+    int stop = (max_bytes_out > 0 && (long)pos >= max_bytes_out);
+    if (!stop) {
+        for (int i = 0; i < 6; i++) out[pos++] = 0xff;
+        out[pos++] = (uint8_t)mode;
+        for (int k = 0; k < n_ops; k++) {
+            if (max_bytes_out > 0 && (long)pos >= max_bytes_out) break; /* movie.py:132-134 */
+            const uint8_t *o = ops + 6 * k;
+            uint16_t a = tick_addr[((ticks[k] - 4) / 2) * 32 + (o[0] - 32)];
+            out[pos++] = (uint8_t)(a >> 8);  /* emit_command, opcodes.py:49-53 */
+            out[pos++] = (uint8_t)(a & 0xff);
+            for (int i = 1; i < 6; i++) out[pos++] = o[i]; /* content + 4 offsets */
+            if (pos % 2048 >= 2044) {      /* movie.py:139-148 */
+                if (mode == ORC_DHGR) aux = !aux;
+                out[pos++] = (uint8_t)(ack_addr >> 8);
+                out[pos++] = (uint8_t)(ack_addr & 0xff);
+                out[pos++] = aux ? 0x55 : 0x54;
+                out[pos++] = 0xff;
+            }
+        }
+    }
+    /* done(): Terminate + zero padding to the 2 KiB boundary (movie.py:152-161) */
+    out[pos++] = (uint8_t)(terminate_addr >> 8);
+    out[pos++] = (uint8_t)(terminate_addr & 0xff);
+    size_t pad = 2048 - (pos % 2048);
+    for (size_t i = 0; i < pad; i++) out[pos++] = 0;
+    return pos;
+}

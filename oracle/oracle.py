@@ -144,6 +144,8 @@ def _declare(L):
     L.orc_video_draws_py.argtypes = [C.c_void_p]
     L.orc_video_draws_np.restype = C.c_uint64
     L.orc_video_draws_np.argtypes = [C.c_void_p]
+    L.orc_emit_stream.restype = C.c_size_t
+    L.orc_emit_stream.argtypes = [C.c_int, C.c_int, u8p, u8p, u16p, C.c_uint16, C.c_uint16, C.c_long, u8p]
 
 
 # --------------------------------------------------------------------------
@@ -253,6 +255,18 @@ def compute_delta_page(mode, table, tgt_packed, page, content, dw_row, is_aux):
     lib().orc_compute_delta_page(mode, _p(table, C.c_uint16), _p(tgt_packed, C.c_uint64), int(page),
                                  int(content), _p(dw_row, C.c_int32), int(is_aux), _p(out, C.c_int32))
     return out
+
+
+def emit_stream(mode, ops, ticks, tick_addr, ack_addr, terminate_addr, max_bytes_out=None):
+    """movie.emit_stream bytes for one stream (ops (n,6) u8, ticks (n,) 4..66)."""
+    ops = np.ascontiguousarray(ops, dtype=np.uint8).reshape(-1, 6)
+    ticks = np.ascontiguousarray(ticks, dtype=np.uint8)
+    ta = np.ascontiguousarray(tick_addr, dtype=np.uint16).reshape(1024)
+    n = len(ops)
+    out = np.zeros(7 + 7 * n + 4 * (n // 291 + 2) + 2 + 2048, dtype=np.uint8)
+    ln = lib().orc_emit_stream(mode, n, _p(ops, C.c_uint8), _p(ticks, C.c_uint8), _p(ta, C.c_uint16),
+                               int(ack_addr), int(terminate_addr), int(max_bytes_out or 0), _p(out, C.c_uint8))
+    return out[:ln].copy()
 
 
 class MT(C.Structure):

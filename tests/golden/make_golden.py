@@ -70,6 +70,11 @@ def setup_reference(scratch):
     sk.io = skio
     sys.modules["skvideo"] = sk
     sys.modules["skvideo.io"] = skio
+    # movie.py imports audio.py, which imports these at module level; neither is called
+    # by the byte-emission path exercised for g6
+    for name in ("audioread", "librosa"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
     sys.path.insert(0, os.path.join(REF, "transcoder"))
     os.chdir(scratch)
 
@@ -198,6 +203,7 @@ def movie_schedule(mode_name, n_frames, ops_per_frame=490):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scratch", default="/tmp/iiv_ref")
+    ap.add_argument("--a2m-only", action="store_true")
     args = ap.parse_args()
 
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -342,7 +348,55 @@ def main():
             g5["%s_%d_sample_val" % (name, pal)] = tab[o, idx]
     np.savez_compressed(os.path.join(HERE, "g5_tables.npz"), **g5)
     print("g5 written")
+    make_a2m_golden(args.scratch)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--a2m-only" not in sys.argv:
     main()
+
+
+def make_a2m_golden(scratch):
+    """G6: opcode byte emission (movie.emit_stream / opcodes / machine), f2 of SURVEY 8f.
+    The opcode start addresses come from the reference's player/iivision.dbg symbol table
+    (data); the expected byte streams come from the reference's own Movie.emit_stream."""
+    import machine
+    import movie
+    import opcodes
+    import video_mode
+    addr = np.zeros((32, 32), dtype=np.uint16)   # [tick index (tick-4)/2][page-32]
+    for ti, tick in enumerate(range(4, 68, 2)):
+        for page in range(32, 64):
+            addr[ti, page - 32] = opcodes.TICK_OPCODES[(tick, page)]._START
+    special = np.array([opcodes.Ack._START, opcodes.Terminate._START, opcodes.Nop._START], dtype=np.uint16)
+    out = {"tick_addr": addr, "special_addr": special}
+    rng = np.random.default_rng(77)
+    for tag, mode, n_ops, max_bytes in (("HGR_a", "HGR", 700, None), ("DHGR_a", "DHGR", 1000, None),
+                                        ("DHGR_b", "DHGR", 291, None), ("DHGR_c", "DHGR", 292, None),
+                                        ("HGR_limit", "HGR", 900, 3000), ("DHGR_empty", "DHGR", 0, None)):
+        m = movie.Movie.__new__(movie.Movie)
+        m.video_mode = video_mode.VideoMode[mode]
+        m.max_bytes_out = max_bytes
+        m.stream_pos = 0
+        m.state = machine.Machine()
+        m.aux_memory_bank = False
+        ticks = rng.integers(0, 32, n_ops) * 2 + 4
+        ops = rng.integers(0, 256, (n_ops, 6)).astype(np.uint8)
+        ops[:, 0] = rng.integers(32, 64, n_ops)
+
+        def gen():
+            yield opcodes.Header(mode=m.video_mode)
+            for k in range(n_ops):
+                yield opcodes.TICK_OPCODES[(int(ticks[k]), int(ops[k, 0]))](int(ops[k, 1]), tuple(int(x) for x in ops[k, 2:6]))
+        stream = np.array(list(m.emit_stream(gen())), dtype=np.uint8)
+        out[tag + "/ticks"] = ticks.astype(np.uint8)
+        out[tag + "/ops"] = ops
+        out[tag + "/stream"] = stream
+        out[tag + "/meta"] = np.array([0 if mode == "HGR" else 1, -1 if max_bytes is None else max_bytes], dtype=np.int32)
+        print(tag, len(stream))
+    np.savez_compressed(os.path.join(HERE, "g6_a2m.npz"), **out)
+
+
+if __name__ == "__main__" and "--a2m-only" in sys.argv:
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    setup_reference("/tmp/iiv_ref")
+    make_a2m_golden("/tmp/iiv_ref")
