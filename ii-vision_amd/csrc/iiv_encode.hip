@@ -272,9 +272,6 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
                     dwv[j] = edit_distance<ModeTraits<MODE>::kDots>(a.x, (uint32_t)a.y, b.x, (uint32_t)b.y, lut);
                 }
             }
-            // keep the eight recurrences from being interleaved: that costs more registers
-            // than the 64 a 2-workgroups-per-CU launch allows
-            __builtin_amdgcn_sched_barrier(0);
         } else {
             // screen.py:441-443: pair = (source << bits) + target
             dwv[j] = table[((size_t)o << (2 * BITS)) + ((size_t)cm << BITS) + tm];
@@ -428,6 +425,7 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
         cursor[1023 - tid] = (uint32_t)bstart;
         start[1023 - tid] = (uint32_t)bstart;
         __syncthreads();
+        IIV_STAMP(8);
         // (the bucket is recovered from the key, so the priorities need not stay in registers)
 #pragma unroll
         for (int j = 0; j < 8; j++)
@@ -436,16 +434,27 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
                 keys[atomicAdd(&cursor[bk], 1u)] = kv[j];
             }
         __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            if (kv[j] != ~0ull) {
-                const int bk = (int)((0x7fffffffu - (uint32_t)(kv[j] >> 29)) >> sh);
-                const int s0 = (int)start[bk];
-                const int e0 = bk == 0 ? n : (int)start[bk - 1];
-                int below = 0;
-                for (int i = s0; i < e0; i++) below += keys[i] < kv[j] ? 1 : 0;
-                S.order[s0 + below] = ((uint32_t)(kv[j] >> 8) & 0x1fffu) | (((uint32_t)kv[j] & 0xffu) << 16);
+        IIV_STAMP(9);
+        // rank: the scattered keys lie densely in keys[0, n_sel) grouped by bucket; thread t takes
+        // slot t (not "its own" entries, which in prefix mode occupy ~1 lane in 9) and counts
+        // the smaller keys of that key's bucket, four independent LDS reads per trip
+        for (int t = tid; t < n_sel; t += kProThreads) {
+            const unsigned long long key = keys[t];
+            const int bk = (int)((0x7fffffffu - (uint32_t)(key >> 29)) >> sh);
+            const int s0 = (int)start[bk];
+            const int e0 = bk == 0 ? n : (int)start[bk - 1];
+            const int last = e0 - 1;
+            int below = 0;
+            for (int i = s0; i < e0; i += 4) {
+                const unsigned long long k0 = keys[i];
+                const unsigned long long k1 = keys[i + 1 < e0 ? i + 1 : last];
+                const unsigned long long k2 = keys[i + 2 < e0 ? i + 2 : last];
+                const unsigned long long k3 = keys[i + 3 < e0 ? i + 3 : last];
+                below += (k0 < key ? 1 : 0) + ((i + 1 < e0 && k1 < key) ? 1 : 0) +
+                         ((i + 2 < e0 && k2 < key) ? 1 : 0) + ((i + 3 < e0 && k3 < key) ? 1 : 0);
             }
+            S.order[s0 + below] = ((uint32_t)(key >> 8) & 0x1fffu) | (((uint32_t)key & 0xffu) << 16);
+        }
     } else if (n_sel <= 4 * kProThreads && n_sel < n) {
         // degenerate buckets, prefix selection still small: compact + bitonic
         int tot;

@@ -1,0 +1,24 @@
+"""Diagnostic: distribution of update_priority in steady state (bucket sizing)."""
+import os, sys
+sys.path.insert(0, os.path.join(os.getcwd(), 'ii-vision_amd', 'transcoder'))
+import numpy as np, torch
+import _iiv_native as native, stream_batch, palette
+_, dm = native.cie2000_matrix(palette.NTSCPalette.rgb_array())
+mode = native.DHGR
+table = native.build_table(mode, dm, True); store = native.build_store_table(mode, dm)
+S = 8
+for coh in (False, True):
+    fm, fa = stream_batch.synth_frames_torch(S, 60, True, seed=5, coherent=coh)
+    b = stream_batch.StreamBatch(mode, table, store, S, seeds=[(i+1,i+1) for i in range(S)], dm=dm)
+    b.encode_frames(fm, fa, 60); b.enc.check()
+    for i in (0, 3):
+        up = b.enc.get_state(native.STATE_UP_MAIN, i).reshape(-1)
+        nz = up[up != 0]
+        mx = int(nz.max()); sh = 0 if mx < 1024 else mx.bit_length() - 10
+        bins = np.bincount(nz >> sh, minlength=1024)
+        srt = np.sort(nz)[::-1]
+        thr = srt[876] if len(srt) > 876 else 0
+        print("coh" if coh else "iid", "stream", i, "n", len(nz), "max", mx, "mean %.0f" % nz.mean(), "p50", int(np.median(nz)),
+              "p88", int(np.percentile(nz, 88)), "sh", sh, "max bucket", bins.max(), "bucket at thr", bins[thr >> sh],
+              "nonempty", (bins > 0).sum())
+    b.close()
