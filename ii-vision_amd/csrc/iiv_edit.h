@@ -48,22 +48,19 @@ template <int MODE> __host__ __device__ inline uint32_t to_dots(uint32_t m, int 
 // the string is returned as packed nibbles, pixel k in nibble k (lo: 0..15, hi: 16..).
 template <int MODE> __host__ __device__ inline void colour_string(uint32_t m, int o, uint64_t &lo, uint32_t &hi)
 {
-    uint32_t dots = to_dots<MODE>(m, o);
-    int ph = phase_of(MODE, o);
-    lo = 0;
-    hi = 0;
+    const uint32_t dots = to_dots<MODE>(m, o);
+    const int ph = phase_of(MODE, o);
+    // 32-bit accumulators of 8 pixels each; rol4(w, r) = ((w | w << 4) >> (4 - r)) & 15
+    uint32_t w[3] = {0, 0, 0};
+#pragma unroll
     for (int k = 0; k < ModeTraits<MODE>::kDots; k++) {
-        uint32_t w = (dots >> k) & 0xf;
-        int r = (ph + k) & 3;
-        uint32_t c = ((w << r) | (w >> (4 - r))) & 0xf;
-        if (k < 16)
-            lo |= (uint64_t)c << (4 * k);
-        else
-            hi |= c << (4 * (k - 16));
+        const uint32_t win = (dots >> k) & 0xf;
+        const uint32_t c = ((win | (win << 4)) >> (4 - ((ph + k) & 3))) & 0xf;
+        w[k >> 3] |= c << (4 * (k & 7));
     }
+    lo = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+    hi = w[2];
 }
-
-// ------------------------------------------------------------------ edit distance
 
 template <int K> __device__ inline uint32_t nib(uint64_t lo, uint32_t hi)
 {
@@ -75,13 +72,21 @@ template <int K> __device__ inline uint32_t nib(uint64_t lo, uint32_t hi)
 // weighted Damerau-Levenshtein between two equal-length colour strings with
 // insert/delete cost 1e5 and transpose cost 1 (make_data_tables.py:30-41,98-104)
 // reduces to E[k] = min(E[k-1] + sub(a_k,b_k), E[k-2] + 1 if a_{k-1}a_k == b_k b_{k-1}).
-// lut = 16x16 substitute costs (u16) in LDS.
+// lut = 16x16 substitute costs (u16) in LDS, diagonal forced to 0 (see load_cost_lut).
+// stage the 16x16 costs in LDS with a zero diagonal (call with >= 256 threads, then barrier)
+__device__ inline void load_cost_lut(uint16_t *lut, const uint16_t *sub, int tid)
+{
+    if (tid < 256) lut[tid] = ((tid >> 4) == (tid & 15)) ? (uint16_t)0 : sub[tid];
+}
+
 template <int N, int K> struct EditStep {
     __device__ static inline void run(uint64_t alo, uint32_t ahi, uint64_t blo, uint32_t bhi,
                                       const uint16_t *lut, uint32_t &e1, uint32_t &e2)
     {
         uint32_t a = nib<K>(alo, ahi), b = nib<K>(blo, bhi);
-        uint32_t s = (a == b) ? 0u : (uint32_t)lut[a * 16 + b];
+        // lut's diagonal is zeroed by whoever loads it (equal pixels cost nothing,
+        // make_data_tables.py / weighted_levenshtein), so the read needs no branch
+        uint32_t s = (uint32_t)lut[a * 16 + b];
         uint32_t e = e1 + s;
         if (K >= 1) {
             uint32_t ap = nib<(K >= 1 ? K - 1 : 0)>(alo, ahi), bp = nib<(K >= 1 ? K - 1 : 0)>(blo, bhi);

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
         reinterpret_cast<uint4 *>(tgt[b])[k] = reinterpret_cast<const uint4 *>(src)[k];
     }
     for (int i = tid; i < 624; i += kProThreads) mtb[0][i] = S.mt_np[i];
-    if (DP && tid < 256) lut[tid] = sub[tid];
+    if (DP) load_cost_lut(lut, sub, tid);
     __syncthreads();
 
     IIV_STAMP(1);

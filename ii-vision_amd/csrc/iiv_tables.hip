@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void table_kernel(const ulonglong2 *__restrict
 {
     constexpr int BITS = ModeTraits<MODE>::kBits, ND = ModeTraits<MODE>::kDots;
     __shared__ uint16_t lut[256];
-    lut[threadIdx.x] = sub[threadIdx.x];
+    load_cost_lut(lut, sub, threadIdx.x);
     __syncthreads();
     const int o = blockIdx.z;
     const ulonglong2 *S = strings + ((size_t)o << BITS);
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void store_kernel(const ulonglong2 *__restrict
 {
     constexpr int BITS = ModeTraits<MODE>::kBits, ND = ModeTraits<MODE>::kDots, CB = ModeTraits<MODE>::kContentBits;
     __shared__ uint16_t lut[256];
-    lut[threadIdx.x] = sub[threadIdx.x];
+    load_cost_lut(lut, sub, threadIdx.x);
     __syncthreads();
     size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // ((o << CB) + content) << BITS) + m
     if (idx >= ((size_t)ModeTraits<MODE>::kOffsets << (CB + BITS))) return;
