@@ -72,7 +72,7 @@ def parse_args():
     ap.add_argument("--coherent", action="store_true", help="S-coh input instead of S-iid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=600, help="frames of stream 0 the CPU baseline encodes")
-    ap.add_argument("--cpu-frames-all", type=int, default=300, help="frames per stream of the all-cores CPU baseline")
+    ap.add_argument("--cpu-frames-all", type=int, default=60, help="frames per stream of the all-cores CPU baseline")
     ap.add_argument("--dw-table", action="store_true",
                     help="gather diff weights from the HBM table instead of recomputing them (same values)")
     ap.add_argument("--greedy", choices=["auto", "wave", "workgroup"], default="auto",
