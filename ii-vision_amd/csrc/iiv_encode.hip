@@ -1181,8 +1181,10 @@ struct Encoder {
     int greedy_mode;        // IIV_GREEDY_WAVE / IIV_GREEDY_WORKGROUP
     int partial_sort;       // allow the prologue's prefix sort when the budget is known
     StreamState *d_states;
+    StreamState *d_snapshot;  // iiv_encoder_snapshot copy (lazily allocated)
     // generator bookkeeping shared by all streams (same schedule)
     int gen_active, gen_is_aux, gen_frame;
+    int snap_gen_active, snap_gen_is_aux, snap_gen_frame;
     // profiling
     int profiling;
     std::vector<hipEvent_t> ev_pool;
@@ -1230,6 +1232,7 @@ int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, c
     e->d_table = d_table;
     e->d_store = d_store;
     e->d_states = nullptr;
+    e->d_snapshot = nullptr;
     e->d_strings = nullptr;
     e->d_sub = nullptr;
     e->dw_mode = dm ? IIV_DW_RECURRENCE : IIV_DW_TABLE;
@@ -1280,9 +1283,33 @@ void encoder_destroy(Encoder *e)
     if (!e) return;
     for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
     if (e->d_states) (void)hipFree(e->d_states);
+    if (e->d_snapshot) (void)hipFree(e->d_snapshot);
     if (e->d_strings) (void)hipFree(e->d_strings);
     if (e->d_sub) (void)hipFree(e->d_sub);
     delete e;
+}
+
+int encoder_snapshot(Encoder *e, hipStream_t st)
+{
+    if (!e) return set_error(IIV_ERR_INVALID, "snapshot: null encoder");
+    const size_t bytes = sizeof(StreamState) * (size_t)e->n_streams;
+    if (!e->d_snapshot) IIV_HIP(hipMalloc(&e->d_snapshot, bytes));
+    IIV_HIP(hipMemcpyAsync(e->d_snapshot, e->d_states, bytes, hipMemcpyDeviceToDevice, st));
+    e->snap_gen_active = e->gen_active;
+    e->snap_gen_is_aux = e->gen_is_aux;
+    e->snap_gen_frame = e->gen_frame;
+    return IIV_OK;
+}
+
+int encoder_rollback(Encoder *e, hipStream_t st)
+{
+    if (!e || !e->d_snapshot) return set_error(IIV_ERR_INVALID, "rollback: no snapshot");
+    const size_t bytes = sizeof(StreamState) * (size_t)e->n_streams;
+    IIV_HIP(hipMemcpyAsync(e->d_states, e->d_snapshot, bytes, hipMemcpyDeviceToDevice, st));
+    e->gen_active = e->snap_gen_active;
+    e->gen_is_aux = e->snap_gen_is_aux;
+    e->gen_frame = e->snap_gen_frame;
+    return IIV_OK;
 }
 
 int encoder_set_option(Encoder *e, int option, int value)
@@ -1600,6 +1627,18 @@ void iiv_encoder_destroy(iiv_encoder *enc)
     if (!enc) return;
     iiv::encoder_destroy(enc->impl);
     delete enc;
+}
+
+int iiv_encoder_snapshot(iiv_encoder *enc, void *stream)
+{
+    if (!enc) return iiv::set_error(IIV_ERR_INVALID, "null encoder");
+    return iiv::encoder_snapshot(enc->impl, (hipStream_t)stream);
+}
+
+int iiv_encoder_rollback(iiv_encoder *enc, void *stream)
+{
+    if (!enc) return iiv::set_error(IIV_ERR_INVALID, "null encoder");
+    return iiv::encoder_rollback(enc->impl, (hipStream_t)stream);
 }
 
 int iiv_encoder_set_option(iiv_encoder *enc, int option, int value)

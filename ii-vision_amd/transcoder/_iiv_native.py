@@ -32,7 +32,8 @@ SYMBOLS = [
     "iiv_store_table_entries",
     "iiv_cie2000_matrix", "iiv_pixel_strings", "iiv_build_table", "iiv_build_store_table",
     "iiv_pack", "iiv_diff_weights", "iiv_compute_delta_pages",
-    "iiv_encoder_create", "iiv_encoder_destroy", "iiv_encoder_set_option", "iiv_encoder_get_state", "iiv_encoder_set_state",
+    "iiv_encoder_create", "iiv_encoder_destroy", "iiv_encoder_set_option",
+    "iiv_encoder_snapshot", "iiv_encoder_rollback", "iiv_encoder_get_state", "iiv_encoder_set_state",
     "iiv_encode", "iiv_encoder_check", "iiv_encoder_profile", "iiv_encoder_profile_read",
     "iiv_emit_stream",
 ]
@@ -88,6 +89,8 @@ def lib():
     L.iiv_compute_delta_pages.argtypes = [i32, vp, i32, vp, vp, vp, vp, i32, vp, vp]
     L.iiv_encoder_create.argtypes = [i32, vp, vp, vp, i32, C.POINTER(vp)]
     L.iiv_encoder_set_option.argtypes = [vp, i32, i32]
+    L.iiv_encoder_snapshot.argtypes = [vp, vp]
+    L.iiv_encoder_rollback.argtypes = [vp, vp]
     L.iiv_encoder_destroy.argtypes = [vp]
     L.iiv_encoder_destroy.restype = None
     L.iiv_encoder_get_state.argtypes = [vp, i32, i32, vp, sz]
@@ -303,6 +306,12 @@ class Encoder:
         check(lib().iiv_encode(self._h, dptr(frames_main), dptr(frames_aux), int(n_frames), segs, len(segments),
                                dptr(ops_out), stream_ptr()))
         return ops_out
+
+    def snapshot(self):
+        check(lib().iiv_encoder_snapshot(self._h, stream_ptr()))
+
+    def rollback(self):
+        check(lib().iiv_encoder_rollback(self._h, stream_ptr()))
 
     def check(self):
         bad = C.c_int(-1)

@@ -17,8 +17,10 @@ Budget: a generator may be abandoned after any next() (movie.py:94-109 does so a
 every frame and bank flip), and its side effects must then be exactly those of
 the opcodes consumed.  Without a hint every next() is therefore one device call.
 `encode_frame(target, is_aux, budget=K)` promises that K opcodes will be pulled;
-they are then computed by one launch.  Batched, many-stream encoding (what
-bench.py measures) goes through stream_batch.StreamBatch instead.
+they are then computed by one launch.  `Video.SPECULATE = N` (opt-in) gets batched
+launches without a promise: N opcodes are produced from a device-side snapshot
+and rolled back + replayed if fewer were consumed.  Batched, many-stream encoding
+(what bench.py measures) goes through stream_batch.StreamBatch instead.
 """
 
 import random
@@ -37,6 +39,15 @@ class Video:
 
     CLOCK_SPEED = 1024 * 1024  # type: int
 
+    #: Opcodes produced per device call when encode_frame() got no `budget`.
+    #: 0 or 1 = one exact step per next().  N > 1 = speculate: N opcodes are produced
+    #: from a device-side snapshot; if the generator is abandoned (or any state
+    #: attribute is read) after k < N of them were consumed, the snapshot is restored
+    #: and exactly k are replayed, so observable state is always that of the consumed
+    #: opcodes.  (The *global* random / np.random states are only re-synchronised at
+    #: those points, hence opt-in.)
+    SPECULATE = 0
+
     def __init__(
             self,
             frame_grabber,
@@ -52,28 +63,63 @@ class Video:
         )  # type: float
         self.frame_number = 0  # type: int
         self.palette = palette  # type: Palette
+        self._pending = None  # speculative chunk not yet fully consumed
 
         # Empty screen (video.py:37-53); the pixelmap aliases the memory maps
-        self.memory_map = screen.MemoryMap(screen_page=1)
+        self._memory_map = screen.MemoryMap(screen_page=1)
+        self._aux_memory_map = None
         if self.mode == VideoMode.DHGR:
-            self.aux_memory_map = screen.MemoryMap(screen_page=1)
-            self.pixelmap = screen.DHGRBitmap(
-                palette=palette, main_memory=self.memory_map, aux_memory=self.aux_memory_map)
+            self._aux_memory_map = screen.MemoryMap(screen_page=1)
+            self._pixelmap = screen.DHGRBitmap(
+                palette=palette, main_memory=self._memory_map, aux_memory=self._aux_memory_map)
         else:
-            self.pixelmap = screen.HGRBitmap(palette=palette, main_memory=self.memory_map)
+            self._pixelmap = screen.HGRBitmap(palette=palette, main_memory=self._memory_map)
 
         # Pending edit weights, accumulated across frames (video.py:55-58)
-        self.update_priority = np.zeros((32, 256), dtype=np.int32)
+        self._update_priority = np.zeros((32, 256), dtype=np.int32)
+        self._aux_update_priority = None
         if self.mode == VideoMode.DHGR:
-            self.aux_update_priority = np.zeros((32, 256), dtype=np.int32)
+            self._aux_update_priority = np.zeros((32, 256), dtype=np.int32)
 
         # True once the main / aux bank has run out of work (video.py:60-62)
-        self.out_of_work = {True: False, False: False}
+        self._out_of_work = {True: False, False: False}
 
-        tables = self.pixelmap.edit_distances(palette)
+        tables = self._pixelmap.edit_distances(palette)
         self._mode_id = native.DHGR if mode == VideoMode.DHGR else native.HGR
         self._enc = native.Encoder(self._mode_id, tables.table, tables.store, n_streams=1, dm=tables.dm)
         self._live = None  # the generator whose state the device currently holds
+
+    # ---- the reference's public attributes; reading one settles any speculation first
+    def _settled(name):  # noqa: N805
+        def get(self):
+            self._settle()
+            return getattr(self, name)
+
+        def set_(self, value):
+            self._settle()
+            setattr(self, name, value)
+        return property(get, set_)
+
+    memory_map = _settled("_memory_map")
+    pixelmap = _settled("_pixelmap")
+    update_priority = _settled("_update_priority")
+    out_of_work = _settled("_out_of_work")
+
+    @property
+    def aux_memory_map(self):
+        if self._aux_memory_map is None:
+            raise AttributeError("aux_memory_map")  # HGR Video has none (video.py:40-42)
+        self._settle()
+        return self._aux_memory_map
+
+    @property
+    def aux_update_priority(self):
+        if self._aux_update_priority is None:
+            raise AttributeError("aux_update_priority")
+        self._settle()
+        return self._aux_update_priority
+
+    del _settled
 
     def tick(self, ticks: int) -> bool:
         """Keep track of when it is time for a new image frame (video.py:64-70)."""
@@ -86,53 +132,63 @@ class Video:
 
     def _upload(self):
         e = self._enc
-        e.set_state(native.STATE_MEM_MAIN, self.memory_map.page_offset)
-        e.set_state(native.STATE_UP_MAIN, self.update_priority)
+        e.set_state(native.STATE_MEM_MAIN, self._memory_map.page_offset)
+        e.set_state(native.STATE_UP_MAIN, self._update_priority)
         if self.mode == VideoMode.DHGR:
-            e.set_state(native.STATE_MEM_AUX, self.aux_memory_map.page_offset)
-            e.set_state(native.STATE_UP_AUX, self.aux_update_priority)
+            e.set_state(native.STATE_MEM_AUX, self._aux_memory_map.page_offset)
+            e.set_state(native.STATE_UP_AUX, self._aux_update_priority)
         e.set_state(native.STATE_RNG_PY, np.array(random.getstate()[1], dtype=np.uint32))
         st = np.random.get_state()
         e.set_state(native.STATE_RNG_NP,
                     np.concatenate([np.asarray(st[1], dtype=np.uint32), np.array([st[2]], dtype=np.uint32)]))
 
-    def _download(self):
+    def _download(self, is_aux):
         e = self._enc
         # in place: callers (and self.pixelmap) hold references to these arrays
-        self.memory_map.page_offset[...] = e.get_state(native.STATE_MEM_MAIN)
-        self.update_priority[...] = e.get_state(native.STATE_UP_MAIN)
+        self._memory_map.page_offset[...] = e.get_state(native.STATE_MEM_MAIN)
+        self._update_priority[...] = e.get_state(native.STATE_UP_MAIN)
         if self.mode == VideoMode.DHGR:
-            self.aux_memory_map.page_offset[...] = e.get_state(native.STATE_MEM_AUX)
-            self.aux_update_priority[...] = e.get_state(native.STATE_UP_AUX)
-        self.pixelmap.packed[...] = e.get_state(native.STATE_PACKED)
+            self._aux_memory_map.page_offset[...] = e.get_state(native.STATE_MEM_AUX)
+            self._aux_update_priority[...] = e.get_state(native.STATE_UP_AUX)
+        self._pixelmap.packed[...] = e.get_state(native.STATE_PACKED)
         random.setstate((3, tuple(int(x) for x in e.get_state(native.STATE_RNG_PY)), None))
         npw = e.get_state(native.STATE_RNG_NP)
         st = np.random.get_state()
         np.random.set_state((st[0], npw[:624].copy(), int(npw[624]), st[3], st[4]))
+        oow = e.get_state(native.STATE_OUT_OF_WORK)
+        if oow[1 if is_aux else 0]:
+            self._out_of_work[bool(is_aux)] = True  # video.py:189
 
-    def _device_steps(self, token, target, is_aux, n_ops):
-        """[prologue +] n_ops greedy steps of generator `token`; returns (n_ops, 6) uint8."""
+    def _launch(self, target, is_aux, restart, n_ops):
+        """[prologue +] n_ops greedy steps on the device state as it stands."""
         import torch
-        restart = 0 if self._live is token else 1
-        if restart and token.started:
-            raise RuntimeError("this encode_frame() generator cannot be resumed: another generator "
-                               "has run on this Video since (the reference's heap is not kept)")
-        self._upload()
         main = np.ascontiguousarray(target.main_memory.page_offset, dtype=np.uint8)
         fm = torch.from_numpy(main[None, None]).cuda()
         fa = None
         if self.mode == VideoMode.DHGR:
             aux = np.ascontiguousarray(target.aux_memory.page_offset, dtype=np.uint8)
             fa = torch.from_numpy(aux[None, None]).cuda()
-        ops = self._enc.encode(fm, fa, [(0, int(bool(is_aux)), restart, int(n_ops))])
+        # a generator's out_of_work flag on the device must reflect the host's (movie.py:96 resets it)
+        ops = self._enc.encode(fm, fa, [(0, int(bool(is_aux)), int(restart), int(n_ops))])
         self._enc.check()
-        self._live = token
-        token.started = True
-        self._download()
-        oow = self._enc.get_state(native.STATE_OUT_OF_WORK)
-        if oow[1 if is_aux else 0]:
-            self.out_of_work[bool(is_aux)] = True  # video.py:189
         return ops[0].cpu().numpy()
+
+    def _settle(self):
+        """Make host state reflect exactly the opcodes consumed so far."""
+        p = self._pending
+        if p is None:
+            return
+        self._pending = None
+        if p["consumed"] == p["produced"]:
+            return
+        # abandoned mid-chunk: restore the snapshot and replay only what was consumed
+        self._enc.rollback()
+        if p["consumed"]:
+            self._launch(p["target"], p["is_aux"], p["restart"], p["consumed"])
+        elif p["restart"]:
+            self._live = p["prev_live"]  # the prologue never happened
+            p["token"].started = False
+        self._download(p["is_aux"])
 
     # ------------------------------------------------------------------ encode
 
@@ -162,9 +218,35 @@ class Video:
             started = False
 
         token = _Token()
-        chunk = int(budget) if budget else 1
+        chunk = int(budget) if budget else max(1, int(self.SPECULATE))
+        speculative = not budget and chunk > 1
         while True:
-            ops = self._device_steps(token, target_pixelmap, is_aux, chunk)
+            self._settle()
+            restart = 0 if self._live is token else 1
+            if restart and token.started:
+                raise RuntimeError("this encode_frame() generator cannot be resumed: another generator "
+                                   "has run on this Video since (the reference's heap is not kept)")
+            prev_live = self._live
+            self._upload()
+            if speculative:
+                self._enc.snapshot()
+            ops = self._launch(target_pixelmap, is_aux, restart, chunk)
+            self._live = token
+            token.started = True
+            self._download(is_aux)
+            rec = None
+            if speculative:
+                rec = dict(token=token, target=target_pixelmap, is_aux=is_aux, restart=restart,
+                           consumed=0, produced=len(ops), prev_live=prev_live)
+                self._pending = rec
             for k in range(len(ops)):
+                if rec is not None:
+                    rec["consumed"] = k + 1
                 yield int(ops[k, 0]), int(ops[k, 1]), [int(o) for o in ops[k, 2:6]]
-            chunk = 1
+                if rec is not None and self._pending is not rec:
+                    break  # settled underneath us: the rest of this chunk was rolled back
+            else:
+                if rec is not None and self._pending is rec:
+                    self._pending = None
+            if not speculative:
+                chunk = 1

@@ -142,6 +142,14 @@ int iiv_encoder_set_option(iiv_encoder *enc, int option, int value);
 int iiv_encoder_get_state(iiv_encoder *enc, int stream_index, int what, void *host_buf, size_t bytes);
 int iiv_encoder_set_state(iiv_encoder *enc, int stream_index, int what, const void *host_buf, size_t bytes);
 
+/* Copy / restore the complete state of every stream (screen, priorities, live
+ * generator, both RNG streams) on the device.  A caller that must not run ahead of
+ * its consumer (a lazy generator, video.py:72-93) can snapshot, produce N opcodes in
+ * one launch, and -- if only k < N were consumed -- roll back and re-run exactly k:
+ * the computation is deterministic. */
+int iiv_encoder_snapshot(iiv_encoder *enc, void *stream);
+int iiv_encoder_rollback(iiv_encoder *enc, void *stream);
+
 /* One segment = what movie.py does between two generator creations:
  * `op_seq = video.encode_frame(target, is_aux)` (if restart) followed by n_ops
  * calls of next(op_seq) (movie.py:94-109).  restart == 0 continues the

@@ -83,7 +83,7 @@ def test_bitmap_apply_and_delta(golden, name):
     assert (mm.page_offset == g[name + "_apply_main"]).all()
 
 
-def _drive(tag, golden, budgeted):
+def _drive(tag, golden, budgeted, speculate=0, peek=False):
     import palette
     import screen
     import video
@@ -95,6 +95,7 @@ def _drive(tag, golden, budgeted):
     random.seed(sp)
     np.random.seed(sn)
     v = video.Video(_FG(), ticks_per_second=14700., mode=vm, palette=palette.Palette(pal))
+    v.SPECULATE = speculate
     got = []
     with contextlib.redirect_stdout(io.StringIO()):
         for fi, ia, n in sched:
@@ -105,9 +106,13 @@ def _drive(tag, golden, budgeted):
             else:
                 tgt = screen.HGRBitmap(main_memory=main, palette=palette.Palette(pal))
             gen = v.encode_frame(tgt, is_aux=bool(ia), budget=int(n) if budgeted else None)
-            for _ in range(int(n)):
+            for k in range(int(n)):
                 page, content, offsets = next(gen)
                 got.append([page, content] + list(offsets))
+                if peek and k % 7 == 3:
+                    # reading state mid-chunk must show exactly the consumed opcodes' effects
+                    mm = v.aux_memory_map if ia else v.memory_map
+                    assert mm.page_offset[page - 32, offsets[0]] == content
     got = np.array(got, dtype=np.uint8)
     assert (got == want).all(), tag
     assert (v.memory_map.page_offset == g3[tag + "/mem_main"]).all()
@@ -131,6 +136,15 @@ def test_video_lazy_generator_exact_without_budget(golden):
 @pytest.mark.parametrize("tag", ["DHGR_iid_s1", "HGR_iid_s2", "DHGR_exhaust"])
 def test_video_with_budget(golden, tag):
     _drive(tag, golden, budgeted=True)
+
+
+@pytest.mark.parametrize("tag,spec,peek", [("DHGR_iid_s1", 64, False), ("HGR_iid_s2", 16, False),
+                                           ("DHGR_exhaust", 200, False), ("DHGR_single_ops", 5, True)])
+def test_video_speculative_chunks(golden, tag, spec, peek):
+    """Video.SPECULATE = N: N opcodes per launch from a device snapshot; abandoning a
+    generator (movie.py:94-109) or reading state mid-chunk rolls back and replays exactly
+    the consumed ones, so the stream and final state equal the reference's."""
+    _drive(tag, golden, budgeted=False, speculate=spec, peek=peek)
 
 
 def test_make_data_tables_main_writes_reference_format(tmp_path, golden, monkeypatch):
