@@ -829,12 +829,29 @@ __global__ __launch_bounds__(256) void greedy_kernel(StreamState *__restrict__ s
 //
 // Same algorithm, one 64-lane wave per stream: lane l owns page bytes 4l..4l+3.
 // Everything that is uniform per opcode (pop, validity, candidate counts, the two
-// winners, RNG cursor, opcode emission) is computed once per stream instead of
-// once per wave of a 4-wave workgroup; there is no workgroup barrier and no LDS
-// exchange in the loop: candidate ranks come from four ballots + mbcnt, the two
-// smallest keys from a DPP butterfly inside each row of 16 lanes and four
-// v_readlane pairs.  LDS accesses of one wave execute in order, which is all the
+// winners, RNG cursor, opcode emission) lives in SGPRs -- values loaded from the
+// stream state are passed through v_readfirstlane so that the compiler keeps the
+// bookkeeping on the scalar unit and the control flow in scalar branches.  There is
+// no workgroup barrier and no LDS exchange in the loop.
+//
+// Scoring, fast form.  The reference orders candidates by (delta, nonce, offset)
+// (video.py:290-301) and draws one nonce per candidate, eligible or not.  The two
+// winners depend on the nonces only if two eligible candidates share the smallest or
+// the second-smallest delta; otherwise the random stream just advances by the number
+// of candidates.  So a step computes signed keys delta << 16 | offset, takes the wave
+// minimum twice (fused-DPP min), and checks that no third eligible key shares the
+// second delta.  Only if a tie is found (2.7 % of the opcodes of the bench workload)
+// the entry is re-scored the long way, materialising the nonces exactly as the
+// reference draws them.  LDS accesses of one wave execute in order, which is all the
 // cross-lane ordering the loop needs.
+
+#define IIV_SGPR(x) __builtin_amdgcn_readfirstlane((int)(x))
+#ifndef IIV_WAVE_OCC
+#define IIV_WAVE_OCC 5     // waves per SIMD the register allocation is held to
+#endif
+#ifndef IIV_WAVE_CHUNK
+#define IIV_WAVE_CHUNK 4   // list entries whose rows and store-table values are fetched together
+#endif
 
 template <int CTRL> __device__ static inline uint32_t dpp_u32(uint32_t v)
 {
@@ -851,8 +868,53 @@ template <int CTRL> __device__ static inline void top2_step(uint32_t &k1, uint32
     k2 = hi < m2 ? hi : m2;
 }
 
+// v_min_i32_dpp: `old` is the identity, so the mov folds into the min (one VALU op)
+template <int CTRL> __device__ static inline int min_dpp(int v)
+{
+    int o = __builtin_amdgcn_update_dpp(0x7fffffff, v, CTRL, 0xf, 0xf, false);
+    return o < v ? o : v;
+}
+
+// signed minimum over the wave, returned in an SGPR
+__device__ static inline int wave_min_i32(int v)
+{
+    v = min_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = min_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = min_dpp<0x141>(v);  // row_half_mirror
+    v = min_dpp<0x140>(v);  // row_mirror: every lane holds its row's minimum
+    v = min_dpp<0x142>(v);  // row_bcast:15
+    v = min_dpp<0x143>(v);  // row_bcast:31: lane 63 holds the wave's
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// next MT19937 block, one wave, fully unrolled (constant LDS offsets, no loop counters)
+__device__ static inline void mt_twist_wave(const uint32_t *src, uint32_t *dst, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = lane + 64 * k;
+        if (k < 3 || i < 227) dst[i] = src[i + 397] ^ mt_mix(src[i], src[i + 1]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = 227 + lane + 64 * k;
+        if (k < 3 || i < 454) dst[i] = dst[i - 227] ^ mt_mix(src[i], src[i + 1]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int i = 454 + lane + 64 * k;
+        if (k < 2 || i < 624) {
+            const uint32_t nx = (i == 623) ? dst[0] : src[i + 1];
+            dst[i] = dst[i - 227] ^ mt_mix(src[i], nx);
+        }
+    }
+    __syncthreads();
+}
+
 template <int MODE>
-__global__ __launch_bounds__(64, 4) void greedy_wave_kernel(StreamState *__restrict__ states,
+__global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamState *__restrict__ states,
                                                          const uint8_t *__restrict__ frames_main,
                                                          const uint8_t *__restrict__ frames_aux, int n_frames,
                                                          int frame, int is_aux, int n_ops,
@@ -863,11 +925,13 @@ __global__ __launch_bounds__(64, 4) void greedy_wave_kernel(StreamState *__restr
     constexpr int BITS = ModeTraits<MODE>::kBits;
     constexpr int CB = ModeTraits<MODE>::kContentBits;
     constexpr uint32_t INF = 0xffffffffu;
-    constexpr int M = kChunk;
+    constexpr uint32_t HI = 0xffff0000u;
+    constexpr int M = IIV_WAVE_CHUNK;
+    typedef uint32_t __attribute__((aligned(2))) u32_a2;
     // LDS per stream: two 1 KiB bitmaps + two MT19937 blocks (~7 KiB), so residency is
-    // set by registers (4 waves per SIMD), not by LDS.  The per-byte rows a step needs
-    // (target window | diff weight, written once by the prologue and immutable while
-    // the generator lives) are fetched from L2 for a whole chunk at a time.
+    // set by registers, not by LDS.  The per-byte rows a step needs (target window |
+    // diff weight, written once by the prologue and immutable while the generator
+    // lives) are fetched from L2 for a whole chunk at a time.
     __shared__ uint32_t nz[256];     // update_priority != 0
     __shared__ uint32_t pdone[256];  // byte already emitted as a primary (its diff weight counts as 0)
     __shared__ uint32_t mt[2 * 624];
@@ -875,7 +939,6 @@ __global__ __launch_bounds__(64, 4) void greedy_wave_kernel(StreamState *__restr
     const int lane = threadIdx.x;
     StreamState &S = states[blockIdx.x];
     uint8_t *out = ops_out + (size_t)blockIdx.x * ops_stride + ops_base;
-    (void)frames_main; (void)frames_aux; (void)n_frames; (void)frame;
 
     if (!S.gen_active || S.error) {
         if (lane == 0 && !S.error) S.error = kErrNoGenerator;
@@ -888,22 +951,113 @@ __global__ __launch_bounds__(64, 4) void greedy_wave_kernel(StreamState *__restr
     for (int i = lane; i < 624; i += 64) mt[i] = S.mt_py[i];
     __syncthreads();
     int cb = 0;  // block cb (mt + 624*cb) is current, the other one follows it
-    mt_twist<64>(mt, mt + 624, lane);
-    int mt_idx = S.mt_py_idx;
+    mt_twist_wave(mt, mt + 624, lane);
+    int mt_idx = IIV_SGPR(S.mt_py_idx);
     if (mt_idx >= 624) {
-        mt_twist<64>(mt + 624, mt, lane);
+        mt_twist_wave(mt + 624, mt, lane);
         cb = 1;
         mt_idx -= 624;
     }
 
-    const int n_sorted = S.n_sorted;
-    int head = S.head, n_pushed = S.n_pushed, exhausted = S.exhausted;
+    const int n_sorted = IIV_SGPR(S.n_sorted);
+    const int truncated = IIV_SGPR(S.truncated);
+    int head = IIV_SGPR(S.head), n_pushed = IIV_SGPR(S.n_pushed), exhausted = IIV_SGPR(S.exhausted);
     int done = 0, err = 0;
     unsigned long long draws = 0, pad_ops = 0;
     const uint16_t *store_e = store + ((size_t)byte_offset<MODE>(0, is_aux) << (CB + BITS));
     const uint16_t *store_d = store + ((size_t)byte_offset<MODE>(1, is_aux) << (CB + BITS));
-    const uint32_t pad_content = S.pad_content;
-    const int bshift = (4 * lane) & 31;  // this lane's 4 bits inside a bitmap word
+    const uint8_t *tgt_frames = (MODE == kDHGR && is_aux ? frames_aux : frames_main) +
+                                ((size_t)blockIdx.x * n_frames + frame) * 8192;
+    const uint4 *wd_rows = reinterpret_cast<const uint4 *>(S.wd);
+    int32_t *up = S.up[is_aux];
+    uint8_t *mem = S.mem[is_aux];
+    const uint32_t pad_content = (uint32_t)IIV_SGPR(S.pad_content);
+    const int wsel = lane >> 3;          // this lane's word inside a page's 8 bitmap words
+    const int sh0 = (4 * lane) & 31;     // its 4 bits inside that word
+    const int y0 = 4 * lane;
+
+    // per-byte keys of entry (p, x) from its wd row and store-table values:
+    //   kt[r] = delta << 16 | y   with the reference's diff weight (0 for primaries, video.py:141)
+    //   ke[r] = the same for bytes that may still be chosen (update_priority != 0, video.py:159),
+    //           >= 0 for every other byte
+    // C = number of candidates (delta < 0), i.e. nonces the reference draws (video.py:290-293);
+    // *below = candidates in lower lanes (only the slow form needs it)
+    auto score = [&](const uint4 &w, const uint32_t (&nd)[4], int p, int x, int (&kt)[4], int (&ke)[4], int &C,
+                     int *below) -> bool {
+        uint32_t nzw = nz[p * 8 + wsel], pdw = pdone[p * 8 + wsel];
+        // video.py:130 -- skip a byte whose priority was cleared since the chunk was formed
+        const uint32_t xw = (uint32_t)__builtin_amdgcn_readlane((int)nzw, (x >> 5) * 8);
+        if (!((xw >> (x & 31)) & 1u)) return false;
+        // x itself leaves both sets before the page is scored (video.py:140-141)
+        const uint32_t xbit = wsel == (x >> 5) ? 1u << (x & 31) : 0u;
+        nzw &= ~xbit;
+        pdw |= xbit;
+        const uint32_t wdr[4] = {w.x, w.y, w.z, w.w};
+        C = 0;
+        if (below) *below = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int sh = 31 - (sh0 + r);
+            const uint32_t gone = (uint32_t)((int)(pdw << sh) >> 31);
+            const uint32_t live = (uint32_t)((int)(nzw << sh) >> 31);
+            const int n16 = (int)((nd[r] << 16) | (uint32_t)(y0 + r));
+            kt[r] = n16 - (int)(wdr[r] & ~gone & HI);   // screen.py:547
+            ke[r] = n16 - (int)(wdr[r] & live & HI);
+            const unsigned long long bal = __ballot(kt[r] < 0);  // video.py:283
+            C += (int)__popcll(bal);
+            if (below) *below += prefix_popc(bal);
+        }
+        return true;
+    };
+
+    // store-table value of page byte y of the scored entry, as a scalar
+    auto nd_of = [&](const uint32_t (&nd)[4], int y) -> uint32_t {
+        const int r = y & 3;
+        const uint32_t v = r == 0 ? nd[0] : r == 1 ? nd[1] : r == 2 ? nd[2] : nd[3];
+        return (uint32_t)__builtin_amdgcn_readlane((int)v, y >> 2);
+    };
+
+    // video.py:140-144, 170-187; screen.py:256-293.  Lanes 0..2 carry (x, y1, y2); a
+    // missing secondary repeats the primary's stores.  Returns false on overflow.
+    auto apply = [&](int p, int x, uint32_t c, int y1, uint32_t nd1, int y2, uint32_t nd2, int C) -> bool {
+        const uint32_t v1 = y1 >= 0 ? nd1 : 0u, v2 = y2 >= 0 ? nd2 : 0u;
+        const int y1e = y1 >= 0 ? y1 : x, y2e = y2 >= 0 ? y2 : x;   // video.py:185-186
+        const int f1 = v1 ? 1 : 0, f2 = v2 ? 1 : 0;
+        if (n_pushed + f1 + f2 > kPushedCap) return false;
+        if (lane < 3) {
+            const int off = lane == 0 ? x : lane == 1 ? y1e : y2e;
+            const uint32_t val = lane == 0 ? 0u : lane == 1 ? v1 : v2;
+            up[p * 256 + off] = (int32_t)val;  // byte_pair_difference == store-table value (screen.py:383-398)
+            mem[p * 256 + off] = (uint8_t)c;
+            if (val == 0) {
+                atomicAnd(&nz[p * 8 + (off >> 5)], ~(1u << (off & 31)));
+            } else {
+                const int k = lane == 2 ? f1 : 0;
+                int j = mt_idx + cb * 624 + C + k;
+                if (j >= 1248) j -= 1248;
+                const uint32_t nonce = mt_temper(mt[j]) >> 24;  // video.py:178
+                S.pushed[n_pushed + k] = ((2047u - val) << 21) | (nonce << 13) | ((uint32_t)p << 8) | (uint32_t)off;
+            }
+            if (lane == 0) {
+                atomicOr(&pdone[p * 8 + (x >> 5)], 1u << (x & 31));
+                uint8_t *q = out + (size_t)done * 6;
+                *reinterpret_cast<u32_a2 *>(q) =
+                    (uint32_t)(p + 32) | (c << 8) | ((uint32_t)x << 16) | ((uint32_t)y1e << 24);
+                *reinterpret_cast<uint16_t *>(q + 4) = (uint16_t)((uint32_t)y2e | ((uint32_t)x << 8));
+            }
+        }
+        mt_idx += C + f1 + f2;
+        draws += (unsigned long long)(C + f1 + f2);
+        n_pushed += f1 + f2;
+        done++;
+        if (mt_idx >= 624) {
+            __syncthreads();
+            mt_twist_wave(mt + 624 * (cb ^ 1), mt + 624 * cb, lane);
+            cb ^= 1;
+            mt_idx -= 624;
+        }
+        return true;
+    };
 
     int guard = n_ops + 8192 + 2 * kPushedCap + 64;
     while (done < n_ops && !err) {
@@ -922,8 +1076,8 @@ __global__ __launch_bounds__(64, 4) void greedy_wave_kernel(StreamState *__restr
         }
 
         // ---- form a chunk: next <= M entries whose priority is still non-zero
-        uint32_t ent[M];  // page << 8 | offset | content << 16
-        int pos[M];
+        uint32_t ent[M];  // page << 8 | offset | content << 16 | (list position - chunk_head) << 24
+        const int chunk_head = head;
         int cnt = 0, chunk_end = head;
         bool from_pushed = false;
         if (head < n_sorted) {
@@ -940,18 +1094,16 @@ __global__ __launch_bounds__(64, 4) void greedy_wave_kernel(StreamState *__restr
 #pragma unroll
             for (int m = 0; m < M; m++) {
                 ent[m] = 0;
-                pos[m] = 0;
                 if (mask) {
                     int l = __builtin_ctzll(mask);
                     mask &= mask - 1;
-                    ent[m] = __builtin_amdgcn_readlane(e, l);
-                    pos[m] = head + l;
+                    ent[m] = (uint32_t)__builtin_amdgcn_readlane(e, l) | ((uint32_t)l << 24);
                     cnt = m + 1;
                 }
             }
-            chunk_end = mask ? pos[M - 1] + 1 : window_end;
+            chunk_end = mask ? head + (int)(ent[M - 1] >> 24) + 1 : window_end;
         } else {
-            if (S.truncated) {  // more initial entries exist than were ordered: host budget bug
+            if (truncated) {  // more initial entries exist than were ordered: host budget bug
                 err = kErrSortBudget;
                 break;
             }
@@ -966,21 +1118,19 @@ __global__ __launch_bounds__(64, 4) void greedy_wave_kernel(StreamState *__restr
                 unsigned long long other = __shfl_xor(best, d, 64);
                 best = other < best ? other : best;
             }
-            uint32_t bk = (uint32_t)(best >> 32);
+            const uint32_t bk = (uint32_t)IIV_SGPR((uint32_t)(best >> 32));
+            const uint32_t bi = (uint32_t)IIV_SGPR((uint32_t)best);
             if (bk == INF) {
                 exhausted = 1;  // video.py:189
                 continue;
             }
-            if (lane == 0) S.pushed[(uint32_t)best] = INF;
+            if (lane == 0) S.pushed[bi] = INF;
             __builtin_amdgcn_s_waitcnt(0x0F70);  // that store precedes the next scan of pushed[]
 #pragma unroll
-            for (int m = 0; m < M; m++) {
-                ent[m] = 0;
-                pos[m] = 0;
-            }
+            for (int m = 0; m < M; m++) ent[m] = 0;
             // pushed keys do not carry the content byte: it is the target byte of that offset
-            uint32_t loc = bk & 0x1fffu;
-            uint32_t c = (MODE == kDHGR && is_aux ? frames_aux : frames_main)[((size_t)blockIdx.x * n_frames + frame) * 8192 + loc];
+            const uint32_t loc = bk & 0x1fffu;
+            const uint32_t c = (uint32_t)IIV_SGPR(tgt_frames[loc]);
             ent[0] = loc | (c << 16);
             cnt = 1;
         }
@@ -990,16 +1140,16 @@ __global__ __launch_bounds__(64, 4) void greedy_wave_kernel(StreamState *__restr
         // retire each slot's loads before issuing the next slot's.
         uint4 wdv[M];
 #pragma unroll
-        for (int m = 0; m < M; m++)
-            wdv[m] = reinterpret_cast<const uint4 *>(S.wd + ((ent[m] >> 8) & 31) * 256)[lane];
+        for (int m = 0; m < M; m++) wdv[m] = wd_rows[((ent[m] >> 8) & 31) * 64 + lane];
         uint32_t ndv[M][4];
 #pragma unroll
         for (int m = 0; m < M; m++) {
             const size_t cbase = (size_t)((ent[m] >> 16) & ((1u << CB) - 1)) << BITS;
-            ndv[m][0] = store_e[cbase + (wdv[m].x & 0xffffu)];
-            ndv[m][1] = store_d[cbase + (wdv[m].y & 0xffffu)];
-            ndv[m][2] = store_e[cbase + (wdv[m].z & 0xffffu)];
-            ndv[m][3] = store_d[cbase + (wdv[m].w & 0xffffu)];
+            const uint16_t *se = store_e + cbase, *sd = store_d + cbase;
+            ndv[m][0] = se[wdv[m].x & 0xffffu];
+            ndv[m][1] = sd[wdv[m].y & 0xffffu];
+            ndv[m][2] = se[wdv[m].z & 0xffffu];
+            ndv[m][3] = sd[wdv[m].w & 0xffffu];
         }
         // vmcnt is one in-order counter for loads AND stores: retire the gathers once, here,
         // before the steps below start issuing stores.
@@ -1015,53 +1165,80 @@ __global__ __launch_bounds__(64, 4) void greedy_wave_kernel(StreamState *__restr
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- process the chunk
+        bool tie = false;
+        uint32_t tie_ent = 0;
 #pragma unroll
         for (int m = 0; m < M; m++) {
             if (m >= cnt || done >= n_ops || err) break;
             const int p = (ent[m] >> 8) & 31, x = ent[m] & 255;
             const uint32_t c = (ent[m] >> 16) & 0xffu;  // video.py:134
-            // video.py:130 -- skip a byte whose priority was cleared since the chunk was formed
-            const uint32_t xw = __builtin_amdgcn_readfirstlane(nz[p * 8 + (x >> 5)]);
-            if (!((xw >> (x & 31)) & 1u)) {
-                if (!from_pushed) head = pos[m] + 1;
+            int kt[4], ke[4], C;
+            if (!score(wdv[m], ndv[m], p, x, kt, ke, C, nullptr)) {
+                if (!from_pushed) head = chunk_head + (int)(ent[m] >> 24) + 1;
                 continue;
             }
             if (MODE == kDHGR && c >= 0x80) {  // video.py:137
                 err = kErrPaletteBit;
                 break;
             }
-            const uint32_t nz4 = (nz[p * 8 + (lane >> 3)] >> bshift) & 0xfu;
-            const uint32_t pd4 = (pdone[p * 8 + (lane >> 3)] >> bshift) & 0xfu;
-            const uint32_t wdr[4] = {wdv[m].x, wdv[m].y, wdv[m].z, wdv[m].w};
-            int d[4];
-            bool cand[4], nzy[4];
-            unsigned long long bal[4];
-            int below = 0, C = 0;
+            // two smallest eligible keys: in the lane, then across the wave
+            const int a0 = ke[0] < ke[1] ? ke[0] : ke[1], b0 = ke[0] < ke[1] ? ke[1] : ke[0];
+            const int a1 = ke[2] < ke[3] ? ke[2] : ke[3], b1 = ke[2] < ke[3] ? ke[3] : ke[2];
+            const int k1 = a0 < a1 ? a0 : a1, hi01 = a0 < a1 ? a1 : a0, mb = b0 < b1 ? b0 : b1;
+            const int k2 = hi01 < mb ? hi01 : mb;
+            const int K1 = wave_min_i32(k1);
+            int y1 = -1, y2 = -1;
+            uint32_t nd1 = 0, nd2 = 0;
+            if (K1 < 0) {
+                y1 = K1 & 255;
+                const int K2 = wave_min_i32(k1 == K1 ? k2 : k1);
+                if (K2 < 0) {
+                    y2 = K2 & 255;
+                    if ((K1 >> 16) == (K2 >> 16)) {
+                        tie = true;
+                    } else {
+                        // does a third eligible byte share the second delta?
+                        const uint32_t D2 = (uint32_t)K2 >> 16;
+                        int n2 = 0;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int y = 4 * lane + r;
-                const bool gone = ((pd4 >> r) & 1u) || (y == x);          // video.py:141
-                const uint32_t dwy = gone ? 0u : (wdr[r] >> 16);
-                nzy[r] = ((nz4 >> r) & 1u) && (y != x);                   // video.py:140
-                d[r] = (int)ndv[m][r] - (int)dwy;                         // screen.py:547
-                cand[r] = d[r] < 0;                                       // video.py:283
-                bal[r] = __ballot(cand[r]);
-                below += prefix_popc(bal[r]);
-                C += (int)__popcll(bal[r]);
+                        for (int r = 0; r < 4; r++) n2 += (int)__popcll(__ballot(((uint32_t)ke[r] >> 16) == D2));
+                        tie = n2 > 1;
+                    }
+                    if (tie) {  // the nonces decide: re-score this entry the long way, below
+                        tie_ent = ent[m];
+                        break;
+                    }
+                    nd2 = nd_of(ndv[m], y2);
+                }
+                nd1 = nd_of(ndv[m], y1);
             }
+            if (!apply(p, x, c, y1, nd1, y2, nd2, C)) {
+                err = kErrPushedOverflow;
+                break;
+            }
+            if (!from_pushed) head = chunk_head + (int)(ent[m] >> 24) + 1;
+        }
+
+        if (tie) {
+            // ---- slow form of one step: the reference's (delta, nonce, offset) heap order
+            const int p = (tie_ent >> 8) & 31, x = tie_ent & 255;
+            const uint32_t c = (tie_ent >> 16) & 0xffu;
+            const uint4 w = wd_rows[p * 64 + lane];
+            const size_t cbase = (size_t)(c & ((1u << CB) - 1)) << BITS;
+            const uint16_t *se = store_e + cbase, *sd = store_d + cbase;
+            const uint32_t nd[4] = {se[w.x & 0xffffu], sd[w.y & 0xffffu], se[w.z & 0xffffu], sd[w.w & 0xffffu]};
+            int kt[4], ke[4], C, below;
+            score(w, nd, p, x, kt, ke, C, &below);  // the entry was live a moment ago: still is
             // one random.getrandbits(8) per candidate in ascending offset (video.py:290-293)
-            // (branch-free: every lane reads a nonce slot for each of its bytes; only
-            // candidates keep it, and only candidates advance the running index)
             uint32_t key[4];
             int run = mt_idx + cb * 624 + below;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                int fj = run >= 1248 ? run - 1248 : run;
-                run += cand[r] ? 1 : 0;
-                uint32_t nonce = mt_temper(mt[fj]) >> 24;
-                uint32_t k = ((uint32_t)(d[r] + 2048) << 17) | (nonce << 9) | ((uint32_t)(4 * lane + r) << 1) |
-                             (ndv[m][r] != 0 ? 1u : 0u);
-                key[r] = (cand[r] && nzy[r]) ? k : INF;  // video.py:159
+                const int fj = run >= 1248 ? run - 1248 : run;
+                run += kt[r] < 0 ? 1 : 0;
+                const uint32_t nonce = mt_temper(mt[fj]) >> 24;
+                const uint32_t k = ((uint32_t)((ke[r] >> 16) + 2048) << 16) | (nonce << 8) | (uint32_t)(y0 + r);
+                key[r] = ke[r] < 0 ? k : INF;  // video.py:159
             }
             // two smallest (delta, nonce, offset): lane, row of 16 (DPP), wave (readlane)
             uint32_t a0 = key[0] < key[1] ? key[0] : key[1], b0 = key[0] < key[1] ? key[1] : key[0];
@@ -1082,67 +1259,15 @@ __global__ __launch_bounds__(64, 4) void greedy_wave_kernel(StreamState *__restr
                 K1 = lo;
                 K2 = hi < m2 ? hi : m2;
             }
-            const int y1 = K1 != INF ? (int)((K1 >> 1) & 255) : -1;
-            const int f1 = K1 != INF ? (int)(K1 & 1) : 0;
-            const int y2 = K2 != INF ? (int)((K2 >> 1) & 255) : -1;
-            const int f2 = K2 != INF ? (int)(K2 & 1) : 0;
-            if (n_pushed + f1 + f2 > kPushedCap) {
+            const int y1 = K1 != INF ? (int)(K1 & 255) : -1;
+            const int y2 = K2 != INF ? (int)(K2 & 255) : -1;
+            const uint32_t nd1 = y1 >= 0 ? nd_of(nd, y1) : 0u, nd2 = y2 >= 0 ? nd_of(nd, y2) : 0u;
+            if (!apply(p, x, c, y1, nd1, y2, nd2, C)) {
                 err = kErrPushedOverflow;
                 break;
             }
-
-            // ---- apply (video.py:140-144, 170-178; screen.py:256-293)
-            if (lane < 8) {
-                // lane w owns word w of page p in both bitmaps
-                uint32_t clr = 0, setp = 0;
-                if ((x >> 5) == lane) {
-                    clr |= 1u << (x & 31);
-                    setp |= 1u << (x & 31);
-                }
-                if (y1 >= 0 && !f1 && (y1 >> 5) == lane) clr |= 1u << (y1 & 31);
-                if (y2 >= 0 && !f2 && (y2 >> 5) == lane) clr |= 1u << (y2 & 31);
-                if (clr) nz[p * 8 + lane] &= ~clr;
-                if (setp) pdone[p * 8 + lane] |= setp;
-            }
-            if (lane == 0) {
-                S.up[is_aux][p * 256 + x] = 0;
-                S.mem[is_aux][p * 256 + x] = (uint8_t)c;
-                uint8_t *q = out + (size_t)done * 6;
-                q[0] = (uint8_t)(p + 32);
-                q[1] = (uint8_t)c;
-                q[2] = (uint8_t)x;
-                q[3] = (uint8_t)(y1 >= 0 ? y1 : x);  // video.py:185-186
-                q[4] = (uint8_t)(y2 >= 0 ? y2 : x);
-                q[5] = (uint8_t)x;
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < 2; s2++) {
-                const int ys = s2 ? y2 : y1;
-                if (ys >= 0 && (ys >> 2) == lane) {
-                    const int r = ys & 3;
-                    const uint32_t nd = r == 0 ? ndv[m][0] : r == 1 ? ndv[m][1] : r == 2 ? ndv[m][2] : ndv[m][3];
-                    S.up[is_aux][p * 256 + ys] = (int32_t)nd;  // byte_pair_difference == nd (screen.py:383-398)
-                    S.mem[is_aux][p * 256 + ys] = (uint8_t)c;
-                    if (nd) {
-                        int j = mt_idx + cb * 624 + C + (s2 ? f1 : 0);
-                        if (j >= 1248) j -= 1248;
-                        uint32_t nonce = mt_temper(mt[j]) >> 24;  // video.py:178
-                        S.pushed[n_pushed + (s2 ? f1 : 0)] =
-                            ((2047u - nd) << 21) | (nonce << 13) | ((uint32_t)p << 8) | (uint32_t)ys;
-                    }
-                }
-            }
-            mt_idx += C + f1 + f2;
-            draws += (unsigned long long)(C + f1 + f2);
-            n_pushed += f1 + f2;
-            done++;
-            if (!from_pushed) head = pos[m] + 1;
-            if (mt_idx >= 624) {
-                __syncthreads();
-                mt_twist<64>(mt + 624 * (cb ^ 1), mt + 624 * cb, lane);
-                cb ^= 1;
-                mt_idx -= 624;
-            }
+            if (!from_pushed) head = chunk_head + (int)(tie_ent >> 24) + 1;
+            continue;  // the rest of the chunk is formed again from `head`
         }
         if (!from_pushed && !err && done < n_ops) head = chunk_end > head ? chunk_end : head;
     }
