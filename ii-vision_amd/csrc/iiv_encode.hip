@@ -913,12 +913,34 @@ __device__ static inline void mt_twist_wave(const uint32_t *src, uint32_t *dst, 
     __syncthreads();
 }
 
-template <int MODE>
+// The store table as the wave kernel reads it when every value fits 10 bits (DHGR):
+// three values per 32-bit word, [offset][content][kP10Words], value t of a slice in
+// word t / 3 at bit 10 * (t % 3).  A slice is 86 cache lines instead of 128, so the
+// half of the table one launch uses (two of the four byte offsets) is 2.7 MiB and
+// stays in the 4 MiB L2 of an XCD next to the streams' own state; 64 random lookups
+// also fall into fewer distinct lines.  Built once per encoder from the u16 table.
+constexpr int kP10Words = 2731;  // ceil(8192 / 3)
+
+__global__ void pack10_kernel(const uint16_t *__restrict__ store, uint32_t *__restrict__ out, int n_slices,
+                              int slice_len, uint32_t *__restrict__ d_max)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x, slice = blockIdx.y;
+    if (q >= kP10Words || slice >= n_slices) return;
+    const uint16_t *src = store + (size_t)slice * slice_len;
+    uint32_t v[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) v[r] = 3 * q + r < slice_len ? src[3 * q + r] : 0u;
+    out[(size_t)slice * kP10Words + q] = (v[0] & 1023u) | ((v[1] & 1023u) << 10) | ((v[2] & 1023u) << 20);
+    const uint32_t mx = max(v[0], max(v[1], v[2]));
+    if (mx >= 1024u) atomicMax(d_max, mx);
+}
+
+template <int MODE, bool P10>
 __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamState *__restrict__ states,
                                                          const uint8_t *__restrict__ frames_main,
                                                          const uint8_t *__restrict__ frames_aux, int n_frames,
                                                          int frame, int is_aux, int n_ops,
-                                                         const uint16_t *__restrict__ store,
+                                                         const void *__restrict__ store_any,
                                                          uint8_t *__restrict__ ops_out, size_t ops_stride,
                                                          size_t ops_base)
 {
@@ -964,8 +986,10 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
     int head = IIV_SGPR(S.head), n_pushed = IIV_SGPR(S.n_pushed), exhausted = IIV_SGPR(S.exhausted);
     int done = 0, err = 0;
     unsigned long long draws = 0, pad_ops = 0;
-    const uint16_t *store_e = store + ((size_t)byte_offset<MODE>(0, is_aux) << (CB + BITS));
-    const uint16_t *store_d = store + ((size_t)byte_offset<MODE>(1, is_aux) << (CB + BITS));
+    // slices of the even / odd page bytes of this bank, in 16-bit units
+    constexpr size_t SLICE = P10 ? 2 * (size_t)kP10Words : (size_t)1 << BITS;
+    const uint16_t *store_e = (const uint16_t *)store_any + ((size_t)byte_offset<MODE>(0, is_aux) << CB) * SLICE;
+    const uint16_t *store_d = (const uint16_t *)store_any + ((size_t)byte_offset<MODE>(1, is_aux) << CB) * SLICE;
     const uint8_t *tgt_frames = (MODE == kDHGR && is_aux ? frames_aux : frames_main) +
                                 ((size_t)blockIdx.x * n_frames + frame) * 8192;
     const uint4 *wd_rows = reinterpret_cast<const uint4 *>(S.wd);
@@ -975,6 +999,37 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
     const int wsel = lane >> 3;          // this lane's word inside a page's 8 bitmap words
     const int sh0 = (4 * lane) & 31;     // its 4 bits inside that word
     const int y0 = 4 * lane;
+
+    // issue the four store-table loads of one entry (content c, row w); P10: the low
+    // half of each row word (the window, not needed any more) is replaced by the bit
+    // position of the value inside the loaded word
+    auto gather4 = [&](uint4 &w, uint32_t c, uint32_t (&nd)[4]) {
+        const size_t cbase = (size_t)(c & ((1u << CB) - 1)) * SLICE;
+        const uint16_t *se = store_e + cbase, *sd = store_d + cbase;
+        if (P10) {
+            uint32_t *wr[4] = {&w.x, &w.y, &w.z, &w.w};
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t t = *wr[r] & 0xffffu;
+                const uint32_t q = (t * 43691u) >> 17;  // t / 3 for t < 2^16
+                nd[r] = reinterpret_cast<const uint32_t *>(r & 1 ? sd : se)[q];
+                *wr[r] = (*wr[r] & HI) | ((t - 3u * q) * 10u);
+            }
+        } else {
+            nd[0] = se[w.x & 0xffffu];
+            nd[1] = sd[w.y & 0xffffu];
+            nd[2] = se[w.z & 0xffffu];
+            nd[3] = sd[w.w & 0xffffu];
+        }
+    };
+    auto finish4 = [&](const uint4 &w, uint32_t (&nd)[4]) {
+        if (P10) {
+            nd[0] = __builtin_amdgcn_ubfe(nd[0], w.x, 10);  // v_bfe_u32 takes the offset from bits 4:0
+            nd[1] = __builtin_amdgcn_ubfe(nd[1], w.y, 10);
+            nd[2] = __builtin_amdgcn_ubfe(nd[2], w.z, 10);
+            nd[3] = __builtin_amdgcn_ubfe(nd[3], w.w, 10);
+        }
+    };
 
     // per-byte keys of entry (p, x) from its wd row and store-table values:
     //   kt[r] = delta << 16 | y   with the reference's diff weight (0 for primaries, video.py:141)
@@ -1143,14 +1198,7 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         for (int m = 0; m < M; m++) wdv[m] = wd_rows[((ent[m] >> 8) & 31) * 64 + lane];
         uint32_t ndv[M][4];
 #pragma unroll
-        for (int m = 0; m < M; m++) {
-            const size_t cbase = (size_t)((ent[m] >> 16) & ((1u << CB) - 1)) << BITS;
-            const uint16_t *se = store_e + cbase, *sd = store_d + cbase;
-            ndv[m][0] = se[wdv[m].x & 0xffffu];
-            ndv[m][1] = sd[wdv[m].y & 0xffffu];
-            ndv[m][2] = se[wdv[m].z & 0xffffu];
-            ndv[m][3] = sd[wdv[m].w & 0xffffu];
-        }
+        for (int m = 0; m < M; m++) gather4(wdv[m], ent[m] >> 16, ndv[m]);
         // vmcnt is one in-order counter for loads AND stores: retire the gathers once, here,
         // before the steps below start issuing stores.
         // (hipcc does not track a builtin s_waitcnt in its scoreboard, so the loaded
@@ -1163,6 +1211,8 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
             asm volatile("" : "+v"(ndv[m][0]), "+v"(ndv[m][1]), "+v"(ndv[m][2]), "+v"(ndv[m][3]));
         }
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < M; m++) finish4(wdv[m], ndv[m]);
 
         // ---- process the chunk
         bool tie = false;
@@ -1223,10 +1273,10 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
             // ---- slow form of one step: the reference's (delta, nonce, offset) heap order
             const int p = (tie_ent >> 8) & 31, x = tie_ent & 255;
             const uint32_t c = (tie_ent >> 16) & 0xffu;
-            const uint4 w = wd_rows[p * 64 + lane];
-            const size_t cbase = (size_t)(c & ((1u << CB) - 1)) << BITS;
-            const uint16_t *se = store_e + cbase, *sd = store_d + cbase;
-            const uint32_t nd[4] = {se[w.x & 0xffffu], sd[w.y & 0xffffu], se[w.z & 0xffffu], sd[w.w & 0xffffu]};
+            uint4 w = wd_rows[p * 64 + lane];
+            uint32_t nd[4];
+            gather4(w, c, nd);
+            finish4(w, nd);
             int kt[4], ke[4], C, below;
             score(w, nd, p, x, kt, ke, C, &below);  // the entry was live a moment ago: still is
             // one random.getrandbits(8) per candidate in ascending offset (video.py:290-293)
@@ -1300,6 +1350,7 @@ struct Encoder {
     int n_streams;
     const uint16_t *d_table;
     const uint16_t *d_store;
+    uint32_t *d_store10;    // DHGR: d_store repacked 3 x 10 bit (see pack10_kernel); null if a value needs more
     ulonglong2 *d_strings;  // colour string of every masked value (recurrence mode)
     uint16_t *d_sub;        // 16x16 substitute costs
     int dw_mode;            // IIV_DW_TABLE / IIV_DW_RECURRENCE
@@ -1356,6 +1407,7 @@ int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, c
     e->n_streams = n_streams;
     e->d_table = d_table;
     e->d_store = d_store;
+    e->d_store10 = nullptr;
     e->d_states = nullptr;
     e->d_snapshot = nullptr;
     e->d_strings = nullptr;
@@ -1380,6 +1432,25 @@ int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, c
             (void)hipFree(e->d_states);
             delete e;
             return rc;
+        }
+    }
+    if (mode == kDHGR) {
+        // 10-bit repack of the store table for the wave kernel; kept only if lossless
+        const int n_slices = 4 << ModeTraits<kDHGR>::kContentBits, slice_len = 1 << ModeTraits<kDHGR>::kBits;
+        uint32_t *d_max = nullptr, h_max = 0;
+        bool ok = hipDeviceSynchronize() == hipSuccess &&  // d_store may have been built on any stream
+                  hipMalloc(&e->d_store10, (size_t)n_slices * kP10Words * 4) == hipSuccess &&
+                  hipMalloc(&d_max, 4) == hipSuccess && hipMemset(d_max, 0, 4) == hipSuccess;
+        if (ok) {
+            hipLaunchKernelGGL(pack10_kernel, dim3((kP10Words + 255) / 256, n_slices), dim3(256), 0, 0, d_store,
+                               e->d_store10, n_slices, slice_len, d_max);
+            ok = hipMemcpy(&h_max, d_max, 4, hipMemcpyDeviceToHost) == hipSuccess && h_max < 1024u;
+        }
+        if (d_max) (void)hipFree(d_max);
+        if (!ok) {
+            (void)hipGetLastError();
+            if (e->d_store10) (void)hipFree(e->d_store10);
+            e->d_store10 = nullptr;
         }
     }
     // Video.__init__ (video.py:21-62): blank screen, zero priorities.  RNG
@@ -1411,6 +1482,7 @@ void encoder_destroy(Encoder *e)
     if (e->d_snapshot) (void)hipFree(e->d_snapshot);
     if (e->d_strings) (void)hipFree(e->d_strings);
     if (e->d_sub) (void)hipFree(e->d_sub);
+    if (e->d_store10) (void)hipFree(e->d_store10);
     delete e;
 }
 
@@ -1663,17 +1735,19 @@ int encode(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux, int n_frames
         e->gen_is_aux = g.is_aux;
         e->gen_frame = g.frame;
         if (e->profiling) { int prc = prof_begin(e, 1, st, slot); if (prc) return prc; }
-#define IIV_GREEDY(K, T)                                                                                        \
+#define IIV_GREEDY(K, T, STORE)                                                                                 \
     hipLaunchKernelGGL(K, dim3(e->n_streams), dim3(T), 0, st, e->d_states, d_main, d_aux, n_frames, g.frame,       \
-                       g.is_aux, g.n_ops, e->d_store, d_ops, stride, done * 6)
+                       g.is_aux, g.n_ops, STORE, d_ops, stride, done * 6)
         // few streams: the 4-wave workgroup has the shorter dependent chain per opcode;
         // many streams: the one-wave kernel keeps 16 streams resident per CU instead of 4
         const bool use_wave = e->greedy_mode == IIV_GREEDY_WAVE ||
                               (e->greedy_mode == IIV_GREEDY_AUTO && e->n_streams >= 1536);
         if (use_wave) {
-            if (e->mode == kDHGR) IIV_GREEDY(greedy_wave_kernel<kDHGR>, 64); else IIV_GREEDY(greedy_wave_kernel<kHGR>, 64);
+            if (e->mode == kDHGR && e->d_store10) IIV_GREEDY((greedy_wave_kernel<kDHGR, true>), 64, (const void *)e->d_store10);
+            else if (e->mode == kDHGR) IIV_GREEDY((greedy_wave_kernel<kDHGR, false>), 64, (const void *)e->d_store);
+            else IIV_GREEDY((greedy_wave_kernel<kHGR, false>), 64, (const void *)e->d_store);
         } else {
-            if (e->mode == kDHGR) IIV_GREEDY(greedy_kernel<kDHGR>, 256); else IIV_GREEDY(greedy_kernel<kHGR>, 256);
+            if (e->mode == kDHGR) IIV_GREEDY(greedy_kernel<kDHGR>, 256, e->d_store); else IIV_GREEDY(greedy_kernel<kHGR>, 256, e->d_store);
         }
 #undef IIV_GREEDY
         IIV_HIP(hipGetLastError());
