@@ -60,6 +60,41 @@ struct StreamState {
 
 enum { kErrNone = 0, kErrHoles = 1, kErrNegative = 2, kErrPaletteBit = 3, kErrPushedOverflow = 4, kErrNoGenerator = 5, kErrGuard = 6, kErrSortBudget = 7 };
 
+// LDS accesses of one wave execute in order: making one lane's LDS writes visible to the
+// other lanes of the same wave needs no s_barrier, only that the compiler keeps the order.
+__device__ static inline void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// next MT19937 block, one wave, fully unrolled (constant LDS offsets, no loop counters)
+__device__ static inline void mt_twist_wave(const uint32_t *src, uint32_t *dst, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = lane + 64 * k;
+        if (k < 3 || i < 227) dst[i] = src[i + 397] ^ mt_mix(src[i], src[i + 1]);
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = 227 + lane + 64 * k;
+        if (k < 3 || i < 454) dst[i] = dst[i - 227] ^ mt_mix(src[i], src[i + 1]);
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int i = 454 + lane + 64 * k;
+        if (k < 2 || i < 624) {
+            const uint32_t nx = (i == 623) ? dst[0] : src[i + 1];
+            dst[i] = dst[i - 227] ^ mt_mix(src[i], nx);
+        }
+    }
+    wave_lds_sync();
+}
+
 // ------------------------------------------------------------------------- prologue
 
 constexpr int kProThreads = 1024;
@@ -195,8 +230,11 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
     uint8_t(*cur)[8192] = reinterpret_cast<uint8_t(*)[8192]>(smem);
     uint8_t(*tgt)[8192] = reinterpret_cast<uint8_t(*)[8192]>(smem + NB * 8192);
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);
-    __shared__ uint8_t nonce[8192];
-    __shared__ uint32_t mtb[2][624];
+    // np.random's MT19937 blocks 1..13 -- every block the <= 7680 draws of this call can reach --
+    // are generated above cur | tgt by the last wave while the other waves score
+    uint32_t *gen = reinterpret_cast<uint32_t *>(smem + 2 * NB * 8192);
+    __shared__ uint32_t aux4k[1024];  // DHGR colour-string LUTs, then histogram, then bucket cursors
+    __shared__ uint32_t mtb[2][624];  // [0] = the stream's current block; later the bucket starts
     __shared__ uint16_t lut[256];
     __shared__ uint32_t wsum[kProThreads / 64];
     __shared__ int flag_bad;
@@ -206,6 +244,7 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
     const size_t fbase = ((size_t)blockIdx.x * n_frames + frame) * 8192;
 
     IIV_STAMP(0);
+    const int first = S.mt_np_idx;  // (read before the first barrier: thread 0 updates it later)
     if (tid == 0) flag_bad = 0;
     // stage current screen and target memory maps (16 B per lane per load)
     for (int i = tid; i < 512 * NB; i += kProThreads) {
@@ -216,7 +255,30 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
     }
     for (int i = tid; i < 624; i += kProThreads) mtb[0][i] = S.mt_np[i];
     if (DP) load_cost_lut(lut, sub, tid);
+    // DHGR colour strings from three LDS lookups instead of ten rotates: pixels 0..3
+    // depend on dots 0..6, pixels 4..6 on dots 4..9, pixels 7..9 on dots 7..12
+    // (colours.py:100-134).  slut[odd][0..127 | 128..191 | 192..255].
+    uint16_t *slut = reinterpret_cast<uint16_t *>(aux4k);
+    if (DP && MODE == kDHGR && tid < 512) {
+        const int odd = tid >> 8, e = tid & 255;
+        const int ph = phase_of(kDHGR, byte_offset<kDHGR>(odd, is_aux));
+        const int k0 = e < 128 ? 0 : e < 192 ? 4 : 7, nk = e < 128 ? 4 : 3;
+        const uint32_t v = e < 128 ? e : (e - 128) & 63;
+        uint32_t out = 0;
+        for (int k = 0; k < nk; k++) {
+            const uint32_t win = (v >> k) & 0xf;
+            out |= (((win | (win << 4)) >> (4 - ((ph + k0 + k) & 3))) & 0xf) << (4 * k);
+        }
+        slut[tid] = (uint16_t)out;
+    }
     __syncthreads();
+    if (tid >= kProThreads - 64) {
+        const uint32_t *src = mtb[0];
+        for (int k = 0; k < 13; k++) {
+            mt_twist_wave(src, gen + k * 624, tid & 63);
+            src = gen + k * 624;
+        }
+    }
 
     IIV_STAMP(1);
     const int tgt_first = tgt[(MODE == kDHGR && is_aux) ? 1 : 0][0];
@@ -259,13 +321,13 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
             dwv[j] = 0;
             if (cm != tm) {
                 if (MODE == kDHGR) {
-                    // DHGR windows are already dot strings (screen.py:983-990): ten rotates are
-                    // cheaper than two dependent L2 loads
-                    uint64_t alo, blo;
-                    uint32_t ahi, bhi;
-                    colour_string<MODE>(cm, o, alo, ahi);
-                    colour_string<MODE>(tm, o, blo, bhi);
-                    dwv[j] = edit_distance<ModeTraits<MODE>::kDots>(alo, ahi, blo, bhi, lut);
+                    // DHGR windows are already dot strings (screen.py:983-990)
+                    const uint16_t *sl = slut + 256 * odd;
+                    const uint64_t alo = (uint64_t)sl[cm & 127] | ((uint64_t)sl[128 + ((cm >> 4) & 63)] << 16) |
+                                         ((uint64_t)sl[192 + (cm >> 7)] << 28);
+                    const uint64_t blo = (uint64_t)sl[tm & 127] | ((uint64_t)sl[128 + ((tm >> 4) & 63)] << 16) |
+                                         ((uint64_t)sl[192 + (tm >> 7)] << 28);
+                    dwv[j] = edit_distance<ModeTraits<MODE>::kDots>(alo, 0u, blo, 0u, lut);
                 } else {
                     const ulonglong2 *Sg = strings + ((size_t)o << BITS);
                     ulonglong2 a = Sg[cm], b = Sg[tm];
@@ -315,7 +377,7 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
     // secondaries resolved to zero per opcode), so when the host knows B (`need` = 3B)
     // only the buckets holding the `need` highest priorities are ordered at all (every
     // entry of the boundary bucket is kept: a superset of the true top-`need`).
-    uint32_t *hist = reinterpret_cast<uint32_t *>(nonce);  // 4 KiB of the (not yet used) nonce buffer
+    uint32_t *hist = aux4k;  // the string LUTs are dead by now
     int sh;
     {
         int mx = 0;
@@ -361,38 +423,21 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
 #pragma unroll
     for (int j = 0; j < 8; j++)
         if ((nzmask & (1u << j)) && (upv[j] >> sh) >= first_bucket) selmask |= 1u << j;
-    __syncthreads();  // hist (aliasing nonce[]) is dead from here on; big_bucket is final
+    __syncthreads();  // hist is dead from here on; big_bucket is final
     const bool by_buckets = big_bucket == 0;
 
     IIV_STAMP(3);
-    // n draws of np.random.randint(0, 256): low byte of the next n MT outputs (video.py:265)
-    int idx = S.mt_np_idx;
+    // n draws of np.random.randint(0, 256): low byte of the next n MT outputs (video.py:265).
+    // Draw r is output first + r of the block sequence (block 0 = mtb[0], block k = gen[k - 1]);
+    // the stream is left in the block holding the last draw.
     {
-        int cb = 0;
-        int first = idx;             // position of draw 0 inside block 0
-        int remaining = n;
-        int blk = 0;
-        while (true) {
-            // draws that live in block `blk`: global positions [blk*624, blk*624+624)
-            for (int w = tid; w < 624; w += kProThreads) {
-                int r = blk * 624 + w - first;
-                if (r >= 0 && r < n) nonce[r] = (uint8_t)(mt_temper(mtb[cb][w]) & 0xff);
-            }
-            int last_needed = first + n;  // one past the last global position
-            if (last_needed <= (blk + 1) * 624) break;
-            mt_twist<kProThreads>(mtb[cb], mtb[cb ^ 1], tid);
-            cb ^= 1;
-            blk++;
-        }
-        (void)remaining;
-        __syncthreads();
-        // persist the generator: block `cb` with index (first + n) - blk*624 in [0,624]
-        for (int w = tid; w < 624; w += kProThreads) S.mt_np[w] = mtb[cb][w];
+        const int blk = first + n > 0 ? (first + n - 1) / 624 : 0;
+        const uint32_t *fin = blk ? gen + (blk - 1) * 624 : mtb[0];
+        for (int w = tid; w < 624; w += kProThreads) S.mt_np[w] = fin[w];
         if (tid == 0) {
             S.mt_np_idx = first + n - blk * 624;
             S.draws_np += (unsigned long long)n;
         }
-        __syncthreads();  // mtb is reused below
     }
 
     IIV_STAMP(4);
@@ -400,18 +445,23 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
     // whose priority is zero (or that were not selected) get the all-ones key and sink
     unsigned long long kv[8];
     {
-        int r = rank0;
+        int bk = (first + rank0) / 624, bw = first + rank0 - bk * 624;  // block / word of this thread's next draw
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             kv[j] = ~0ull;
             if (nzmask & (1u << j)) {
                 // the content byte rides in the low bits (offsets are unique, so it never
                 // takes part in the ordering)
-                if (selmask & (1u << j))
+                if (selmask & (1u << j)) {
+                    const uint32_t nonce = mt_temper((bk ? gen + (bk - 1) * 624 : mtb[0])[bw]) & 0xffu;
                     kv[j] = ((unsigned long long)(0x7fffffffu - (uint32_t)upv[j]) << 29) |
-                            ((unsigned long long)nonce[r] << 21) | ((unsigned long long)(i0 + j) << 8) |
+                            ((unsigned long long)nonce << 21) | ((unsigned long long)(i0 + j) << 8) |
                             (unsigned long long)((cpk[j >> 2] >> (8 * (j & 3))) & 0xffu);
-                r++;
+                }
+                if (++bw == 624) {
+                    bw = 0;
+                    bk++;
+                }
             }
         }
     }
@@ -419,7 +469,7 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
     if (by_buckets) {
         // counting sort: scatter every selected key into its bucket's slot range, then
         // rank it among the (few) keys of the same bucket
-        uint32_t *cursor = reinterpret_cast<uint32_t *>(nonce);   // nonces now live in the keys
+        uint32_t *cursor = aux4k;                                 // histogram is dead
         uint32_t *start = reinterpret_cast<uint32_t *>(mtb);      // MT state is back in HBM
         __syncthreads();
         cursor[1023 - tid] = (uint32_t)bstart;
@@ -457,6 +507,7 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
         }
     } else if (n_sel <= 4 * kProThreads && n_sel < n) {
         // degenerate buckets, prefix selection still small: compact + bitonic
+        __syncthreads();  // every key is built: the MT blocks under keys[] are dead
         int tot;
         int nsel_mine = 0;
 #pragma unroll
@@ -482,6 +533,7 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
         }
     } else {
         // order everything with the bitonic network (keys not selected sink to the end)
+        __syncthreads();  // every key is built: the MT blocks under keys[] are dead
         bitonic_sort<8, kProThreads>(kv, keys, tid);
         write_order<8>(S.order, kv, tid);  // entries >= n_sel are never read
     }
@@ -850,7 +902,7 @@ __global__ __launch_bounds__(256) void greedy_kernel(StreamState *__restrict__ s
 #define IIV_WAVE_OCC 5     // waves per SIMD the register allocation is held to
 #endif
 #ifndef IIV_WAVE_CHUNK
-#define IIV_WAVE_CHUNK 4   // list entries whose rows and store-table values are fetched together
+#define IIV_WAVE_CHUNK 2   // list entries whose rows and store-table values are fetched together
 #endif
 
 template <int CTRL> __device__ static inline uint32_t dpp_u32(uint32_t v)
@@ -885,32 +937,6 @@ __device__ static inline int wave_min_i32(int v)
     v = min_dpp<0x142>(v);  // row_bcast:15
     v = min_dpp<0x143>(v);  // row_bcast:31: lane 63 holds the wave's
     return __builtin_amdgcn_readlane(v, 63);
-}
-
-// next MT19937 block, one wave, fully unrolled (constant LDS offsets, no loop counters)
-__device__ static inline void mt_twist_wave(const uint32_t *src, uint32_t *dst, int lane)
-{
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int i = lane + 64 * k;
-        if (k < 3 || i < 227) dst[i] = src[i + 397] ^ mt_mix(src[i], src[i + 1]);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int i = 227 + lane + 64 * k;
-        if (k < 3 || i < 454) dst[i] = dst[i - 227] ^ mt_mix(src[i], src[i + 1]);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int i = 454 + lane + 64 * k;
-        if (k < 2 || i < 624) {
-            const uint32_t nx = (i == 623) ? dst[0] : src[i + 1];
-            dst[i] = dst[i - 227] ^ mt_mix(src[i], nx);
-        }
-    }
-    __syncthreads();
 }
 
 // The store table as the wave kernel reads it when every value fits 10 bits (DHGR):
@@ -1008,8 +1034,11 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         const uint16_t *se = store_e + cbase, *sd = store_d + cbase;
         if (P10) {
             uint32_t *wr[4] = {&w.x, &w.y, &w.z, &w.w};
+            // both lookups of a slice back to back: the second finds part of its lines in L1
+            constexpr int ORD[4] = {0, 2, 1, 3};
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
+            for (int k = 0; k < 4; k++) {
+                const int r = ORD[k];
                 const uint32_t t = *wr[r] & 0xffffu;
                 const uint32_t q = (t * 43691u) >> 17;  // t / 3 for t < 2^16
                 nd[r] = reinterpret_cast<const uint32_t *>(r & 1 ? sd : se)[q];
