@@ -253,8 +253,10 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
         const uint8_t *src = (b == 0 ? frames_main : frames_aux) + fbase;
         reinterpret_cast<uint4 *>(tgt[b])[k] = reinterpret_cast<const uint4 *>(src)[k];
     }
+    IIV_STAMP(10);
     for (int i = tid; i < 624; i += kProThreads) mtb[0][i] = S.mt_np[i];
     if (DP) load_cost_lut(lut, sub, tid);
+    IIV_STAMP(11);
     // DHGR colour strings from three LDS lookups instead of ten rotates: pixels 0..3
     // depend on dots 0..6, pixels 4..6 on dots 4..9, pixels 7..9 on dots 7..12
     // (colours.py:100-134).  slut[odd][0..127 | 128..191 | 192..255].
@@ -272,22 +274,16 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
         slut[tid] = (uint16_t)out;
     }
     __syncthreads();
-    if (tid >= kProThreads - 64) {
-        const uint32_t *src = mtb[0];
-        for (int k = 0; k < 13; k++) {
-            mt_twist_wave(src, gen + k * 624, tid & 63);
-            src = gen + k * 624;
-        }
-    }
-
     IIV_STAMP(1);
     const int tgt_first = tgt[(MODE == kDHGR && is_aux) ? 1 : 0][0];
+    const int own_b = (MODE == kDHGR && is_aux) ? 1 : 0;
     // 8 consecutive bytes of one page row per thread (row-major, as nonzero() walks them)
     const int i0 = tid * 8;
-    const int page = i0 >> 8;
-    const int own_b = (MODE == kDHGR && is_aux) ? 1 : 0;
-    const uint8_t *cur_own = cur[own_b] + page * 256, *cur_oth = cur[NB - 1 - own_b] + page * 256;
-    const uint8_t *tgt_own = tgt[own_b] + page * 256, *tgt_oth = tgt[NB - 1 - own_b] + page * 256;
+    // The last wave generates the MT19937 blocks instead of scoring its 512 bytes (pages 30, 31);
+    // the first 512 threads score one of those bytes each on top of their own eight and hand the
+    // diff weight over through LDS.
+    const bool mt_wave = tid >= kProThreads - 64;
+    uint16_t *dwx = reinterpret_cast<uint16_t *>(aux4k + 512);
 
     int32_t upv[8];
     {
@@ -296,48 +292,83 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
         upv[0] = a.x; upv[1] = a.y; upv[2] = a.z; upv[3] = a.w;
         upv[4] = b.x; upv[5] = b.y; upv[6] = b.z; upv[7] = b.w;
     }
-    uint32_t dwv[8], tmv[8];
-    uint32_t cpk[2] = {0, 0};  // the 8 target bytes, packed (needed again when the keys are built)
-    int bad = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        int y = (i0 & 255) + j;
-        tmv[j] = 0;
-        cpk[j >> 2] |= (uint32_t)tgt_own[y] << (8 * (j & 3));
-        if (is_hole(y)) {
-            dwv[j] = 0;  // video.py:111
-            if (cur_own[y] != 0) bad = kErrHoles;  // video.py:87
-            continue;
+    if (mt_wave) {
+        __builtin_amdgcn_s_setprio(3);  // the other waves only have to wait for this one
+        const uint32_t *src = mtb[0];
+        for (int k = 0; k < 13; k++) {
+            mt_twist_wave(src, gen + k * 624, tid & 63);
+            src = gen + k * 624;
         }
-        int odd = y & 1;
-        int o = byte_offset<MODE>(y, is_aux);
+        __builtin_amdgcn_s_setprio(0);
+    }
+    IIV_STAMP(12);
+
+    // windows of page byte (page, y) on the current screen and in the target (0, 0 for a hole)
+    auto windows = [&](int page, int y, uint32_t &cm, uint32_t &tm) {
+        const uint8_t *cur_own = cur[own_b] + page * 256, *cur_oth = cur[NB - 1 - own_b] + page * 256;
+        const uint8_t *tgt_own = tgt[own_b] + page * 256, *tgt_oth = tgt[NB - 1 - own_b] + page * 256;
         uint32_t cp, cn, tp, tn;
         neighbours<MODE>(cur_own, cur_oth, y, is_aux, cp, cn);
         neighbours<MODE>(tgt_own, tgt_oth, y, is_aux, tp, tn);
-        uint32_t cm = masked_window<MODE>(cp, cur_own[y], cn, odd);
-        uint32_t tm = masked_window<MODE>(tp, tgt_own[y], tn, odd);
-        tmv[j] = tm;
-        if (DP) {
-            dwv[j] = 0;
-            if (cm != tm) {
-                if (MODE == kDHGR) {
-                    // DHGR windows are already dot strings (screen.py:983-990)
-                    const uint16_t *sl = slut + 256 * odd;
-                    const uint64_t alo = (uint64_t)sl[cm & 127] | ((uint64_t)sl[128 + ((cm >> 4) & 63)] << 16) |
-                                         ((uint64_t)sl[192 + (cm >> 7)] << 28);
-                    const uint64_t blo = (uint64_t)sl[tm & 127] | ((uint64_t)sl[128 + ((tm >> 4) & 63)] << 16) |
-                                         ((uint64_t)sl[192 + (tm >> 7)] << 28);
-                    dwv[j] = edit_distance<ModeTraits<MODE>::kDots>(alo, 0u, blo, 0u, lut);
-                } else {
-                    const ulonglong2 *Sg = strings + ((size_t)o << BITS);
-                    ulonglong2 a = Sg[cm], b = Sg[tm];
-                    dwv[j] = edit_distance<ModeTraits<MODE>::kDots>(a.x, (uint32_t)a.y, b.x, (uint32_t)b.y, lut);
-                }
-            }
-        } else {
-            // screen.py:441-443: pair = (source << bits) + target
-            dwv[j] = table[((size_t)o << (2 * BITS)) + ((size_t)cm << BITS) + tm];
+        cm = masked_window<MODE>(cp, cur_own[y], cn, y & 1);
+        tm = masked_window<MODE>(tp, tgt_own[y], tn, y & 1);
+    };
+    // diff weight of one byte = edit distance current window -> target window (screen.py:400-449)
+    auto diff_weight = [&](uint32_t cm, uint32_t tm, int y) -> uint32_t {
+        const int odd = y & 1;
+        const int o = byte_offset<MODE>(y, is_aux);
+        if (!DP) return table[((size_t)o << (2 * BITS)) + ((size_t)cm << BITS) + tm];  // screen.py:441-443
+        if (cm == tm) return 0u;
+        if (MODE == kDHGR) {
+            // DHGR windows are already dot strings (screen.py:983-990)
+            const uint16_t *sl = slut + 256 * odd;
+            const uint64_t alo = (uint64_t)sl[cm & 127] | ((uint64_t)sl[128 + ((cm >> 4) & 63)] << 16) |
+                                 ((uint64_t)sl[192 + (cm >> 7)] << 28);
+            const uint64_t blo = (uint64_t)sl[tm & 127] | ((uint64_t)sl[128 + ((tm >> 4) & 63)] << 16) |
+                                 ((uint64_t)sl[192 + (tm >> 7)] << 28);
+            return edit_distance<ModeTraits<MODE>::kDots>(alo, 0u, blo, 0u, lut);
         }
+        const ulonglong2 *Sg = strings + ((size_t)o << BITS);
+        const ulonglong2 a = Sg[cm], b = Sg[tm];
+        return edit_distance<ModeTraits<MODE>::kDots>(a.x, (uint32_t)a.y, b.x, (uint32_t)b.y, lut);
+    };
+
+    uint32_t dwv[8], tmv[8];
+    uint32_t cpk[2] = {0, 0};  // the 8 target bytes, packed (needed again when the keys are built)
+    int bad = 0;
+    {
+        const int page = i0 >> 8;
+        const uint8_t *cur_own = cur[own_b] + page * 256, *tgt_own = tgt[own_b] + page * 256;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int y = (i0 & 255) + j;
+            tmv[j] = 0;
+            dwv[j] = 0;
+            cpk[j >> 2] |= (uint32_t)tgt_own[y] << (8 * (j & 3));
+            if (is_hole(y)) {  // video.py:111
+                if (cur_own[y] != 0) bad = kErrHoles;  // video.py:87
+                continue;
+            }
+            uint32_t cm, tm;
+            windows(page, y, cm, tm);
+            tmv[j] = tm;
+            if (!mt_wave) dwv[j] = diff_weight(cm, tm, y);
+        }
+    }
+    if (tid < 512) {
+        const int page = 30 + (tid >> 8), y = tid & 255;
+        uint32_t d = 0;
+        if (!is_hole(y)) {
+            uint32_t cm, tm;
+            windows(page, y, cm, tm);
+            d = diff_weight(cm, tm, y);
+        }
+        dwx[tid] = (uint16_t)d;
+    }
+    __syncthreads();
+    if (mt_wave) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) dwv[j] = dwx[(tid - (kProThreads - 64)) * 8 + j];
     }
     uint32_t nzmask = 0;
 #pragma unroll

@@ -20,6 +20,8 @@ for S in (1, 512, 4096):
     rows = np.stack([b.enc.get_state(100, i) for i in range(0, S, max(1, S//16))]).astype(np.int64)
     sub = rows[:, [5, 8, 9, 6]]
     print("   ordering sub-phases (init, scatter, rank+store):", np.median(np.diff(sub, axis=1), axis=0).astype(int).tolist())
+    st = rows[:, [0, 10, 11, 1, 12]]
+    print("   stage sub-phases (cur|tgt loads, mt+cost lut loads, string lut+barrier, MT wave):", np.median(np.diff(st, axis=1), axis=0).astype(int).tolist())
     d = np.diff(rows[:, :8], axis=1)
     print("S=%d last prologue phases (median cycles of s_memtime @100MHz?):" % S)
     print("  prefix: stage,phase1(dw),scan+select,MT,keys+compact,sort,write :", np.median(d, axis=0).astype(int).tolist(), "total", int(np.median(rows[:,7]-rows[:,0])))
