@@ -1174,6 +1174,146 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         return true;
     };
 
+    // one greedy step on list entry e (row w, store-table values nd), fast form.  Returns
+    // 0 = opcode emitted, 1 = entry skipped (its priority is gone), 2 = tie: nothing was
+    // done and the caller re-scores the entry with slow_step, 3 = error (err is set).
+    auto fast_step = [&](uint32_t e, const uint4 &w, const uint32_t (&nd)[4]) -> int {
+        const int p = (e >> 8) & 31, x = e & 255;
+        const uint32_t c = (e >> 16) & 0xffu;  // video.py:134
+        int kt[4], ke[4], C;
+        if (!score(w, nd, p, x, kt, ke, C, nullptr)) return 1;
+        if (MODE == kDHGR && c >= 0x80) {  // video.py:137
+            err = kErrPaletteBit;
+            return 3;
+        }
+        // two smallest eligible keys: in the lane, then across the wave
+        const int a0 = ke[0] < ke[1] ? ke[0] : ke[1], b0 = ke[0] < ke[1] ? ke[1] : ke[0];
+        const int a1 = ke[2] < ke[3] ? ke[2] : ke[3], b1 = ke[2] < ke[3] ? ke[3] : ke[2];
+        const int k1 = a0 < a1 ? a0 : a1, hi01 = a0 < a1 ? a1 : a0, mb = b0 < b1 ? b0 : b1;
+        const int k2 = hi01 < mb ? hi01 : mb;
+        const int K1 = wave_min_i32(k1);
+        int y1 = -1, y2 = -1;
+        uint32_t nd1 = 0, nd2 = 0;
+        if (K1 < 0) {
+            y1 = K1 & 255;
+            const int K2 = wave_min_i32(k1 == K1 ? k2 : k1);
+            if (K2 < 0) {
+                y2 = K2 & 255;
+                if ((K1 >> 16) == (K2 >> 16)) return 2;
+                // does a third eligible byte share the second delta?
+                const uint32_t D2 = (uint32_t)K2 >> 16;
+                int n2 = 0;
+#pragma unroll
+                for (int r = 0; r < 4; r++) n2 += (int)__popcll(__ballot(((uint32_t)ke[r] >> 16) == D2));
+                if (n2 > 1) return 2;  // the nonces decide
+                nd2 = nd_of(nd, y2);
+            }
+            nd1 = nd_of(nd, y1);
+        }
+        if (!apply(p, x, c, y1, nd1, y2, nd2, C)) {
+            err = kErrPushedOverflow;
+            return 3;
+        }
+        return 0;
+    };
+
+    // the same step in the reference's (delta, nonce, offset) heap order: every candidate's
+    // nonce is materialised.  Fetches the entry's row and values itself.  0 = emitted, 3 = error.
+    auto slow_step = [&](uint32_t e) -> int {
+        const int p = (e >> 8) & 31, x = e & 255;
+        const uint32_t c = (e >> 16) & 0xffu;
+        uint4 w = wd_rows[p * 64 + lane];
+        uint32_t nd[4];
+        gather4(w, c, nd);
+        finish4(w, nd);
+        int kt[4], ke[4], C, below;
+        score(w, nd, p, x, kt, ke, C, &below);  // the entry was live a moment ago: still is
+        // one random.getrandbits(8) per candidate in ascending offset (video.py:290-293)
+        uint32_t key[4];
+        int run = mt_idx + cb * 624 + below;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int fj = run >= 1248 ? run - 1248 : run;
+            run += kt[r] < 0 ? 1 : 0;
+            const uint32_t nonce = mt_temper(mt[fj]) >> 24;
+            const uint32_t k = ((uint32_t)((ke[r] >> 16) + 2048) << 16) | (nonce << 8) | (uint32_t)(y0 + r);
+            key[r] = ke[r] < 0 ? k : INF;  // video.py:159
+        }
+        // two smallest (delta, nonce, offset): lane, row of 16 (DPP), wave (readlane)
+        uint32_t a0 = key[0] < key[1] ? key[0] : key[1], b0 = key[0] < key[1] ? key[1] : key[0];
+        uint32_t a1 = key[2] < key[3] ? key[2] : key[3], b1 = key[2] < key[3] ? key[3] : key[2];
+        uint32_t k1 = a0 < a1 ? a0 : a1;
+        uint32_t hi01 = a0 < a1 ? a1 : a0, mb = b0 < b1 ? b0 : b1;
+        uint32_t k2 = hi01 < mb ? hi01 : mb;
+        top2_step<0xB1>(k1, k2);   // quad_perm [1,0,3,2]
+        top2_step<0x4E>(k1, k2);   // quad_perm [2,3,0,1]
+        top2_step<0x141>(k1, k2);  // row_half_mirror
+        top2_step<0x140>(k1, k2);  // row_mirror
+        uint32_t K1 = INF, K2 = INF;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t r1 = __builtin_amdgcn_readlane(k1, 16 * q), r2 = __builtin_amdgcn_readlane(k2, 16 * q);
+            uint32_t lo = K1 < r1 ? K1 : r1, hi = K1 < r1 ? r1 : K1;
+            uint32_t m2 = K2 < r2 ? K2 : r2;
+            K1 = lo;
+            K2 = hi < m2 ? hi : m2;
+        }
+        const int y1 = K1 != INF ? (int)(K1 & 255) : -1;
+        const int y2 = K2 != INF ? (int)(K2 & 255) : -1;
+        const uint32_t nd1 = y1 >= 0 ? nd_of(nd, y1) : 0u, nd2 = y2 >= 0 ? nd_of(nd, y2) : 0u;
+        if (!apply(p, x, c, y1, nd1, y2, nd2, C)) {
+            err = kErrPushedOverflow;
+            return 3;
+        }
+        return 0;
+    };
+
+    // ---- the sorted list is read through a 64-entry window held in registers (one entry per
+    // lane); a chunk = the next <= M window entries whose priority is still non-zero
+    int win_base = -1;  // list position of lane 0's entry
+    uint32_t win_e = 0;
+    // entries: page << 8 | offset | content << 16 | (list position - base) << 24
+    auto form = [&](int start, uint32_t (&ent)[M], int &cnt, int &base, int &end) {
+        cnt = 0;
+        end = start;
+        while (start < n_sorted) {
+            if (win_base < 0 || start < win_base || start >= win_base + 64) {
+                win_base = start;
+                const int idx = start + lane;
+                win_e = idx < n_sorted ? S.order[idx] : 0u;
+            }
+            const int idx = win_base + lane;
+            const uint32_t loc = win_e & 0x1fffu;
+            const bool v = idx >= start && idx < n_sorted && ((nz[loc >> 5] >> (loc & 31)) & 1u);
+            unsigned long long mask = __ballot(v);
+            const int window_end = win_base + 64 < n_sorted ? win_base + 64 : n_sorted;
+            if (mask == 0) {
+                start = end = window_end;
+                continue;
+            }
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                ent[m] = 0;
+                if (mask) {
+                    const int l = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    ent[m] = (uint32_t)__builtin_amdgcn_readlane((int)win_e, l) | ((uint32_t)l << 24);
+                    cnt = m + 1;
+                }
+            }
+            base = win_base;
+            end = mask ? win_base + (int)(ent[M - 1] >> 24) + 1 : window_end;
+            return;
+        }
+    };
+
+    // current chunk (its rows are in flight or here) and the one after it (rows prefetched
+    // while the current one is scored)
+    uint32_t c_ent[M];
+    uint4 c_rows[M];
+    int c_cnt = 0, c_base = 0, c_end = 0;
+    bool have_cur = false;
+
     int guard = n_ops + 8192 + 2 * kPushedCap + 64;
     while (done < n_ops && !err) {
         if (--guard < 0) {
@@ -1190,39 +1330,12 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
             break;
         }
 
-        // ---- form a chunk: next <= M entries whose priority is still non-zero
-        uint32_t ent[M];  // page << 8 | offset | content << 16 | (list position - chunk_head) << 24
-        const int chunk_head = head;
-        int cnt = 0, chunk_end = head;
-        bool from_pushed = false;
-        if (head < n_sorted) {
-            int idx = head + lane;
-            uint32_t e = idx < n_sorted ? S.order[idx] : 0u;
-            uint32_t loc = e & 0x1fffu;
-            bool v = idx < n_sorted && ((nz[loc >> 5] >> (loc & 31)) & 1u);
-            unsigned long long mask = __ballot(v);
-            int window_end = head + 64 < n_sorted ? head + 64 : n_sorted;
-            if (mask == 0) {
-                head = window_end;
-                continue;
-            }
-#pragma unroll
-            for (int m = 0; m < M; m++) {
-                ent[m] = 0;
-                if (mask) {
-                    int l = __builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    ent[m] = (uint32_t)__builtin_amdgcn_readlane(e, l) | ((uint32_t)l << 24);
-                    cnt = m + 1;
-                }
-            }
-            chunk_end = mask ? head + (int)(ent[M - 1] >> 24) + 1 : window_end;
-        } else {
+        if (head >= n_sorted) {
+            // ---- the initial list is used up: pop the re-queued bag (video.py:124-131, 170-178)
             if (truncated) {  // more initial entries exist than were ordered: host budget bug
                 err = kErrSortBudget;
                 break;
             }
-            from_pushed = true;
             unsigned long long best = ~0ull;
             for (int i = lane; i < n_pushed; i += 64) {
                 unsigned long long k = ((unsigned long long)S.pushed[i] << 32) | (unsigned)i;
@@ -1241,24 +1354,43 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
             }
             if (lane == 0) S.pushed[bi] = INF;
             __builtin_amdgcn_s_waitcnt(0x0F70);  // that store precedes the next scan of pushed[]
-#pragma unroll
-            for (int m = 0; m < M; m++) ent[m] = 0;
             // pushed keys do not carry the content byte: it is the target byte of that offset
             const uint32_t loc = bk & 0x1fffu;
             const uint32_t c = (uint32_t)IIV_SGPR(tgt_frames[loc]);
-            ent[0] = loc | (c << 16);
-            cnt = 1;
+            const uint32_t e = loc | (c << 16);
+            uint4 w = wd_rows[((e >> 8) & 31) * 64 + lane];
+            uint32_t nd[4];
+            gather4(w, c, nd);
+            finish4(w, nd);
+            int rc = fast_step(e, w, nd);
+            if (rc == 2) rc = slow_step(e);
+            if (rc == 3) break;
+            continue;
         }
 
-        // ---- fetch the chunk's rows: (window | diff weight) x4 per lane, then the store-table values.
-        // Branch-free on purpose (slots beyond cnt repeat entry 0): a branch makes the compiler
-        // retire each slot's loads before issuing the next slot's.
-        uint4 wdv[M];
+        if (!have_cur) {
+            form(head, c_ent, c_cnt, c_base, c_end);
+            if (c_cnt == 0) {
+                head = c_end;
+                continue;
+            }
 #pragma unroll
-        for (int m = 0; m < M; m++) wdv[m] = wd_rows[((ent[m] >> 8) & 31) * 64 + lane];
+            for (int m = 0; m < M; m++) c_rows[m] = wd_rows[((c_ent[m] >> 8) & 31) * 64 + lane];
+        }
+        // ---- this chunk's store-table values (slots beyond c_cnt repeat entry 0: branch-free
+        // on purpose, a branch makes the compiler retire each slot's loads before the next slot's)
         uint32_t ndv[M][4];
 #pragma unroll
-        for (int m = 0; m < M; m++) gather4(wdv[m], ent[m] >> 16, ndv[m]);
+        for (int m = 0; m < M; m++) gather4(c_rows[m], c_ent[m] >> 16, ndv[m]);
+        // ---- meanwhile: pick the next chunk and start fetching its rows
+        uint32_t n_ent[M];
+        uint4 n_rows[M];
+        int n_cnt = 0, n_base = 0, n_end = c_end;
+        if (c_end < n_sorted) form(c_end, n_ent, n_cnt, n_base, n_end);
+        if (n_cnt) {
+#pragma unroll
+            for (int m = 0; m < M; m++) n_rows[m] = wd_rows[((n_ent[m] >> 8) & 31) * 64 + lane];
+        }
         // vmcnt is one in-order counter for loads AND stores: retire the gathers once, here,
         // before the steps below start issuing stores.
         // (hipcc does not track a builtin s_waitcnt in its scoreboard, so the loaded
@@ -1267,119 +1399,45 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < M; m++) {
-            asm volatile("" : "+v"(wdv[m].x), "+v"(wdv[m].y), "+v"(wdv[m].z), "+v"(wdv[m].w));
+            asm volatile("" : "+v"(c_rows[m].x), "+v"(c_rows[m].y), "+v"(c_rows[m].z), "+v"(c_rows[m].w));
             asm volatile("" : "+v"(ndv[m][0]), "+v"(ndv[m][1]), "+v"(ndv[m][2]), "+v"(ndv[m][3]));
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < M; m++) finish4(wdv[m], ndv[m]);
+        for (int m = 0; m < M; m++) finish4(c_rows[m], ndv[m]);
 
         // ---- process the chunk
-        bool tie = false;
-        uint32_t tie_ent = 0;
+        bool redo = false;
 #pragma unroll
         for (int m = 0; m < M; m++) {
-            if (m >= cnt || done >= n_ops || err) break;
-            const int p = (ent[m] >> 8) & 31, x = ent[m] & 255;
-            const uint32_t c = (ent[m] >> 16) & 0xffu;  // video.py:134
-            int kt[4], ke[4], C;
-            if (!score(wdv[m], ndv[m], p, x, kt, ke, C, nullptr)) {
-                if (!from_pushed) head = chunk_head + (int)(ent[m] >> 24) + 1;
-                continue;
+            if (m >= c_cnt || done >= n_ops || err) break;
+            int rc = fast_step(c_ent[m], c_rows[m], ndv[m]);
+            if (rc == 2) {
+                rc = slow_step(c_ent[m]);
+                redo = rc == 0;  // the rest of the chunk is formed again from `head`
             }
-            if (MODE == kDHGR && c >= 0x80) {  // video.py:137
-                err = kErrPaletteBit;
-                break;
-            }
-            // two smallest eligible keys: in the lane, then across the wave
-            const int a0 = ke[0] < ke[1] ? ke[0] : ke[1], b0 = ke[0] < ke[1] ? ke[1] : ke[0];
-            const int a1 = ke[2] < ke[3] ? ke[2] : ke[3], b1 = ke[2] < ke[3] ? ke[3] : ke[2];
-            const int k1 = a0 < a1 ? a0 : a1, hi01 = a0 < a1 ? a1 : a0, mb = b0 < b1 ? b0 : b1;
-            const int k2 = hi01 < mb ? hi01 : mb;
-            const int K1 = wave_min_i32(k1);
-            int y1 = -1, y2 = -1;
-            uint32_t nd1 = 0, nd2 = 0;
-            if (K1 < 0) {
-                y1 = K1 & 255;
-                const int K2 = wave_min_i32(k1 == K1 ? k2 : k1);
-                if (K2 < 0) {
-                    y2 = K2 & 255;
-                    if ((K1 >> 16) == (K2 >> 16)) {
-                        tie = true;
-                    } else {
-                        // does a third eligible byte share the second delta?
-                        const uint32_t D2 = (uint32_t)K2 >> 16;
-                        int n2 = 0;
-#pragma unroll
-                        for (int r = 0; r < 4; r++) n2 += (int)__popcll(__ballot(((uint32_t)ke[r] >> 16) == D2));
-                        tie = n2 > 1;
-                    }
-                    if (tie) {  // the nonces decide: re-score this entry the long way, below
-                        tie_ent = ent[m];
-                        break;
-                    }
-                    nd2 = nd_of(ndv[m], y2);
-                }
-                nd1 = nd_of(ndv[m], y1);
-            }
-            if (!apply(p, x, c, y1, nd1, y2, nd2, C)) {
-                err = kErrPushedOverflow;
-                break;
-            }
-            if (!from_pushed) head = chunk_head + (int)(ent[m] >> 24) + 1;
+            if (rc == 3) break;
+            head = c_base + (int)(c_ent[m] >> 24) + 1;
+            if (redo) break;
         }
-
-        if (tie) {
-            // ---- slow form of one step: the reference's (delta, nonce, offset) heap order
-            const int p = (tie_ent >> 8) & 31, x = tie_ent & 255;
-            const uint32_t c = (tie_ent >> 16) & 0xffu;
-            uint4 w = wd_rows[p * 64 + lane];
-            uint32_t nd[4];
-            gather4(w, c, nd);
-            finish4(w, nd);
-            int kt[4], ke[4], C, below;
-            score(w, nd, p, x, kt, ke, C, &below);  // the entry was live a moment ago: still is
-            // one random.getrandbits(8) per candidate in ascending offset (video.py:290-293)
-            uint32_t key[4];
-            int run = mt_idx + cb * 624 + below;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int fj = run >= 1248 ? run - 1248 : run;
-                run += kt[r] < 0 ? 1 : 0;
-                const uint32_t nonce = mt_temper(mt[fj]) >> 24;
-                const uint32_t k = ((uint32_t)((ke[r] >> 16) + 2048) << 16) | (nonce << 8) | (uint32_t)(y0 + r);
-                key[r] = ke[r] < 0 ? k : INF;  // video.py:159
-            }
-            // two smallest (delta, nonce, offset): lane, row of 16 (DPP), wave (readlane)
-            uint32_t a0 = key[0] < key[1] ? key[0] : key[1], b0 = key[0] < key[1] ? key[1] : key[0];
-            uint32_t a1 = key[2] < key[3] ? key[2] : key[3], b1 = key[2] < key[3] ? key[3] : key[2];
-            uint32_t k1 = a0 < a1 ? a0 : a1;
-            uint32_t hi01 = a0 < a1 ? a1 : a0, mb = b0 < b1 ? b0 : b1;
-            uint32_t k2 = hi01 < mb ? hi01 : mb;
-            top2_step<0xB1>(k1, k2);   // quad_perm [1,0,3,2]
-            top2_step<0x4E>(k1, k2);   // quad_perm [2,3,0,1]
-            top2_step<0x141>(k1, k2);  // row_half_mirror
-            top2_step<0x140>(k1, k2);  // row_mirror
-            uint32_t K1 = INF, K2 = INF;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                uint32_t r1 = __builtin_amdgcn_readlane(k1, 16 * q), r2 = __builtin_amdgcn_readlane(k2, 16 * q);
-                uint32_t lo = K1 < r1 ? K1 : r1, hi = K1 < r1 ? r1 : K1;
-                uint32_t m2 = K2 < r2 ? K2 : r2;
-                K1 = lo;
-                K2 = hi < m2 ? hi : m2;
-            }
-            const int y1 = K1 != INF ? (int)(K1 & 255) : -1;
-            const int y2 = K2 != INF ? (int)(K2 & 255) : -1;
-            const uint32_t nd1 = y1 >= 0 ? nd_of(nd, y1) : 0u, nd2 = y2 >= 0 ? nd_of(nd, y2) : 0u;
-            if (!apply(p, x, c, y1, nd1, y2, nd2, C)) {
-                err = kErrPushedOverflow;
-                break;
-            }
-            if (!from_pushed) head = chunk_head + (int)(tie_ent >> 24) + 1;
-            continue;  // the rest of the chunk is formed again from `head`
+        if (err || done >= n_ops) break;
+        if (redo) {
+            have_cur = false;
+            continue;
         }
-        if (!from_pushed && !err && done < n_ops) head = chunk_end > head ? chunk_end : head;
+        head = c_end > head ? c_end : head;
+        // the prefetched chunk becomes the current one
+        have_cur = n_cnt > 0;
+        if (have_cur) {
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                c_ent[m] = n_ent[m];
+                c_rows[m] = n_rows[m];
+            }
+            c_cnt = n_cnt;
+            c_base = n_base;
+            c_end = n_end;
+        }
     }
 
     __syncthreads();
