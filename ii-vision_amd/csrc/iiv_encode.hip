@@ -224,20 +224,31 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
 {
     constexpr int BITS = ModeTraits<MODE>::kBits;
     constexpr int NB = ModeTraits<MODE>::kBanks;
-    // One 64 KiB region, used first for the staged memory maps (cur | tgt), then --
-    // once every diff weight is in registers -- as the sort's exchange buffer.
-    __shared__ __attribute__((aligned(16))) unsigned char smem[65536];
+    // One LDS block, carved by hand so that the small lookup tables sit at the lowest
+    // addresses: their offsets then fold into the 16-bit offset field of ds_read and the
+    // recurrence needs no address add per lookup.
+    //      0  lut    16x16 substitute costs (u16)
+    //    512  aux4k  DHGR colour-string LUTs | handed-over diff weights, then histogram, then bucket cursors
+    //   4608  mtb    [0] = the stream's current MT19937 block; later the bucket starts
+    //   9600  wsum, flags
+    //   9728  smem   64 KiB: staged memory maps (cur | tgt) + generated MT blocks, then -- once
+    //                every diff weight is in registers -- the sort's key buffer
+    __shared__ __attribute__((aligned(16))) unsigned char lds[9728 + 65536];
+    uint16_t *lut = reinterpret_cast<uint16_t *>(lds);
+    uint32_t *aux4k = reinterpret_cast<uint32_t *>(lds + 512);
+    uint32_t(*mtb)[624] = reinterpret_cast<uint32_t(*)[624]>(lds + 4608);
+    uint32_t *wsum = reinterpret_cast<uint32_t *>(lds + 9600);
+    int &flag_bad = *reinterpret_cast<int *>(lds + 9664);
+    int &sel_bucket = *reinterpret_cast<int *>(lds + 9668);
+    int &sel_count = *reinterpret_cast<int *>(lds + 9672);
+    int &big_bucket = *reinterpret_cast<int *>(lds + 9676);
+    unsigned char *smem = lds + 9728;
     uint8_t(*cur)[8192] = reinterpret_cast<uint8_t(*)[8192]>(smem);
     uint8_t(*tgt)[8192] = reinterpret_cast<uint8_t(*)[8192]>(smem + NB * 8192);
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);
     // np.random's MT19937 blocks 1..13 -- every block the <= 7680 draws of this call can reach --
     // are generated above cur | tgt by the last wave while the other waves score
     uint32_t *gen = reinterpret_cast<uint32_t *>(smem + 2 * NB * 8192);
-    __shared__ uint32_t aux4k[1024];  // DHGR colour-string LUTs, then histogram, then bucket cursors
-    __shared__ uint32_t mtb[2][624];  // [0] = the stream's current block; later the bucket starts
-    __shared__ uint16_t lut[256];
-    __shared__ uint32_t wsum[kProThreads / 64];
-    __shared__ int flag_bad;
 
     const int tid = threadIdx.x;
     StreamState &S = states[blockIdx.x];
@@ -434,7 +445,6 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
     const int bcount = (int)hist[1023 - tid];
     int total_unused;
     const int bstart = block_scan_excl<kProThreads>(bcount, tid, wsum, total_unused);
-    __shared__ int sel_bucket, sel_count, big_bucket;
     if (tid == 0) {
         sel_bucket = 0;
         sel_count = n;
@@ -1072,6 +1082,9 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
                 const int r = ORD[k];
                 const uint32_t t = *wr[r] & 0xffffu;
                 const uint32_t q = (t * 43691u) >> 17;  // t / 3 for t < 2^16
+#ifdef IIV_PROBE_SKIP3
+                if (r == 3) { nd[r] = 0x3fffffffu; } else
+#endif
                 nd[r] = reinterpret_cast<const uint32_t *>(r & 1 ? sd : se)[q];
                 *wr[r] = (*wr[r] & HI) | ((t - 3u * q) * 10u);
             }
@@ -1474,6 +1487,7 @@ struct Encoder {
     int dw_mode;            // IIV_DW_TABLE / IIV_DW_RECURRENCE
     int greedy_mode;        // IIV_GREEDY_WAVE / IIV_GREEDY_WORKGROUP
     int partial_sort;       // allow the prologue's prefix sort when the budget is known
+    int packed_store;       // let the wave kernel use d_store10
     StreamState *d_states;
     StreamState *d_snapshot;  // iiv_encoder_snapshot copy (lazily allocated)
     // generator bookkeeping shared by all streams (same schedule)
@@ -1533,6 +1547,7 @@ int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, c
     e->dw_mode = dm ? IIV_DW_RECURRENCE : IIV_DW_TABLE;
     e->greedy_mode = IIV_GREEDY_AUTO;
     e->partial_sort = 1;
+    e->packed_store = 1;
     e->gen_active = 0;
     e->gen_is_aux = 0;
     e->gen_frame = 0;
@@ -1640,6 +1655,10 @@ int encoder_set_option(Encoder *e, int option, int value)
     }
     if (option == IIV_OPT_PREFIX_SORT) {
         e->partial_sort = value ? 1 : 0;
+        return IIV_OK;
+    }
+    if (option == IIV_OPT_PACKED_STORE) {
+        e->packed_store = value ? 1 : 0;
         return IIV_OK;
     }
     if (option == IIV_OPT_GREEDY_KERNEL) {
@@ -1861,7 +1880,7 @@ int encode(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux, int n_frames
         const bool use_wave = e->greedy_mode == IIV_GREEDY_WAVE ||
                               (e->greedy_mode == IIV_GREEDY_AUTO && e->n_streams >= 1536);
         if (use_wave) {
-            if (e->mode == kDHGR && e->d_store10) IIV_GREEDY((greedy_wave_kernel<kDHGR, true>), 64, (const void *)e->d_store10);
+            if (e->mode == kDHGR && e->d_store10 && e->packed_store) IIV_GREEDY((greedy_wave_kernel<kDHGR, true>), 64, (const void *)e->d_store10);
             else if (e->mode == kDHGR) IIV_GREEDY((greedy_wave_kernel<kDHGR, false>), 64, (const void *)e->d_store);
             else IIV_GREEDY((greedy_wave_kernel<kHGR, false>), 64, (const void *)e->d_store);
         } else {

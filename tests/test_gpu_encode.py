@@ -23,7 +23,7 @@ def _seed_states(O, seed_py, seed_np):
 
 
 def _run_device(native, device_tables, mode, pal, frames_list, sched, seeds, recurrence=True, wave=True,
-                prefix_sort=True):
+                prefix_sort=True, packed_store=True):
     """frames_list: list (per stream) of (n_frames, banks, 32, 256) arrays."""
     import torch
     t, s = device_tables.get(mode, pal)
@@ -31,6 +31,7 @@ def _run_device(native, device_tables, mode, pal, frames_list, sched, seeds, rec
     enc = native.Encoder(mode, t, s, n, dm=device_tables.dm[(mode, pal)] if recurrence else None)
     enc.set_greedy_kernel(wave)
     enc.set_prefix_sort(prefix_sort)
+    enc.set_packed_store(packed_store)
     fr = np.stack(frames_list)
     fm = torch.from_numpy(np.ascontiguousarray(fr[:, :, 0])).cuda()
     fa = torch.from_numpy(np.ascontiguousarray(fr[:, :, 1])).cuda() if mode == 1 else None
@@ -51,17 +52,19 @@ def _next_draws(O, words, n, high):
     return [f(C.byref(m)) for _ in range(n)]
 
 
-@pytest.mark.parametrize("recurrence,wave", [(True, True), (False, True), (True, False)])
-def test_golden_runs(native, O, golden, device_tables, recurrence, wave):
+@pytest.mark.parametrize("recurrence,wave,packed", [(True, True, True), (False, True, True), (True, False, True),
+                                                    (True, True, False)])
+def test_golden_runs(native, O, golden, device_tables, recurrence, wave, packed):
     """recurrence=True: diff weights recomputed in the prologue; False: gathered from
     the HBM table.  wave=True: one wave per stream; False: one 256-thread workgroup
-    per stream.  Every combination must reproduce the reference bit for bit."""
+    per stream.  packed: the wave kernel reads the 10-bit repack of the DHGR store table
+    or the u16 table itself.  Every combination must reproduce the reference bit for bit."""
     g3 = golden.g3_encode_runs
     for tag in _tags(g3):
         mode, pal, sp, sn = (int(x) for x in g3[tag + "/meta"])
         frames, sched, ops = g3[tag + "/frames"], g3[tag + "/schedule"], g3[tag + "/ops"]
         enc, got = _run_device(native, device_tables, mode, pal, [frames], sched, [_seed_states(O, sp, sn)],
-                               recurrence=recurrence, wave=wave)
+                               recurrence=recurrence, wave=wave, packed_store=packed)
         bad = np.nonzero((got[0] != ops).any(axis=1))[0]
         assert len(bad) == 0, "%s: first mismatch at op %d: got %s want %s" % (
             tag, bad[0], got[0][bad[0]], ops[bad[0]])
@@ -107,8 +110,10 @@ def _oracle_run(O, oracle_tables, mode, pal, frames, sched, sp, sn):
     return v, np.concatenate(out)
 
 
-@pytest.mark.parametrize("mode,wave,prefix", [(1, True, True), (0, True, True), (1, False, True), (1, True, False)])
-def test_batch_of_independent_streams(native, O, oracle_tables, device_tables, mode, wave, prefix):
+@pytest.mark.parametrize("mode,wave,prefix,packed", [(1, True, True, True), (0, True, True, True),
+                                                     (1, False, True, True), (1, True, False, True),
+                                                     (1, True, True, False)])
+def test_batch_of_independent_streams(native, O, oracle_tables, device_tables, mode, wave, prefix, packed):
     """12 streams with different data / seeds / coherence in ONE launch sequence,
     ragged segment lengths incl. bank flips; every stream equals its own oracle run."""
     n = 12
@@ -116,7 +121,8 @@ def test_batch_of_independent_streams(native, O, oracle_tables, device_tables, m
     frames = [_synth(mode, 3, 100 + i, coherent=(i % 2 == 1)) for i in range(n)]
     seeds = [(i + 1, 1000 + i) for i in range(n)]
     enc, got = _run_device(native, device_tables, mode, 5, frames, sched,
-                           [_seed_states(O, a, b) for a, b in seeds], wave=wave, prefix_sort=prefix)
+                           [_seed_states(O, a, b) for a, b in seeds], wave=wave, prefix_sort=prefix,
+                           packed_store=packed)
     for i in range(n):
         v, exp = _oracle_run(O, oracle_tables, mode, 5, frames[i], sched, *seeds[i])
         assert (got[i] == exp).all(), "stream %d" % i
