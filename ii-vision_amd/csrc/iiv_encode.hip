@@ -1145,6 +1145,18 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         return (uint32_t)__builtin_amdgcn_readlane((int)v, y >> 2);
     };
 
+    // opcodes emitted but not yet written: opcode ob_base + l sits in lane l of (ob0, ob1)
+    uint32_t ob0 = 0, ob1 = 0;
+    int ob_base = 0;
+    auto flush_ops = [&]() {
+        if (lane < done - ob_base) {
+            uint8_t *q = out + (size_t)(ob_base + lane) * 6;
+            *reinterpret_cast<u32_a2 *>(q) = ob0;
+            *reinterpret_cast<uint16_t *>(q + 4) = (uint16_t)ob1;
+        }
+        ob_base = done;
+    };
+
     // video.py:140-144, 170-187; screen.py:256-293.  Lanes 0..2 carry (x, y1, y2); a
     // missing secondary repeats the primary's stores.  Returns false on overflow.
     auto apply = [&](int p, int x, uint32_t c, int y1, uint32_t nd1, int y2, uint32_t nd2, int C) -> bool {
@@ -1166,18 +1178,18 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
                 const uint32_t nonce = mt_temper(mt[j]) >> 24;  // video.py:178
                 S.pushed[n_pushed + k] = ((2047u - val) << 21) | (nonce << 13) | ((uint32_t)p << 8) | (uint32_t)off;
             }
-            if (lane == 0) {
-                atomicOr(&pdone[p * 8 + (x >> 5)], 1u << (x & 31));
-                uint8_t *q = out + (size_t)done * 6;
-                *reinterpret_cast<u32_a2 *>(q) =
-                    (uint32_t)(p + 32) | (c << 8) | ((uint32_t)x << 16) | ((uint32_t)y1e << 24);
-                *reinterpret_cast<uint16_t *>(q + 4) = (uint16_t)((uint32_t)y2e | ((uint32_t)x << 8));
-            }
+            if (lane == 0) atomicOr(&pdone[p * 8 + (x >> 5)], 1u << (x & 31));
         }
+        // the opcode (page + 32, content, x, y1, y2, x) goes into lane (done - ob_base) of a
+        // register pair; 64 of them leave in two coalesced stores
+        const bool mine = lane == done - ob_base;
+        ob0 = mine ? (uint32_t)(p + 32) | (c << 8) | ((uint32_t)x << 16) | ((uint32_t)y1e << 24) : ob0;
+        ob1 = mine ? (uint32_t)y2e | ((uint32_t)x << 8) : ob1;
         mt_idx += C + f1 + f2;
         draws += (unsigned long long)(C + f1 + f2);
         n_pushed += f1 + f2;
         done++;
+        if (done - ob_base == 64) flush_ops();
         if (mt_idx >= 624) {
             __syncthreads();
             mt_twist_wave(mt + 624 * (cb ^ 1), mt + 624 * cb, lane);
@@ -1334,12 +1346,14 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
             break;
         }
         if (exhausted) {
+            flush_ops();
             for (int i = done + lane; i < n_ops; i += 64) {  // video.py:249-251
                 uint8_t *q = out + (size_t)i * 6;
                 q[0] = 32; q[1] = (uint8_t)pad_content; q[2] = 0; q[3] = 0; q[4] = 0; q[5] = 0;
             }
             pad_ops += (unsigned long long)(n_ops - done);
             done = n_ops;
+            ob_base = done;  // nothing buffered
             break;
         }
 
@@ -1453,6 +1467,7 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         }
     }
 
+    flush_ops();
     __syncthreads();
     for (int i = lane; i < 256; i += 64) {
         S.nzbits[i] = nz[i];
