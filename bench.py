@@ -38,6 +38,7 @@ OPS_PER_FRAME = 490                # 14700 Hz / 30 fps (video.py:31-33)
 BYTES_PER_OPCODE = 534             # 256 x 2 B gathers + 6 B out + 2 x 8 B packed RMW
 BYTES_PER_PROLOGUE = 147456        # 2 x 32 KiB packed + 16 KiB gathers + 64 KiB priority r/w
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
+GATHER_CEILING_LINES_PER_S = 265e9  # tools/gather_bench.hip, MI355X: 0.43 distinct lines / CU / cycle
 
 
 def rank_seeds(rank, streams):
@@ -203,6 +204,14 @@ def main():
             "algorithmic_bytes_per_launch": greedy_bytes / g_n,
             "avg_launch_ms": g_ms / g_n,
             "launches": prof["greedy_launches"],
+            # what actually bounds this kernel: 256 random store-table lookups per opcode through the
+            # CU's L1 (TCP).  Ceiling = tools/gather_bench.hip on this GPU model, L2-resident table,
+            # fully divergent wave64 loads (profiles/*gather_bench.txt): distinct lines per second.
+            "gather": {
+                "lookups_per_s": float(op_count) * S * 256 / (g_ms * 1e-3) if g_ms > 0 else 0.0,
+                "ceiling_divergent_lines_per_s": GATHER_CEILING_LINES_PER_S,
+                "note": "lookups that share a 128 B line inside one load instruction count once against the ceiling",
+            },
         }
         pro_bytes = float(seg_count) * S * BYTES_PER_PROLOGUE
         out["roofline_prologue"] = {

@@ -51,8 +51,8 @@ template <typename T, int G, int SHARE = 1, int ACTIVE = 64> static void run(siz
     float ms;
     hipEventElapsedTime(&ms, a, b);
     double lookups = (double)waves * 64 * iters * G;
-    printf("%-6s share %d active %d table %6.1f MiB  waves %6d  batch %2d: %8.3f ms  %7.1f G lookups/s  (%.3f per CU-cycle @2.4GHz)\n", name, SHARE, ACTIVE,
-           bytes / 1048576.0, waves, G, ms, lookups / ms * 1e-6, lookups / (ms * 1e-3) / 256 / 2.4e9);
+    printf("%-6s share %d active %2d table %8.0f KiB  waves %6d  batch %2d: %8.3f ms  %7.1f G lookups/s  (%.3f per CU-cycle @2.4GHz)\n", name, SHARE, ACTIVE,
+           bytes / 1024.0, waves, G, ms, lookups / ms * 1e-6, lookups / (ms * 1e-3) / 256 / 2.4e9);
     hipFree(d);
     hipFree(sink);
 }
