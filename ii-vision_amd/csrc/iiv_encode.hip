@@ -1243,14 +1243,10 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
     };
 
     // the same step in the reference's (delta, nonce, offset) heap order: every candidate's
-    // nonce is materialised.  Fetches the entry's row and values itself.  0 = emitted, 3 = error.
-    auto slow_step = [&](uint32_t e) -> int {
+    // nonce is materialised.  0 = emitted, 3 = error.
+    auto slow_step = [&](uint32_t e, const uint4 &w, const uint32_t (&nd)[4]) -> int {
         const int p = (e >> 8) & 31, x = e & 255;
         const uint32_t c = (e >> 16) & 0xffu;
-        uint4 w = wd_rows[p * 64 + lane];
-        uint32_t nd[4];
-        gather4(w, c, nd);
-        finish4(w, nd);
         int kt[4], ke[4], C, below;
         score(w, nd, p, x, kt, ke, C, &below);  // the entry was live a moment ago: still is
         // one random.getrandbits(8) per candidate in ascending offset (video.py:290-293)
@@ -1390,7 +1386,7 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
             gather4(w, c, nd);
             finish4(w, nd);
             int rc = fast_step(e, w, nd);
-            if (rc == 2) rc = slow_step(e);
+            if (rc == 2) rc = slow_step(e, w, nd);
             if (rc == 3) break;
             continue;
         }
@@ -1434,24 +1430,15 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         for (int m = 0; m < M; m++) finish4(c_rows[m], ndv[m]);
 
         // ---- process the chunk
-        bool redo = false;
 #pragma unroll
         for (int m = 0; m < M; m++) {
             if (m >= c_cnt || done >= n_ops || err) break;
             int rc = fast_step(c_ent[m], c_rows[m], ndv[m]);
-            if (rc == 2) {
-                rc = slow_step(c_ent[m]);
-                redo = rc == 0;  // the rest of the chunk is formed again from `head`
-            }
+            if (rc == 2) rc = slow_step(c_ent[m], c_rows[m], ndv[m]);
             if (rc == 3) break;
             head = c_base + (int)(c_ent[m] >> 24) + 1;
-            if (redo) break;
         }
         if (err || done >= n_ops) break;
-        if (redo) {
-            have_cur = false;
-            continue;
-        }
         head = c_end > head ? c_end : head;
         // the prefetched chunk becomes the current one
         have_cur = n_cnt > 0;
