@@ -71,6 +71,7 @@ def parse_args():
     ap.add_argument("--frames-per-step", type=int, default=50)
     ap.add_argument("--mode", choices=["DHGR", "HGR"], default="DHGR")
     ap.add_argument("--coherent", action="store_true", help="S-coh input instead of S-iid")
+    ap.add_argument("--img", action="store_true", help="S-img input (dithered moving bars) instead of S-iid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=600, help="frames of stream 0 the CPU baseline encodes")
     ap.add_argument("--cpu-frames-all", type=int, default=60, help="frames per stream of the all-cores CPU baseline")
@@ -117,7 +118,10 @@ def main():
     store = native.build_store_table(mode, dm)
     torch.cuda.synchronize()
     t_tab = time.time() - t_tab
-    fm, fa = stream_batch.synth_frames_torch(S, n_frames, dhgr, seed=data_seed(rank), coherent=args.coherent)
+    if args.img:
+        fm, fa = stream_batch.synth_frames_img(S, n_frames, dhgr, seed=data_seed(rank))
+    else:
+        fm, fa = stream_batch.synth_frames_torch(S, n_frames, dhgr, seed=data_seed(rank), coherent=args.coherent)
     seeds = rank_seeds(rank, S)
     batch = stream_batch.StreamBatch(mode, table, store, S, seeds=seeds, dm=dm)
     if args.dw_table:
@@ -175,7 +179,7 @@ def main():
         "config": {
             "workload": "%s NTSC %dx192 S-%s synthetic clips, %d frames each, %d independent clips per GPU, "
                         "Movie.encode control flow (490 opcodes/frame%s)" % (
-                            args.mode, 560 if dhgr else 280, "coh" if args.coherent else "iid",
+                            args.mode, 560 if dhgr else 280, "img" if args.img else "coh" if args.coherent else "iid",
                             args.steps * F, S, ", bank flip per 2 KiB" if dhgr else ""),
             "streams_per_gpu": S,
             "frames_per_step": F,

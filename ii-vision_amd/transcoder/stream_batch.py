@@ -98,6 +98,45 @@ def synth_frames_torch(n_streams, n_frames, dhgr, seed, coherent=False, device="
     return out[0], (out[1] if dhgr else None)
 
 
+def synth_frames_img(n_streams, n_frames, dhgr, seed, device="cuda"):
+    """SURVEY 8(d) S-img: 1-bit dot fields -- moving grey-ramp bars rendered with a 4x4
+    ordered dither -- packed 7 dots per byte through X_Y_TO_PAGE / X_Y_TO_OFFSET
+    (DHGR: aux, main bytes alternate along a row).  Image-like input: large
+    coherent areas, many equal windows, many delta ties.  Every stream gets its own
+    bar period / speed / slope / phase.  Returns (main, aux) as synth_frames_torch."""
+    import torch
+    import screen
+    g = torch.Generator(device="cpu")
+    g.manual_seed(int(seed))
+    S = n_streams
+    W = 560 if dhgr else 280
+
+    def par(lo, hi):
+        return torch.randint(lo, hi, (S, 1, 1), generator=g).to(device)
+
+    period, speed, slope, phase = par(24, 120), par(1, 6), par(-2, 3), par(0, 120)
+    y = torch.arange(192, device=device).view(1, 192, 1)
+    x = torch.arange(W, device=device).view(1, 1, W)
+    bayer = torch.tensor([[0, 8, 2, 10], [12, 4, 14, 6], [3, 11, 1, 9], [15, 7, 13, 5]], device=device)
+    thr = bayer[y % 4, x % 4]                                       # (1,192,W)
+    lin = torch.from_numpy(screen.X_Y_TO_PAGE.astype(np.int64) * 256 + screen.X_Y_TO_OFFSET.astype(np.int64))
+    lin = lin.reshape(-1).to(device)                                # (192*40,) page*256+offset, row-major (y, x)
+    weights = (1 << torch.arange(7, device=device)).view(1, 1, 1, 7)
+    nb = 2 if dhgr else 1
+    out = [torch.zeros((S, n_frames, 8192), dtype=torch.uint8, device=device) for _ in range(nb)]
+    for f in range(n_frames):
+        t = (x + slope * y + speed * f + phase) % period            # (S,192,W)
+        dots = ((t * 17) // period) > thr
+        by = (dots.view(S, 192, W // 7, 7) * weights).sum(-1).to(torch.uint8)   # (S,192,W/7)
+        if dhgr:
+            out[1][:, f, lin] = by[:, :, 0::2].reshape(S, -1)      # aux bytes come first in dot order
+            out[0][:, f, lin] = by[:, :, 1::2].reshape(S, -1)
+        else:
+            out[0][:, f, lin] = by.reshape(S, -1)
+    out = [o.view(S, n_frames, 32, 256) for o in out]
+    return out[0], (out[1] if dhgr else None)
+
+
 class StreamBatch:
     """S independent video.Video encoders advanced in lock step on one GPU."""
 

@@ -195,3 +195,34 @@ def test_reference_asserts_are_reported(native, device_tables):
     with pytest.raises(native.IIVError):
         enc.encode(fm[:1], fa[:1], [(0, 0, 0, 5)])  # continues a generator that does not exist
     enc.close()
+
+
+@pytest.mark.parametrize("mode,wave", [(1, True), (1, False), (0, True)])
+def test_image_like_streams(native, O, oracle_tables, device_tables, mode, wave):
+    """S-img input (dithered moving bars): large coherent areas, many identical
+    windows, so the two best deltas tie far more often than on random data -- the wave
+    kernel's nonce-resolved slow step, zero diff weights and early out-of-work all get
+    exercised.  Every stream equals its own oracle run."""
+    import stream_batch
+    n = 6
+    fm, fa = stream_batch.synth_frames_img(n, 3, mode == 1, seed=11, device="cpu")
+    frames = []
+    for i in range(n):
+        fr = np.zeros((3, 2, 32, 256), np.uint8)
+        fr[:, 0] = fm[i].numpy()
+        if mode == 1:
+            fr[:, 1] = fa[i].numpy()
+        frames.append(fr)
+    b = 1 if mode == 1 else 0
+    sched = [(0, 0, 292), (0, b, 198), (1, b, 94), (1, 0, 292), (1, b, 104), (2, b, 490)]
+    seeds = [(50 + i, 90 + i) for i in range(n)]
+    enc, got = _run_device(native, device_tables, mode, 5, frames, sched,
+                           [_seed_states(O, a, c) for a, c in seeds], wave=wave)
+    for i in range(n):
+        v, exp = _oracle_run(O, oracle_tables, mode, 5, frames[i], sched, *seeds[i])
+        assert (got[i] == exp).all(), "stream %d" % i
+        assert (enc.get_state(native.STATE_UP_MAIN, i) == v.update_priority(0)).all()
+        assert (enc.get_state(native.STATE_PACKED, i) == v.packed).all()
+        cnt = enc.get_state(native.STATE_COUNTERS, i)
+        assert (int(cnt[0]), int(cnt[1])) == v.draws()
+    enc.close()
