@@ -38,6 +38,7 @@ OPS_PER_FRAME = 490                # 14700 Hz / 30 fps (video.py:31-33)
 BYTES_PER_OPCODE = 534             # 256 x 2 B gathers + 6 B out + 2 x 8 B packed RMW
 BYTES_PER_PROLOGUE = 147456        # 2 x 32 KiB packed + 16 KiB gathers + 64 KiB priority r/w
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_MEASURED_READ_GBS = 5990.0     # tools/hbm_copy_bench.py on the same box (profiles/r01f_hbm_copy.txt); copy 4610, write 6900
 GATHER_CEILING_LINES_PER_S = 265e9  # tools/gather_bench.hip, MI355X: 0.43 distinct lines / CU / cycle
 
 
@@ -204,6 +205,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
+            "peak_measured_read": HBM_MEASURED_READ_GBS,
             "traffic": _pmc_traffic(),
             "algorithmic_bytes_per_launch": greedy_bytes / g_n,
             "avg_launch_ms": g_ms / g_n,
