@@ -1157,6 +1157,15 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         ob_base = done;
     };
 
+    // block cb is current; block cb ^ 1 must follow it before a step can read past word 623
+    bool twist_pending = false;
+    auto twist_now = [&]() {
+        if (twist_pending) {
+            mt_twist_wave(mt + 624 * cb, mt + 624 * (cb ^ 1), lane);
+            twist_pending = false;
+        }
+    };
+
     // video.py:140-144, 170-187; screen.py:256-293.  Lanes 0..2 carry (x, y1, y2); a
     // missing secondary repeats the primary's stores.  Returns false on overflow.
     auto apply = [&](int p, int x, uint32_t c, int y1, uint32_t nd1, int y2, uint32_t nd2, int C) -> bool {
@@ -1164,6 +1173,7 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         const int y1e = y1 >= 0 ? y1 : x, y2e = y2 >= 0 ? y2 : x;   // video.py:185-186
         const int f1 = v1 ? 1 : 0, f2 = v2 ? 1 : 0;
         if (n_pushed + f1 + f2 > kPushedCap) return false;
+        if (mt_idx + C + 2 >= 624) twist_now();
         if (lane < 3) {
             const int off = lane == 0 ? x : lane == 1 ? y1e : y2e;
             const uint32_t val = lane == 0 ? 0u : lane == 1 ? v1 : v2;
@@ -1191,10 +1201,12 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         done++;
         if (done - ob_base == 64) flush_ops();
         if (mt_idx >= 624) {
-            __syncthreads();
-            mt_twist_wave(mt + 624 * (cb ^ 1), mt + 624 * cb, lane);
+            // the following block becomes the current one; the block after it is generated
+            // later, while store-table loads are in flight (twist_now), at the latest before
+            // the next step reads nonces
             cb ^= 1;
             mt_idx -= 624;
+            twist_pending = true;
         }
         return true;
     };
@@ -1248,6 +1260,7 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         const int p = (e >> 8) & 31, x = e & 255;
         const uint32_t c = (e >> 16) & 0xffu;
         int kt[4], ke[4], C, below;
+        twist_now();
         score(w, nd, p, x, kt, ke, C, &below);  // the entry was live a moment ago: still is
         // one random.getrandbits(8) per candidate in ascending offset (video.py:290-293)
         uint32_t key[4];
@@ -1414,6 +1427,7 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
 #pragma unroll
             for (int m = 0; m < M; m++) n_rows[m] = wd_rows[((n_ent[m] >> 8) & 31) * 64 + lane];
         }
+        twist_now();  // (the MT19937 block generation hides behind the loads)
         // vmcnt is one in-order counter for loads AND stores: retire the gathers once, here,
         // before the steps below start issuing stores.
         // (hipcc does not track a builtin s_waitcnt in its scoreboard, so the loaded
