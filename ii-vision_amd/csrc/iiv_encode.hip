@@ -1024,6 +1024,7 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
     __shared__ uint32_t nz[256];     // update_priority != 0
     __shared__ uint32_t pdone[256];  // byte already emitted as a primary (its diff weight counts as 0)
     __shared__ uint32_t mt[2 * 624];
+    __shared__ uint32_t xw[64];      // compaction of a list window
 
     const int lane = threadIdx.x;
     StreamState &S = states[blockIdx.x];
@@ -1157,6 +1158,17 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         ob_base = done;
     };
 
+#ifdef IIV_STAMPS
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memtime();
+#define IIV_PHASE(i)                                                  \
+    do {                                                              \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        ph[i] += now_ - ph_t;                                         \
+        ph_t = now_;                                                  \
+    } while (0)
+#else
+#define IIV_PHASE(i) do { } while (0)
+#endif
     // block cb is current; block cb ^ 1 must follow it before a step can read past word 623
     bool twist_pending = false;
     auto twist_now = [&]() {
@@ -1302,50 +1314,37 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         return 0;
     };
 
-    // ---- the sorted list is read through a 64-entry window held in registers (one entry per
-    // lane); a chunk = the next <= M window entries whose priority is still non-zero
-    int win_base = -1;  // list position of lane 0's entry
-    uint32_t win_e = 0;
-    // entries: page << 8 | offset | content << 16 | (list position - base) << 24
-    auto form = [&](int start, uint32_t (&ent)[M], int &cnt, int &base, int &end) {
-        cnt = 0;
-        end = start;
-        while (start < n_sorted) {
-            if (win_base < 0 || start < win_base || start >= win_base + 64) {
-                win_base = start;
-                const int idx = start + lane;
-                win_e = idx < n_sorted ? S.order[idx] : 0u;
-            }
-            const int idx = win_base + lane;
-            const uint32_t loc = win_e & 0x1fffu;
-            const bool v = idx >= start && idx < n_sorted && ((nz[loc >> 5] >> (loc & 31)) & 1u);
-            unsigned long long mask = __ballot(v);
-            const int window_end = win_base + 64 < n_sorted ? win_base + 64 : n_sorted;
-            if (mask == 0) {
-                start = end = window_end;
-                continue;
-            }
-#pragma unroll
-            for (int m = 0; m < M; m++) {
-                ent[m] = 0;
-                if (mask) {
-                    const int l = __builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    ent[m] = (uint32_t)__builtin_amdgcn_readlane((int)win_e, l) | ((uint32_t)l << 24);
-                    cnt = m + 1;
-                }
-            }
-            base = win_base;
-            end = mask ? win_base + (int)(ent[M - 1] >> 24) + 1 : window_end;
-            return;
-        }
+    // ---- the sorted list is read 64 entries at a time; the entries of that window whose
+    // priority is still non-zero are compacted into one register (lane k = k-th live entry,
+    // through a 256 B LDS scatter), so that handing out the next chunk is two v_readlane
+    // with a scalar index.  An entry that dies between compaction and use is skipped by the
+    // step itself (video.py:130).
+    // entries: page << 8 | offset | content << 16 | (list position - win_base) << 24
+    int win_base = 0, win_end = 0;  // list positions [win_base, win_end) are in the window
+    int n_dense = 0, qi = 0;        // live entries of the window, next one to hand out
+    uint32_t dense_e = 0;
+    auto refill = [&](int start) {
+        win_base = start;
+        win_end = start + 64 < n_sorted ? start + 64 : n_sorted;
+        const int idx = start + lane;
+        const uint32_t e = idx < n_sorted ? S.order[idx] : 0u;
+        const uint32_t loc = e & 0x1fffu;
+        const bool v = idx < n_sorted && ((nz[loc >> 5] >> (loc & 31)) & 1u);
+        const unsigned long long mask = __ballot(v);
+        n_dense = (int)__popcll(mask);
+        qi = 0;
+        if (v) xw[prefix_popc(mask)] = e | ((uint32_t)lane << 24);
+        wave_lds_sync();
+        dense_e = xw[lane];
+        wave_lds_sync();
     };
+    auto take = [&](int k) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)dense_e, k); };
 
     // current chunk (its rows are in flight or here) and the one after it (rows prefetched
     // while the current one is scored)
     uint32_t c_ent[M];
     uint4 c_rows[M];
-    int c_cnt = 0, c_base = 0, c_end = 0;
+    int c_cnt = 0, c_base = 0, c_end = 0;  // c_end: where `head` moves once the chunk is done (0: nowhere)
     bool have_cur = false;
 
     int guard = n_ops + 8192 + 2 * kPushedCap + 64;
@@ -1404,30 +1403,48 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
             continue;
         }
 
+        IIV_PHASE(0);  // loop overhead, pushed path
         if (!have_cur) {
-            form(head, c_ent, c_cnt, c_base, c_end);
-            if (c_cnt == 0) {
-                head = c_end;
-                continue;
+            if (qi >= n_dense) {
+                refill(head);
+                if (n_dense == 0) {
+                    head = win_end;
+                    continue;
+                }
             }
+            c_cnt = n_dense - qi < M ? n_dense - qi : M;
+#pragma unroll
+            for (int m = 0; m < M; m++) c_ent[m] = take(qi + (m < c_cnt ? m : 0));  // spare slots repeat entry 0
+            qi += c_cnt;
+            c_base = win_base;
+            c_end = qi >= n_dense ? win_end : 0;
 #pragma unroll
             for (int m = 0; m < M; m++) c_rows[m] = wd_rows[((c_ent[m] >> 8) & 31) * 64 + lane];
         }
-        // ---- this chunk's store-table values (slots beyond c_cnt repeat entry 0: branch-free
-        // on purpose, a branch makes the compiler retire each slot's loads before the next slot's)
+        IIV_PHASE(1);  // forming the first chunk + its row loads
+        // ---- this chunk's store-table values (branch-free on purpose: a branch makes the
+        // compiler retire each slot's loads before issuing the next slot's)
         uint32_t ndv[M][4];
 #pragma unroll
         for (int m = 0; m < M; m++) gather4(c_rows[m], c_ent[m] >> 16, ndv[m]);
-        // ---- meanwhile: pick the next chunk and start fetching its rows
+        IIV_PHASE(2);  // waiting for the rows + issuing the store-table loads
+        // ---- meanwhile: start fetching the rows of the next chunk of this window
         uint32_t n_ent[M];
         uint4 n_rows[M];
-        int n_cnt = 0, n_base = 0, n_end = c_end;
-        if (c_end < n_sorted) form(c_end, n_ent, n_cnt, n_base, n_end);
-        if (n_cnt) {
+        const int n_cnt = n_dense - qi < M ? n_dense - qi : M;
+        const int n_base = win_base;
+        int n_end = 0;
+        if (n_cnt > 0) {
+#pragma unroll
+            for (int m = 0; m < M; m++) n_ent[m] = take(qi + (m < n_cnt ? m : 0));
+            qi += n_cnt;
+            n_end = qi >= n_dense ? win_end : 0;
 #pragma unroll
             for (int m = 0; m < M; m++) n_rows[m] = wd_rows[((n_ent[m] >> 8) & 31) * 64 + lane];
         }
+        IIV_PHASE(3);  // next chunk
         twist_now();  // (the MT19937 block generation hides behind the loads)
+        IIV_PHASE(4);  // twist
         // vmcnt is one in-order counter for loads AND stores: retire the gathers once, here,
         // before the steps below start issuing stores.
         // (hipcc does not track a builtin s_waitcnt in its scoreboard, so the loaded
@@ -1442,6 +1459,7 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < M; m++) finish4(c_rows[m], ndv[m]);
+        IIV_PHASE(5);  // waiting for the store-table values
 
         // ---- process the chunk
 #pragma unroll
@@ -1452,6 +1470,7 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
             if (rc == 3) break;
             head = c_base + (int)(c_ent[m] >> 24) + 1;
         }
+        IIV_PHASE(6);  // scoring + applying the chunk
         if (err || done >= n_ops) break;
         head = c_end > head ? c_end : head;
         // the prefetched chunk becomes the current one
@@ -1485,8 +1504,12 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         S.ops += (unsigned long long)done;
         S.pad_ops += pad_ops;
         if (err && S.error == 0) S.error = err;
+#ifdef IIV_STAMPS
+        for (int i = 0; i < 8; i++) S.stamps[8 + i] = ph[i];
+#endif
     }
 }
+#undef IIV_PHASE
 
 // stand-alone packed view of the current screen for IIV_STATE_PACKED: reuse iiv_bitmap's pack
 
