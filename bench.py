@@ -67,7 +67,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("IIV_BENCH_STREAMS", "4096")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("IIV_BENCH_STREAMS", "6144")),
                     help="independent clips per GPU")
     ap.add_argument("--frames-per-step", type=int, default=50)
     ap.add_argument("--mode", choices=["DHGR", "HGR"], default="DHGR")

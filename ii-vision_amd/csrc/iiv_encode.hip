@@ -940,7 +940,7 @@ __global__ __launch_bounds__(256) void greedy_kernel(StreamState *__restrict__ s
 
 #define IIV_SGPR(x) __builtin_amdgcn_readfirstlane((int)(x))
 #ifndef IIV_WAVE_OCC
-#define IIV_WAVE_OCC 5     // waves per SIMD the register allocation is held to
+#define IIV_WAVE_OCC 6     // waves per SIMD the register allocation is held to (<= 80 VGPRs)
 #endif
 #ifndef IIV_WAVE_CHUNK
 #define IIV_WAVE_CHUNK 2   // list entries whose rows and store-table values are fetched together
@@ -1017,14 +1017,14 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
     constexpr uint32_t HI = 0xffff0000u;
     constexpr int M = IIV_WAVE_CHUNK;
     typedef uint32_t __attribute__((aligned(2))) u32_a2;
-    // LDS per stream: two 1 KiB bitmaps + two MT19937 blocks (~7 KiB), so residency is
-    // set by registers, not by LDS.  The per-byte rows a step needs (target window |
+    // LDS per stream: two 1 KiB bitmaps + 1.4 MT19937 blocks (5.7 KiB): 24 streams per CU,
+    // the limit the registers set.  The per-byte rows a step needs (target window |
     // diff weight, written once by the prologue and immutable while the generator
     // lives) are fetched from L2 for a whole chunk at a time.
     __shared__ uint32_t nz[256];     // update_priority != 0
     __shared__ uint32_t pdone[256];  // byte already emitted as a primary (its diff weight counts as 0)
-    __shared__ uint32_t mt[2 * 624];
-    __shared__ uint32_t xw[64];      // compaction of a list window
+    __shared__ uint32_t mt[624 + 256];  // random's current MT19937 block + the first 256 words of the next one
+    __shared__ uint32_t xw[64];         // compaction of a list window
 
     const int lane = threadIdx.x;
     StreamState &S = states[blockIdx.x];
@@ -1040,12 +1040,51 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
     }
     for (int i = lane; i < 624; i += 64) mt[i] = S.mt_py[i];
     __syncthreads();
-    int cb = 0;  // block cb (mt + 624*cb) is current, the other one follows it
-    mt_twist_wave(mt, mt + 624, lane);
+    // A step reads nonces at mt_idx + t, t <= 256 (one per candidate, then <= 2 for the
+    // re-queued bytes), so it can run at most 256 words into the next block: only that much
+    // of it is kept ahead (`ahead`, computable from the current block alone plus itself).
+    // When the current block is used up, the head moves down, the other 368 words are
+    // generated in place (word i needs the old words i, i + 1 and the new word i - 227) and
+    // a new head is generated.
+    uint32_t *ahead = mt + 624;
+    auto gen_ahead = [&]() {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = lane + 64 * k;
+            if (k < 3 || i < 227) ahead[i] = mt[i + 397] ^ mt_mix(mt[i], mt[i + 1]);
+        }
+        wave_lds_sync();
+        {
+            const int i = 192 + lane;
+            if (i >= 227) ahead[i] = ahead[i - 227] ^ mt_mix(mt[i], mt[i + 1]);
+        }
+        wave_lds_sync();
+    };
+    auto gen_rest = [&]() {
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int i = 256 + 64 * k + lane;
+            if (k < 5 || i < 624) {
+                const uint32_t nv = i < 483 ? ahead[i - 227] : mt[i - 227];
+                const uint32_t nx = i == 623 ? ahead[0] : mt[i + 1];
+                const uint32_t v = nv ^ mt_mix(mt[i], nx);
+                wave_lds_sync();  // every lane has read its old words before any lane overwrites one
+                mt[i] = v;
+            }
+            wave_lds_sync();
+        }
+    };
+    auto move_head = [&]() {
+#pragma unroll
+        for (int k = 0; k < 4; k++) mt[lane + 64 * k] = ahead[lane + 64 * k];
+        wave_lds_sync();
+    };
+    gen_ahead();
     int mt_idx = IIV_SGPR(S.mt_py_idx);
     if (mt_idx >= 624) {
-        mt_twist_wave(mt + 624, mt, lane);
-        cb = 1;
+        move_head();
+        gen_rest();
+        gen_ahead();
         mt_idx -= 624;
     }
 
@@ -1169,11 +1208,12 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
 #else
 #define IIV_PHASE(i) do { } while (0)
 #endif
-    // block cb is current; block cb ^ 1 must follow it before a step can read past word 623
+    // after a block switch only words 0..255 of the current block are in place until twist_now()
     bool twist_pending = false;
     auto twist_now = [&]() {
         if (twist_pending) {
-            mt_twist_wave(mt + 624 * cb, mt + 624 * (cb ^ 1), lane);
+            gen_rest();
+            gen_ahead();
             twist_pending = false;
         }
     };
@@ -1185,7 +1225,7 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         const int y1e = y1 >= 0 ? y1 : x, y2e = y2 >= 0 ? y2 : x;   // video.py:185-186
         const int f1 = v1 ? 1 : 0, f2 = v2 ? 1 : 0;
         if (n_pushed + f1 + f2 > kPushedCap) return false;
-        if (mt_idx + C + 2 >= 624) twist_now();
+        if (mt_idx + C + 2 >= 256) twist_now();
         if (lane < 3) {
             const int off = lane == 0 ? x : lane == 1 ? y1e : y2e;
             const uint32_t val = lane == 0 ? 0u : lane == 1 ? v1 : v2;
@@ -1195,9 +1235,7 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
                 atomicAnd(&nz[p * 8 + (off >> 5)], ~(1u << (off & 31)));
             } else {
                 const int k = lane == 2 ? f1 : 0;
-                int j = mt_idx + cb * 624 + C + k;
-                if (j >= 1248) j -= 1248;
-                const uint32_t nonce = mt_temper(mt[j]) >> 24;  // video.py:178
+                const uint32_t nonce = mt_temper(mt[mt_idx + C + k]) >> 24;  // video.py:178
                 S.pushed[n_pushed + k] = ((2047u - val) << 21) | (nonce << 13) | ((uint32_t)p << 8) | (uint32_t)off;
             }
             if (lane == 0) atomicOr(&pdone[p * 8 + (x >> 5)], 1u << (x & 31));
@@ -1213,10 +1251,10 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         done++;
         if (done - ob_base == 64) flush_ops();
         if (mt_idx >= 624) {
-            // the following block becomes the current one; the block after it is generated
-            // later, while store-table loads are in flight (twist_now), at the latest before
-            // the next step reads nonces
-            cb ^= 1;
+            // the next block becomes the current one: its head moves down now, the rest of it
+            // and the new head are generated later, while store-table loads are in flight
+            // (twist_now), at the latest before a step reads past word 255
+            move_head();
             mt_idx -= 624;
             twist_pending = true;
         }
@@ -1276,10 +1314,10 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         score(w, nd, p, x, kt, ke, C, &below);  // the entry was live a moment ago: still is
         // one random.getrandbits(8) per candidate in ascending offset (video.py:290-293)
         uint32_t key[4];
-        int run = mt_idx + cb * 624 + below;
+        int run = mt_idx + below;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const int fj = run >= 1248 ? run - 1248 : run;
+            const int fj = run;
             run += kt[r] < 0 ? 1 : 0;
             const uint32_t nonce = mt_temper(mt[fj]) >> 24;
             const uint32_t k = ((uint32_t)((ke[r] >> 16) + 2048) << 16) | (nonce << 8) | (uint32_t)(y0 + r);
@@ -1488,12 +1526,13 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
     }
 
     flush_ops();
+    twist_now();
     __syncthreads();
     for (int i = lane; i < 256; i += 64) {
         S.nzbits[i] = nz[i];
         S.pdone[i] = pdone[i];
     }
-    for (int i = lane; i < 624; i += 64) S.mt_py[i] = mt[624 * cb + i];
+    for (int i = lane; i < 624; i += 64) S.mt_py[i] = mt[i];
     if (lane == 0) {
         S.mt_py_idx = mt_idx;
         S.head = head;
