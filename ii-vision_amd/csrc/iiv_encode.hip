@@ -55,7 +55,7 @@ struct StreamState {
     int32_t pad_content;      // target[0,0] of the live generator's bank (video.py:249)
     int32_t truncated;        // order[] holds only the top of the list (prefix sort)
     unsigned long long draws_py, draws_np, ops, pad_ops;
-    unsigned long long stamps[16];  // diagnostic builds only (-DIIV_STAMPS): s_memtime at phase boundaries
+    unsigned long long stamps[32];  // diagnostic builds only (-DIIV_STAMPS): prologue s_memtime stamps [0,16), greedy phase cycles [16,24)
 };
 
 enum { kErrNone = 0, kErrHoles = 1, kErrNegative = 2, kErrPaletteBit = 3, kErrPushedOverflow = 4, kErrNoGenerator = 5, kErrGuard = 6, kErrSortBudget = 7 };
@@ -1544,7 +1544,7 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         S.pad_ops += pad_ops;
         if (err && S.error == 0) S.error = err;
 #ifdef IIV_STAMPS
-        for (int i = 0; i < 8; i++) S.stamps[8 + i] = ph[i];
+        for (int i = 0; i < 8; i++) S.stamps[16 + i] = ph[i];
 #endif
     }
 }
@@ -1762,7 +1762,7 @@ static int state_item(int mode, int what, size_t &off, size_t &bytes, bool &writ
         off = offsetof(StreamState, up[1]); bytes = 8192 * 4; return 0;
     case IIV_STATE_OUT_OF_WORK: off = offsetof(StreamState, out_of_work); bytes = 8; return 0;
     case IIV_STATE_COUNTERS: off = offsetof(StreamState, draws_py); bytes = 32; writable = false; return 0;
-    case 100: off = offsetof(StreamState, stamps); bytes = 128; writable = false; return 0;  // diagnostic
+    case 100: off = offsetof(StreamState, stamps); bytes = 256; writable = false; return 0;  // diagnostic
     default: return -1;
     }
 }

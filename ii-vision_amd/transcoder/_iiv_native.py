@@ -280,7 +280,7 @@ class Encoder:
         STATE_RNG_PY: ((625,), np.uint32), STATE_RNG_NP: ((625,), np.uint32),
         STATE_OUT_OF_WORK: ((2,), np.int32), STATE_PACKED: ((32, 128), np.uint64),
         STATE_COUNTERS: ((4,), np.uint64),
-        100: ((16,), np.uint64),  # phase stamps of diagnostic (-DIIV_STAMPS) builds
+        100: ((32,), np.uint64),  # phase stamps of diagnostic (-DIIV_STAMPS) builds
     }
 
     def get_state(self, what, stream=0, out=None):
