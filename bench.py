@@ -139,16 +139,21 @@ def main():
     def run_step():
         return batch.encode_frames(fm, fa, F, ops_buf)
 
-    for _ in range(args.warmup):
-        run_step()
+    first_ops = None   # stream 0's opcodes of the first F frames, checked against the oracle below
+    for i in range(args.warmup):
+        _, segs0 = run_step()
+        if i == 0:   # (streams are packed at the call's own opcode count, see iiv_encode)
+            first_ops = ops_buf.view(-1)[: 6 * sum(s[3] for s in segs0)].clone().view(-1, 6)
     batch.enc.check()
     batch.enc.profile(True)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     op_count, seg_count = 0, 0
-    for _ in range(args.steps):
+    for i in range(args.steps):
         _, segs = run_step()
+        if first_ops is None and i == 0:   # (only when there is no warm-up step; async D2D copy)
+            first_ops = ops_buf.view(-1)[: 6 * sum(s[3] for s in segs)].clone().view(-1, 6)
         op_count += sum(s[3] for s in segs)
         seg_count += len(segs)
     torch.cuda.synchronize()
@@ -235,7 +240,8 @@ def main():
             out["single_stream"] = _single_stream(native, stream_batch, mode, table, store, dm, dhgr, args)
 
         if not args.no_cpu_baseline and n_gpus == 1:
-            out["cpu_baseline"] = _cpu_baseline(mode, dhgr, fm, fa, seeds[0], args, ops_check=None)
+            out["cpu_baseline"] = _cpu_baseline(mode, dhgr, fm, fa, seeds[0], args,
+                                                ops_check=(first_ops.cpu().numpy(), F))
             out["cpu_baseline_all_cores"] = _cpu_baseline_all_cores(mode, dhgr, fm, fa, seeds, args)
 
         print(json.dumps(out))
@@ -282,11 +288,21 @@ def _cpu_baseline(mode, dhgr, fm, fa, seed, args, ops_check):
     v = O.Video(mode, tab, seed_py=seed[0], seed_np=seed[1])
     segs = stream_batch.MovieClock(dhgr).segments(n)
     t0 = time.perf_counter()
+    got = []
     for (fr, ia, _, k) in segs:
         v.encode_frame(main[fr], aux[fr] if aux is not None else None, ia)
-        v.next(k)
+        got.append(v.next(k))
     dt = time.perf_counter() - t0
+    parity = None
+    if ops_check is not None:
+        # the oracle as the checker: the GPU's opcode stream of this clip's first frames, bit for bit
+        gpu_ops, nf = ops_check
+        cpu_ops = np.concatenate(got)[: gpu_ops.shape[0]]
+        parity = {"stream": 0, "frames": int(min(nf, n)), "opcodes": int(cpu_ops.shape[0]),
+                  "equal": bool(cpu_ops.shape == gpu_ops[: cpu_ops.shape[0]].shape
+                                and (cpu_ops == gpu_ops[: cpu_ops.shape[0]]).all())}
     return {
+        "parity_vs_oracle": parity,
         "value": n / dt,
         "unit": "frames/s",
         "cores": 1,
