@@ -102,6 +102,48 @@ template <int N> struct EditStep<N, N> {
     __device__ static inline void run(uint64_t, uint32_t, uint64_t, uint32_t, const uint16_t *, uint32_t &, uint32_t &) {}
 };
 
+// The same recurrence for strings delivered one pixel per byte and already paired:
+// byte j of xs[g] = a << 4 | b of pixel 4g + j (exactly the index into lut), so a step
+// needs one byte extract for the lookup, and its transposition test -- a_{k-1} == b_k and
+// a_k == b_{k-1} -- is "this byte equals the previous byte with its nibbles swapped".
+// G = number of 32-bit groups, LAST = pixels in the last group.
+template <int K, int N> struct EditStepBytes {
+    template <typename X>
+    __device__ static inline void run(const X &xs, const X &ys, const uint16_t *lut, uint32_t &e1, uint32_t &e2)
+    {
+        const uint32_t idx = (xs[K >> 2] >> (8 * (K & 3))) & 0xffu;
+        uint32_t e = e1 + (uint32_t)lut[idx];
+        if (K >= 1) {
+            const uint32_t prev_swapped = (ys[(K - 1) >> 2] >> (8 * ((K - 1) & 3))) & 0xffu;
+            const uint32_t t = e2 + 1;
+            if (idx == prev_swapped && t < e) e = t;
+        }
+        e2 = e1;
+        e1 = e;
+        EditStepBytes<K + 1, N>::run(xs, ys, lut, e1, e2);
+    }
+};
+template <int N> struct EditStepBytes<N, N> {
+    template <typename X>
+    __device__ static inline void run(const X &, const X &, const uint16_t *, uint32_t &, uint32_t &) {}
+};
+
+// pixel p of the string sits in byte p % 4 of group p / 4 (groups may be partly filled: the
+// caller lays the pixels out so that N consecutive byte slots are used)
+template <int N, int G>
+__device__ inline uint32_t edit_distance_bytes(const uint32_t (&src)[G], const uint32_t (&tgt)[G], const uint16_t *lut)
+{
+    uint32_t xs[G], ys[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        xs[g] = (src[g] << 4) | tgt[g];
+        ys[g] = ((xs[g] & 0x0f0f0f0fu) << 4) | ((xs[g] >> 4) & 0x0f0f0f0fu);
+    }
+    uint32_t e1 = 0, e2 = 0;
+    EditStepBytes<0, N>::run(xs, ys, lut, e1, e2);
+    return e1;
+}
+
 template <int N>
 __device__ inline uint32_t edit_distance(uint64_t alo, uint32_t ahi, uint64_t blo, uint32_t bhi, const uint16_t *lut)
 {

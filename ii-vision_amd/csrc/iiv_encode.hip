@@ -270,19 +270,27 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
     IIV_STAMP(11);
     // DHGR colour strings from three LDS lookups instead of ten rotates: pixels 0..3
     // depend on dots 0..6, pixels 4..6 on dots 4..9, pixels 7..9 on dots 7..12
-    // (colours.py:100-134).  slut[odd][0..127 | 128..191 | 192..255].
-    uint16_t *slut = reinterpret_cast<uint16_t *>(aux4k);
+    // (colours.py:100-134).  slut[odd][0..127 | 128..191 | 192..255], one pixel per byte.
+    // The ten pixels of a string occupy byte slots 0..9 of three words: pixels 0..3 in word
+    // 0, 4..6 in bytes 0..2 of word 1, 7 in byte 3 of word 1, 8..9 in word 2 -- so the
+    // third LUT delivers a pair (lo: pixel 7 in byte 3; hi: pixels 8, 9).
+    uint32_t *slut = aux4k;  // 2 parities x (128 + 64) words + 2 x 64 x 2 words = 2.5 KiB
     if (DP && MODE == kDHGR && tid < 512) {
         const int odd = tid >> 8, e = tid & 255;
         const int ph = phase_of(kDHGR, byte_offset<kDHGR>(odd, is_aux));
         const int k0 = e < 128 ? 0 : e < 192 ? 4 : 7, nk = e < 128 ? 4 : 3;
         const uint32_t v = e < 128 ? e : (e - 128) & 63;
-        uint32_t out = 0;
+        uint32_t px[4] = {0, 0, 0, 0};
         for (int k = 0; k < nk; k++) {
             const uint32_t win = (v >> k) & 0xf;
-            out |= (((win | (win << 4)) >> (4 - ((ph + k0 + k) & 3))) & 0xf) << (4 * k);
+            px[k] = ((win | (win << 4)) >> (4 - ((ph + k0 + k) & 3))) & 0xf;
         }
-        slut[tid] = (uint16_t)out;
+        if (e < 192) {
+            slut[odd * 320 + e] = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+        } else {
+            slut[odd * 320 + 192 + 2 * (e - 192)] = px[0] << 24;
+            slut[odd * 320 + 192 + 2 * (e - 192) + 1] = px[1] | (px[2] << 8);
+        }
     }
     __syncthreads();
     IIV_STAMP(1);
@@ -294,7 +302,7 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
     // the first 512 threads score one of those bytes each on top of their own eight and hand the
     // diff weight over through LDS.
     const bool mt_wave = tid >= kProThreads - 64;
-    uint16_t *dwx = reinterpret_cast<uint16_t *>(aux4k + 512);
+    uint16_t *dwx = reinterpret_cast<uint16_t *>(aux4k + 768);  // (the string LUTs end at word 640)
 
     int32_t upv[8];
     {
@@ -332,12 +340,12 @@ __global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *_
         if (cm == tm) return 0u;
         if (MODE == kDHGR) {
             // DHGR windows are already dot strings (screen.py:983-990)
-            const uint16_t *sl = slut + 256 * odd;
-            const uint64_t alo = (uint64_t)sl[cm & 127] | ((uint64_t)sl[128 + ((cm >> 4) & 63)] << 16) |
-                                 ((uint64_t)sl[192 + (cm >> 7)] << 28);
-            const uint64_t blo = (uint64_t)sl[tm & 127] | ((uint64_t)sl[128 + ((tm >> 4) & 63)] << 16) |
-                                 ((uint64_t)sl[192 + (tm >> 7)] << 28);
-            return edit_distance<ModeTraits<MODE>::kDots>(alo, 0u, blo, 0u, lut);
+            const uint32_t *sl = slut + 320 * odd;
+            const uint2 ca = reinterpret_cast<const uint2 *>(sl + 192)[cm >> 7];
+            const uint2 ct = reinterpret_cast<const uint2 *>(sl + 192)[tm >> 7];
+            const uint32_t src[3] = {sl[cm & 127], sl[128 + ((cm >> 4) & 63)] | ca.x, ca.y};
+            const uint32_t tgt[3] = {sl[tm & 127], sl[128 + ((tm >> 4) & 63)] | ct.x, ct.y};
+            return edit_distance_bytes<ModeTraits<MODE>::kDots, 3>(src, tgt, lut);
         }
         const ulonglong2 *Sg = strings + ((size_t)o << BITS);
         const ulonglong2 a = Sg[cm], b = Sg[tm];
