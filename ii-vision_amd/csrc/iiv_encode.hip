@@ -1130,9 +1130,6 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
                 const int r = ORD[k];
                 const uint32_t t = *wr[r] & 0xffffu;
                 const uint32_t q = (t * 43691u) >> 17;  // t / 3 for t < 2^16
-#ifdef IIV_PROBE_SKIP3
-                if (r == 3) { nd[r] = 0x3fffffffu; } else
-#endif
                 nd[r] = reinterpret_cast<const uint32_t *>(r & 1 ? sd : se)[q];
                 *wr[r] = (*wr[r] & HI) | ((t - 3u * q) * 10u);
             }
