@@ -128,8 +128,10 @@ void iiv_encoder_destroy(iiv_encoder *enc);
                                  * 3B <= 2048, only that many highest priorities are ordered;
                                  * 0: always order the whole list.  Same output either way. */
 #define IIV_OPT_PACKED_STORE 4   /* 1 (default): the one-wave greedy kernel reads a 10-bit repack of
-                                 * the DHGR store table made at creation (3 values per 32-bit word;
-                                 * used only if every value fits, d_store must not change afterwards);
+                                 * the store table made at creation (3 values per 32-bit word, a
+                                 * per-word base and an escape to d_store where 10 bits do not do;
+                                 * HGR lookups are also folded onto one half of the symmetric
+                                 * table).  d_store must not change while the encoder lives.
                                  * 0: it reads d_store itself.  Same output either way. */
 int iiv_encoder_set_option(iiv_encoder *enc, int option, int value);
 

@@ -84,6 +84,28 @@ def test_table_symmetry_properties(native, device_tables):
         assert int(torch.diagonal(m).abs().sum()) == 0
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_store_table_content_body_symmetry(native, device_tables, mode):
+    """The property the HGR wave kernel relies on to touch only half of its store table:
+    S[o][c][(h, B, f)] == S[o][c'][(h, C, f)], C = content c in window form, c' = the byte whose
+    window form is the body B (HGR odd bytes sit rotated by one bit in their window)."""
+    _, s = device_tables.get(mode)
+    L = native.lib()
+    bits, noff = L.iiv_masked_bits(mode), L.iiv_num_offsets(mode)
+    cb = 7 if mode == 1 else 8
+    S = native.table_to_numpy(s).reshape(noff, 1 << cb, 1 << bits)
+    bm = (1 << cb) - 1
+    t = np.arange(1 << bits, dtype=np.int64)
+    B = (t >> 3) & bm
+    for o in range(noff):
+        rot = mode == 0 and o == 1
+        cprime = ((B >> 1) | ((B & 1) << 7)) if rot else B
+        for c in range(0, 1 << cb, 5):
+            C = (((c & 0x7f) << 1) | (c >> 7)) if rot else c
+            tprime = (t & ~(bm << 3)) | (C << 3)
+            assert np.array_equal(S[o, c, t], S[o, cprime, tprime]), (o, c)
+
+
 def test_rejects_bad_arguments(native):
     with pytest.raises(native.IIVError):
         native.build_table(1, np.full(256, 500, np.int32))  # 500*10 > 2047
