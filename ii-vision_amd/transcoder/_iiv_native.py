@@ -258,7 +258,8 @@ class Encoder:
         check(lib().iiv_encoder_set_option(self._h, OPT_PREFIX_SORT, 1 if enable else 0))
 
     def set_packed_store(self, enable):
-        check(lib().iiv_encoder_set_option(self._h, OPT_PACKED_STORE, 1 if enable else 0))
+        """False / True, or 2 = packed in the base + escape form even if 10 bits suffice."""
+        check(lib().iiv_encoder_set_option(self._h, OPT_PACKED_STORE, int(enable)))
 
     def set_diff_weights_mode(self, recurrence):
         check(lib().iiv_encoder_set_option(self._h, OPT_DIFF_WEIGHTS, DW_RECURRENCE if recurrence else DW_TABLE))

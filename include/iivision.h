@@ -132,7 +132,8 @@ void iiv_encoder_destroy(iiv_encoder *enc);
                                  * per-word base and an escape to d_store where 10 bits do not do;
                                  * HGR lookups are also folded onto one half of the symmetric
                                  * table).  d_store must not change while the encoder lives.
-                                 * 0: it reads d_store itself.  Same output either way. */
+                                 * 0: it reads d_store itself.  2: like 1, but always in the
+                                 * base + escape form (tests).  Same output either way. */
 int iiv_encoder_set_option(iiv_encoder *enc, int option, int value);
 
 /* state items, per stream */

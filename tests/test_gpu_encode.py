@@ -53,12 +53,12 @@ def _next_draws(O, words, n, high):
 
 
 @pytest.mark.parametrize("recurrence,wave,packed", [(True, True, True), (False, True, True), (True, False, True),
-                                                    (True, True, False)])
+                                                    (True, True, False), (True, True, 2)])
 def test_golden_runs(native, O, golden, device_tables, recurrence, wave, packed):
     """recurrence=True: diff weights recomputed in the prologue; False: gathered from
     the HBM table.  wave=True: one wave per stream; False: one 256-thread workgroup
-    per stream.  packed: the wave kernel reads the 10-bit repack of the DHGR store table
-    or the u16 table itself.  Every combination must reproduce the reference bit for bit."""
+    per stream.  packed: the wave kernel reads the 10-bit repack of the store table (2: in its
+    base + escape form even where 10 bits suffice) or the u16 table itself.  Every combination must reproduce the reference bit for bit."""
     g3 = golden.g3_encode_runs
     for tag in _tags(g3):
         mode, pal, sp, sn = (int(x) for x in g3[tag + "/meta"])
