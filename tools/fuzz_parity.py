@@ -1,0 +1,82 @@
+"""Randomised differential run: GPU (through the C ABI) against the oracle, many seeds,
+ragged schedules, all input kinds, both kernels and table forms.  The oracle here is the
+checker (same role as in tests/); run on an MI355X:  python tools/fuzz_parity.py [rounds]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "ii-vision_amd", "transcoder")):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+import oracle as O  # noqa: E402
+import _iiv_native as native  # noqa: E402
+import stream_batch  # noqa: E402
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+rng = np.random.default_rng(2026)
+O.build()
+dms = {pal: O.cie2000_matrix(O.PALETTE_RGB[pal])[1] for pal in (5, 0)}
+otab, dtab = {}, {}
+t_start = time.time()
+total_ops = 0
+for rnd in range(rounds):
+    mode = int(rng.integers(0, 2))
+    pal = 5 if rng.random() < 0.7 else 0
+    key = (mode, pal)
+    if key not in otab:
+        otab[key] = O.build_table(mode, dms[pal], symmetric=True)
+        dtab[key] = (native.build_table(mode, dms[pal], True), native.build_store_table(mode, dms[pal]))
+    n, nf = 8, 4
+    kind = ("iid", "coh", "img")[int(rng.integers(0, 3))]
+    if kind == "img":
+        fm, fa = stream_batch.synth_frames_img(n, nf, mode == 1, seed=int(rng.integers(1 << 30)), device="cpu")
+    else:
+        fm, fa = stream_batch.synth_frames_torch(n, nf, mode == 1, seed=int(rng.integers(1 << 30)),
+                                                 coherent=kind == "coh", device="cpu")
+    # schedule: (frame, is_aux, restart, n_ops) with ragged lengths, continued generators, zero-length creations
+    sched, f, ia = [], 0, 0
+    for _ in range(int(rng.integers(4, 10))):
+        k = int(rng.choice([0, 1, 2, 63, 64, 65, 127, 200, 292, 490, 700, 1500]))
+        restart = 1 if not sched or rng.random() < 0.7 else 0
+        if restart:
+            f = int(rng.integers(0, nf))
+            ia = int(rng.integers(0, 2)) if mode == 1 else 0
+        sched.append((f, ia, restart, k))
+    wave = bool(rng.random() < 0.75)
+    packed = int(rng.choice([0, 1, 1, 2]))
+    recurrence = bool(rng.random() < 0.8)
+    prefix = bool(rng.random() < 0.7)
+    enc = native.Encoder(mode, dtab[key][0], dtab[key][1], n, dm=dms[pal] if recurrence else None)
+    enc.set_greedy_kernel(wave)
+    enc.set_packed_store(packed)
+    enc.set_prefix_sort(prefix)
+    seeds = [(int(rng.integers(1 << 20)), int(rng.integers(1 << 20))) for _ in range(n)]
+    for i, (sp, sn) in enumerate(seeds):
+        enc.set_state(native.STATE_RNG_PY, O.mt_seed_py(sp).state_words(), i)
+        enc.set_state(native.STATE_RNG_NP, O.mt_seed_np(sn).state_words(), i)
+    got = enc.encode(fm.cuda(), fa.cuda() if fa is not None else None, sched).cpu().numpy()
+    enc.check()
+    for i in range(n):
+        v = O.Video(mode, otab[key], seed_py=seeds[i][0], seed_np=seeds[i][1])
+        exp = []
+        for (fr, a, restart, k) in sched:
+            if restart:
+                v.encode_frame(fm[i, fr].numpy(), fa[i, fr].numpy() if fa is not None else None, a)
+            if k:
+                exp.append(v.next(k))
+        exp = np.concatenate(exp) if exp else np.zeros((0, 6), np.uint8)
+        assert (got[i] == exp).all(), ("opcodes", rnd, i, mode, pal, kind, wave, packed, recurrence, prefix, sched)
+        assert (enc.get_state(native.STATE_UP_MAIN, i) == v.update_priority(0)).all(), ("up", rnd, i)
+        assert (enc.get_state(native.STATE_MEM_MAIN, i) == v.memory(0)).all(), ("mem", rnd, i)
+        if mode == 1:
+            assert (enc.get_state(native.STATE_UP_AUX, i) == v.update_priority(1)).all(), ("up aux", rnd, i)
+        cnt = enc.get_state(native.STATE_COUNTERS, i)
+        assert (int(cnt[0]), int(cnt[1])) == v.draws(), ("draws", rnd, i)
+        total_ops += exp.shape[0]
+    enc.close()
+    print("round %2d ok: mode=%s pal=%d %s wave=%d packed=%d rec=%d prefix=%d segs=%s" % (
+        rnd, "DHGR" if mode else "HGR", pal, kind, wave, packed, recurrence, prefix, [s[3] for s in sched]), flush=True)
+print("fuzz parity: %d rounds, %d opcodes compared, all equal (%.0f s)" % (rounds, total_ops, time.time() - t_start))
