@@ -8,14 +8,18 @@ and `encode_frame` is still a lazy, never-ending generator of
 greedy selection loop and both MT19937 nonce streams -- runs in the gfx950 kernels
 of csrc/iiv_encode.hip through iiv_encode() (include/iivision.h).
 
-State model: between device calls the host numpy arrays and Python's / NumPy's
-global RNG states are authoritative, exactly as in the reference, so code that
-pokes `video.memory_map.page_offset` or reseeds `random` keeps working; each device
-call uploads them, runs, and downloads them back *in place*.
+State model: the device holds the live state while a generator runs; the host numpy
+arrays (memory maps, update priorities, pixelmap.packed, out_of_work) and Python's /
+NumPy's global RNG states are brought up to date *when somebody looks*: reading any of
+the state attributes, starting another generator (its prologue uploads the host state,
+so code that pokes `video.memory_map.page_offset` or reseeds `random` between frames
+keeps working) -- the same points at which the reference's caller (movie.py) looks.
+`Video.STRICT_SYNC = True` restores the literal behaviour (every next() round-trips the
+whole state, global RNG states included), at about 1.5 k opcodes per second.
 
 Budget: a generator may be abandoned after any next() (movie.py:94-109 does so at
 every frame and bank flip), and its side effects must then be exactly those of
-the opcodes consumed.  Without a hint every next() is therefore one device call.
+the opcodes consumed.  Without a hint every next() is therefore one device step.
 `encode_frame(target, is_aux, budget=K)` promises that K opcodes will be pulled;
 they are then computed by one launch.  `Video.SPECULATE = N` (opt-in) gets batched
 launches without a promise: N opcodes are produced from a device-side snapshot
@@ -44,9 +48,14 @@ class Video:
     #: from a device-side snapshot; if the generator is abandoned (or any state
     #: attribute is read) after k < N of them were consumed, the snapshot is restored
     #: and exactly k are replayed, so observable state is always that of the consumed
-    #: opcodes.  (The *global* random / np.random states are only re-synchronised at
-    #: those points, hence opt-in.)
+    #: opcodes.
     SPECULATE = 0
+
+    #: True: after every next() the host arrays and the *global* random / np.random states
+    #: are those of the reference at that point (one full state round trip per opcode).
+    #: False (default): they are synchronised whenever a state attribute is read or another
+    #: generator starts.
+    STRICT_SYNC = False
 
     def __init__(
             self,
@@ -64,6 +73,8 @@ class Video:
         self.frame_number = 0  # type: int
         self.palette = palette  # type: Palette
         self._pending = None  # speculative chunk not yet fully consumed
+        self._host_current = True  # host arrays / global RNG states equal the device's
+        self._touched = True  # a state attribute was handed out since the last upload
 
         # Empty screen (video.py:37-53); the pixelmap aliases the memory maps
         self._memory_map = screen.MemoryMap(screen_page=1)
@@ -93,10 +104,12 @@ class Video:
     def _settled(name):  # noqa: N805
         def get(self):
             self._settle()
+            self._touched = True  # the caller may change what it gets
             return getattr(self, name)
 
         def set_(self, value):
             self._settle()
+            self._touched = True
             setattr(self, name, value)
         return property(get, set_)
 
@@ -110,6 +123,7 @@ class Video:
         if self._aux_memory_map is None:
             raise AttributeError("aux_memory_map")  # HGR Video has none (video.py:40-42)
         self._settle()
+        self._touched = True
         return self._aux_memory_map
 
     @property
@@ -117,6 +131,7 @@ class Video:
         if self._aux_update_priority is None:
             raise AttributeError("aux_update_priority")
         self._settle()
+        self._touched = True
         return self._aux_update_priority
 
     del _settled
@@ -141,8 +156,12 @@ class Video:
         st = np.random.get_state()
         e.set_state(native.STATE_RNG_NP,
                     np.concatenate([np.asarray(st[1], dtype=np.uint32), np.array([st[2]], dtype=np.uint32)]))
+        # movie.py:96 resets the flags at every frame
+        e.set_state(native.STATE_OUT_OF_WORK,
+                    np.array([int(bool(self._out_of_work[False])), int(bool(self._out_of_work[True]))], dtype=np.int32))
+        self._touched = False
 
-    def _download(self, is_aux):
+    def _download(self):
         e = self._enc
         # in place: callers (and self.pixelmap) hold references to these arrays
         self._memory_map.page_offset[...] = e.get_state(native.STATE_MEM_MAIN)
@@ -156,39 +175,32 @@ class Video:
         st = np.random.get_state()
         np.random.set_state((st[0], npw[:624].copy(), int(npw[624]), st[3], st[4]))
         oow = e.get_state(native.STATE_OUT_OF_WORK)
-        if oow[1 if is_aux else 0]:
-            self._out_of_work[bool(is_aux)] = True  # video.py:189
+        self._out_of_work[False] = bool(oow[0])  # video.py:189
+        self._out_of_work[True] = bool(oow[1])
+        self._host_current = True
 
-    def _launch(self, target, is_aux, restart, n_ops):
+    def _launch(self, token, restart, n_ops):
         """[prologue +] n_ops greedy steps on the device state as it stands."""
-        import torch
-        main = np.ascontiguousarray(target.main_memory.page_offset, dtype=np.uint8)
-        fm = torch.from_numpy(main[None, None]).cuda()
-        fa = None
-        if self.mode == VideoMode.DHGR:
-            aux = np.ascontiguousarray(target.aux_memory.page_offset, dtype=np.uint8)
-            fa = torch.from_numpy(aux[None, None]).cuda()
-        # a generator's out_of_work flag on the device must reflect the host's (movie.py:96 resets it)
-        ops = self._enc.encode(fm, fa, [(0, int(bool(is_aux)), int(restart), int(n_ops))])
+        ops = self._enc.encode(token.fm, token.fa, [(0, int(bool(token.is_aux)), int(restart), int(n_ops))])
         self._enc.check()
+        self._host_current = False
         return ops[0].cpu().numpy()
 
     def _settle(self):
         """Make host state reflect exactly the opcodes consumed so far."""
         p = self._pending
-        if p is None:
-            return
         self._pending = None
-        if p["consumed"] == p["produced"]:
-            return
-        # abandoned mid-chunk: restore the snapshot and replay only what was consumed
-        self._enc.rollback()
-        if p["consumed"]:
-            self._launch(p["target"], p["is_aux"], p["restart"], p["consumed"])
-        elif p["restart"]:
-            self._live = p["prev_live"]  # the prologue never happened
-            p["token"].started = False
-        self._download(p["is_aux"])
+        if p is not None and p["consumed"] < p["produced"]:
+            # abandoned mid-chunk: restore the snapshot and replay only what was consumed
+            self._enc.rollback()
+            self._host_current = False
+            if p["consumed"]:
+                self._launch(p["token"], p["restart"], p["consumed"])
+            elif p["restart"]:
+                self._live = p["prev_live"]  # the prologue never happened
+                p["token"].started = False
+        if not self._host_current:
+            self._download()
 
     # ------------------------------------------------------------------ encode
 
@@ -214,30 +226,43 @@ class Video:
         yield from self._index_changes(target, is_aux, budget)
 
     def _index_changes(self, target_pixelmap, is_aux, budget):
+        import torch
+
         class _Token:
             started = False
 
         token = _Token()
+        token.is_aux = bool(is_aux)
+        # the target stays on the device for the generator's life
+        main = np.ascontiguousarray(target_pixelmap.main_memory.page_offset, dtype=np.uint8)
+        token.fm = torch.from_numpy(main[None, None].copy()).cuda()
+        token.fa = None
+        if self.mode == VideoMode.DHGR:
+            aux = np.ascontiguousarray(target_pixelmap.aux_memory.page_offset, dtype=np.uint8)
+            token.fa = torch.from_numpy(aux[None, None].copy()).cuda()
         chunk = int(budget) if budget else max(1, int(self.SPECULATE))
-        speculative = not budget and chunk > 1
+        speculative = not budget and chunk > 1 and not self.STRICT_SYNC
         while True:
-            self._settle()
             restart = 0 if self._live is token else 1
             if restart and token.started:
                 raise RuntimeError("this encode_frame() generator cannot be resumed: another generator "
                                    "has run on this Video since (the reference's heap is not kept)")
             prev_live = self._live
-            self._upload()
+            if restart or self._pending is not None:
+                self._settle()  # the previous generator's speculation ends here
+            if restart or self._touched or self.STRICT_SYNC:
+                self._settle()
+                self._upload()
             if speculative:
                 self._enc.snapshot()
-            ops = self._launch(target_pixelmap, is_aux, restart, chunk)
+            ops = self._launch(token, restart, chunk)
             self._live = token
             token.started = True
-            self._download(is_aux)
+            if self.STRICT_SYNC:
+                self._download()
             rec = None
             if speculative:
-                rec = dict(token=token, target=target_pixelmap, is_aux=is_aux, restart=restart,
-                           consumed=0, produced=len(ops), prev_live=prev_live)
+                rec = dict(token=token, restart=restart, consumed=0, produced=len(ops), prev_live=prev_live)
                 self._pending = rec
             for k in range(len(ops)):
                 if rec is not None:

@@ -83,7 +83,7 @@ def test_bitmap_apply_and_delta(golden, name):
     assert (mm.page_offset == g[name + "_apply_main"]).all()
 
 
-def _drive(tag, golden, budgeted, speculate=0, peek=False):
+def _drive(tag, golden, budgeted, speculate=0, peek=False, strict=False):
     import palette
     import screen
     import video
@@ -96,6 +96,7 @@ def _drive(tag, golden, budgeted, speculate=0, peek=False):
     np.random.seed(sn)
     v = video.Video(_FG(), ticks_per_second=14700., mode=vm, palette=palette.Palette(pal))
     v.SPECULATE = speculate
+    v.STRICT_SYNC = strict
     got = []
     with contextlib.redirect_stdout(io.StringIO()):
         for fi, ia, n in sched:
@@ -131,6 +132,47 @@ def test_video_lazy_generator_exact_without_budget(golden):
     """Default (no budget hint): every next() is exact, generators can be abandoned
     after any opcode (movie.py:94-109)."""
     _drive("DHGR_single_ops", golden, budgeted=False)
+
+
+def _draws(O, words, n=4):
+    """the next n random.getrandbits(8) of an MT19937 state given as random.getstate()[1]"""
+    import ctypes as C
+    m = O.MT()
+    m.set_state_words(words)
+    return [O.lib().orc_py_getrandbits8(C.byref(m)) for _ in range(n)]
+
+
+def test_video_strict_sync(golden):
+    """Video.STRICT_SYNC: after every next() the host arrays and the global random / np.random
+    states are the reference's at that point (checked against an oracle stepped alongside)."""
+    import palette
+    import screen
+    import video
+    import video_mode
+    import oracle as O
+    g3 = golden.g3_encode_runs
+    tag = "DHGR_single_ops"
+    mode, pal, sp, sn = (int(x) for x in g3[tag + "/meta"])
+    frames, sched = g3[tag + "/frames"], g3[tag + "/schedule"]
+    random.seed(sp)
+    np.random.seed(sn)
+    v = video.Video(_FG(), ticks_per_second=14700., mode=video_mode.VideoMode.DHGR, palette=palette.Palette(pal))
+    v.STRICT_SYNC = True
+    _, dm = O.cie2000_matrix(O.PALETTE_RGB[pal])
+    ref = O.Video(1, O.build_table(1, dm, symmetric=True), seed_py=sp, seed_np=sn)
+    with contextlib.redirect_stdout(io.StringIO()):
+        for fi, ia, n in sched[:6]:
+            tgt = screen.DHGRBitmap(main_memory=screen.MemoryMap(1, frames[fi, 0].copy()),
+                                    aux_memory=screen.MemoryMap(1, frames[fi, 1].copy()), palette=palette.Palette(pal))
+            gen = v.encode_frame(tgt, is_aux=bool(ia))
+            ref.encode_frame(frames[fi, 0], frames[fi, 1], int(ia))
+            for _ in range(min(int(n), 5)):
+                next(gen)
+                ref.next(1)
+                # no settle involved: the private arrays and the global generators are already current
+                assert (v._memory_map.page_offset == ref.memory(0)).all()
+                assert (v._update_priority == ref.update_priority(0)).all()
+                assert _draws(O, np.array(random.getstate()[1], dtype=np.uint32)) == _draws(O, ref.rng_py().state_words())
 
 
 @pytest.mark.parametrize("tag", ["DHGR_iid_s1", "HGR_iid_s2", "DHGR_exhaust"])
