@@ -21,9 +21,9 @@ Budget: a generator may be abandoned after any next() (movie.py:94-109 does so a
 every frame and bank flip), and its side effects must then be exactly those of
 the opcodes consumed.  Without a hint every next() is therefore one device step.
 `encode_frame(target, is_aux, budget=K)` promises that K opcodes will be pulled;
-they are then computed by one launch.  `Video.SPECULATE = N` (opt-in) gets batched
-launches without a promise: N opcodes are produced from a device-side snapshot
-and rolled back + replayed if fewer were consumed.  Batched, many-stream encoding
+they are then computed by one launch.  `Video.SPECULATE = N` (default 64; 0 = one device
+step per next()) gets batched launches without a promise: N opcodes are produced from a
+device-side snapshot and rolled back + replayed if fewer were consumed.  Batched, many-stream encoding
 (what bench.py measures) goes through stream_batch.StreamBatch instead.
 """
 
@@ -48,8 +48,10 @@ class Video:
     #: from a device-side snapshot; if the generator is abandoned (or any state
     #: attribute is read) after k < N of them were consumed, the snapshot is restored
     #: and exactly k are replayed, so observable state is always that of the consumed
-    #: opcodes.
-    SPECULATE = 0
+    #: opcodes.  Nothing observable depends on it (an assertion of the reference that would
+    #: fire inside the unconsumed part of a chunk makes the generator fall back to exact
+    #: stepping), only the speed does.
+    SPECULATE = 64
 
     #: True: after every next() the host arrays and the *global* random / np.random states
     #: are those of the reference at that point (one full state round trip per opcode).
@@ -240,8 +242,8 @@ class Video:
         if self.mode == VideoMode.DHGR:
             aux = np.ascontiguousarray(target_pixelmap.aux_memory.page_offset, dtype=np.uint8)
             token.fa = torch.from_numpy(aux[None, None].copy()).cuda()
-        chunk = int(budget) if budget else max(1, int(self.SPECULATE))
-        speculative = not budget and chunk > 1 and not self.STRICT_SYNC
+        chunk = int(budget) if budget else 1 if self.STRICT_SYNC else max(1, int(self.SPECULATE))
+        speculative = not budget and chunk > 1
         while True:
             restart = 0 if self._live is token else 1
             if restart and token.started:
@@ -255,7 +257,18 @@ class Video:
                 self._upload()
             if speculative:
                 self._enc.snapshot()
-            ops = self._launch(token, restart, chunk)
+                try:
+                    ops = self._launch(token, restart, chunk)
+                except native.IIVAssertionError:
+                    # one of the reference's asserts fires somewhere in this chunk -- maybe past
+                    # what the caller will pull: step exactly from here on, so that it is raised
+                    # by the next() that would raise it in the reference
+                    self._enc.rollback()
+                    self._host_current = False
+                    speculative, chunk = False, 1
+                    continue
+            else:
+                ops = self._launch(token, restart, chunk)
             self._live = token
             token.started = True
             if self.STRICT_SYNC:

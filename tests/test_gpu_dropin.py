@@ -131,7 +131,7 @@ def _drive(tag, golden, budgeted, speculate=0, peek=False, strict=False):
 def test_video_lazy_generator_exact_without_budget(golden):
     """Default (no budget hint): every next() is exact, generators can be abandoned
     after any opcode (movie.py:94-109)."""
-    _drive("DHGR_single_ops", golden, budgeted=False)
+    _drive("DHGR_single_ops", golden, budgeted=False, speculate=0)
 
 
 def _draws(O, words, n=4):
@@ -209,3 +209,44 @@ def test_make_data_tables_main_writes_reference_format(tmp_path, golden, monkeyp
             assert hashlib.sha256(d.tobytes()).digest() == g5["%s_%d_lower_sha256" % (name, pal)].tobytes()
     print("make_data_tables.main(): %.2f s" % dt)
     assert dt < 60.0   # the 10 s target is reported by bench/DESIGN; leave slack for slow disks
+
+
+def test_speculation_raises_where_the_reference_would():
+    """A target byte with the palette bit set makes the reference assert (video.py:137) at
+    the step that pops it.  With speculative chunks the same next() must raise, not an
+    earlier one, and everything before it must be unaffected."""
+    import palette
+    import screen
+    import video
+    import video_mode
+    rng = np.random.default_rng(5)
+    holes = (np.arange(256) & 127) >= 120
+
+    def frame():
+        a = rng.integers(0, 128, (32, 256), dtype=np.uint8)
+        a[:, holes] = 0
+        return a
+    main, aux = frame(), frame()
+    main[7, 33] |= 0x80
+
+    def run(spec):
+        random.seed(3)
+        np.random.seed(4)
+        v = video.Video(_FG(), ticks_per_second=14700., mode=video_mode.VideoMode.DHGR, palette=palette.Palette.NTSC)
+        v.SPECULATE = spec
+        tgt = screen.DHGRBitmap(main_memory=screen.MemoryMap(1, main.copy()), aux_memory=screen.MemoryMap(1, aux.copy()),
+                                palette=palette.Palette.NTSC)
+        out = []
+        with contextlib.redirect_stdout(io.StringIO()):
+            gen = v.encode_frame(tgt, is_aux=False)
+            try:
+                for _ in range(9000):
+                    out.append(next(gen))
+            except AssertionError:
+                return out, True
+        return out, False
+
+    exact, raised = run(0)
+    assert raised and 0 < len(exact) < 8000
+    spec, raised_spec = run(64)
+    assert raised_spec and spec == exact

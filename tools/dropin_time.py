@@ -5,7 +5,7 @@ import screen, video, video_mode, palette, stream_batch
 class FG: input_frame_rate = 30
 fm, fa = stream_batch.synth_frames_torch(1, 20, True, seed=3, device="cpu")
 clock = stream_batch.MovieClock(True)
-for spec, budget in ((0, False), (64, False), (512, False), (0, True)):
+for spec, budget in ((0, False), (64, False), (256, False), (0, True)):
     random.seed(1); np.random.seed(1)
     v = video.Video(FG(), ticks_per_second=14700., mode=video_mode.VideoMode.DHGR, palette=palette.Palette.NTSC)
     v.SPECULATE = spec
