@@ -1,6 +1,7 @@
 """Randomised differential run: GPU (through the C ABI) against the oracle, many seeds,
 ragged schedules, all input kinds, both kernels and table forms.  The oracle here is the
-checker (same role as in tests/); run on an MI355X:  python tools/fuzz_parity.py [rounds]"""
+checker.  On an MI355X:  python tests/fuzz_parity.py [rounds]   (tests/test_gpu_fuzz.py runs a few
+rounds of it inside the GPU suite)"""
 import os
 import sys
 import time
@@ -15,8 +16,8 @@ import oracle as O  # noqa: E402
 import _iiv_native as native  # noqa: E402
 import stream_batch  # noqa: E402
 
-rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-rng = np.random.default_rng(2026)
+rounds = int(os.environ.get("IIV_FUZZ_ROUNDS", sys.argv[1] if len(sys.argv) > 1 and sys.argv[1].isdigit() else 12))
+rng = np.random.default_rng(int(os.environ.get("IIV_FUZZ_SEED", "2026")))
 O.build()
 dms = {pal: O.cie2000_matrix(O.PALETTE_RGB[pal])[1] for pal in (5, 0)}
 otab, dtab = {}, {}
