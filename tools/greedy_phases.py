@@ -14,7 +14,12 @@ b = stream_batch.StreamBatch(mode, table, store, S, seeds=[(i+1,i+1) for i in ra
 b.encode_frames(fm, fa, 4)
 b.enc.encode(fm, fa, [(4, 0, 1, 292)])     # the measured launch: 292 opcodes per stream
 b.enc.check()
-rows = np.stack([b.enc.get_state(100, i) for i in range(0, S, max(1, S // 64))]).astype(np.int64)[:, 16:24]
+allst = np.stack([b.enc.get_state(100, i) for i in range(0, S, max(1, S // 256))]).astype(np.int64)
+rows = allst[:, 16:24]
+t0, t1 = allst[:, 24], allst[:, 25]
+span = t1.max() - t0.min()
+print("wave lifetimes (loop only): mean %.0f  min %.0f  max %.0f cycles; launch span %.0f  -> mean/span %.2f; starts spread %.0f" % (
+    (t1 - t0).mean(), (t1 - t0).min(), (t1 - t0).max(), span, (t1 - t0).mean() / span, t0.max() - t0.min()))
 names = ["loop/pushed", "form chunk+rows", "rows wait+issue loads", "next chunk", "twist", "values wait", "score+apply", "-"]
 tot = rows.sum(axis=1).mean()
 print("S=%d: cycles per wave for 292 opcodes: %.0f (%.0f per opcode)" % (S, tot, tot / 292))
