@@ -67,8 +67,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("IIV_BENCH_STREAMS", "6144")),
-                    help="independent clips per GPU")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("IIV_BENCH_STREAMS", "0")),
+                    help="independent clips per GPU (0 = the largest of 12288 / 6144 / 3072 / 1536 whose clips fit "
+                         "the free HBM: 6144 fill the GPU at 24 per CU, twice as many hide the tail of a launch)")
     ap.add_argument("--frames-per-step", type=int, default=50)
     ap.add_argument("--mode", choices=["DHGR", "HGR"], default="DHGR")
     ap.add_argument("--coherent", action="store_true", help="S-coh input instead of S-iid")
@@ -109,9 +110,18 @@ def main():
 
     mode = native.DHGR if args.mode == "DHGR" else native.HGR
     dhgr = mode == native.DHGR
-    S, F = args.streams, args.frames_per_step
+    F = args.frames_per_step
     total_steps = args.warmup + args.steps
     n_frames = total_steps * F
+    S = args.streams
+    if S <= 0:
+        free_b, _ = torch.cuda.mem_get_info()
+        per_clip = n_frames * 8192 * (2 if dhgr else 1) + 260 * 1024 + F * 490 * 6   # frames + stream state + opcodes
+        S = next((c for c in (12288, 6144, 3072, 1536) if c * per_clip + (3 << 30) <= 0.85 * free_b), 1536)
+        if world > 1:   # every rank runs the same number of clips
+            t = torch.tensor([S], dtype=torch.int64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            S = int(t.item())
 
     # ---- setup (untimed): tables, synthetic clips, stream state, all in HBM
     t_tab = time.time()
