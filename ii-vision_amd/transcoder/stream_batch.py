@@ -21,7 +21,14 @@ SOCKET_FRAME = 2048
 
 
 class MovieClock:
-    """movie.Movie.encode/emit_stream pacing (movie.py:56-150, video.py:64-70)."""
+    """movie.Movie.encode/emit_stream pacing (movie.py:56-150, video.py:64-70).
+
+    One tick = one audio sample = one opcode (movie.py:67-111).  The clock is stateful:
+    consecutive calls continue one movie, and a generator that is still live when a call
+    returns (same target, same bank, no new encoded frame, no bank flip) is *continued*
+    by the next call (restart == 0), exactly as the reference keeps pulling from
+    `op_seq` -- with every_n_video_frames > 1 a call boundary can fall on a frame that
+    is not encoded (movie.py:76-80)."""
 
     def __init__(self, dhgr, ticks_per_second=14700.0, input_frame_rate=30.0, every_n_video_frames=1):
         self.dhgr = bool(dhgr)
@@ -31,19 +38,29 @@ class MovieClock:
         self.frame_number = 0            # Video.frame_number
         self.stream_pos = HEADER_BYTES   # Movie.stream_pos after the header opcode
         self.aux_bank = False            # Movie.aux_memory_bank
-        self._last_bank = False
+        self._last_bank = False          # movie.py:66 last_memory_bank
         self._target = None              # frame index being encoded
+        self._live = None                # (target, bank) of the generator op_seq refers to
 
-    def segments(self, n_video_frames):
+    def segments(self, n_video_frames=None, max_ticks=None):
         """Segments (frame, is_aux, restart, n_ops) covering the next n_video_frames
-        input frames (each is encoded if (frame_number - 1) % every_n == 0)."""
+        input frames (frame f is encoded if f % every_n == 0, movie.py:76-80) and / or at
+        most max_ticks further audio samples, whichever ends first.  Stopping in front of
+        frame N is what `next(video_frames)` raising StopIteration does for an N-frame
+        clip (movie.py:71-74): the tick that would have started frame N emits nothing."""
+        if n_video_frames is None and max_ticks is None:
+            raise ValueError("segments() needs a frame count or a tick count")
         segs = []
         cur = None
-        end_frame = self.frame_number + n_video_frames
+        end_frame = None if n_video_frames is None else self.frame_number + int(n_video_frames)
+        end_ticks = None if max_ticks is None else self.ticks + int(max_ticks)
         while True:
+            if end_ticks is not None and self.ticks >= end_ticks:
+                break
             # would the next tick start frame `end_frame`?  then stop before it
             nxt = self.ticks + 1
-            if nxt >= self.ticks_per_frame * self.frame_number and self.frame_number >= end_frame:
+            if end_frame is not None and nxt >= self.ticks_per_frame * self.frame_number \
+                    and self.frame_number >= end_frame:
                 break
             self.ticks = nxt
             restart = False
@@ -57,10 +74,14 @@ class MovieClock:
                 restart = True
             if self._target is None:
                 continue
-            if restart or cur is None:
-                # every segment starts a fresh generator: a chunk boundary is always a
-                # frame boundary, and a new frame / bank flip restarts (movie.py:94,101)
-                cur = [self._target, int(self.aux_bank), 1, 0]
+            gen = (self._target, int(self.aux_bank))
+            if restart or self._live != gen:
+                cur = [gen[0], gen[1], 1, 0]
+                segs.append(cur)
+                self._live = gen
+            elif cur is None:
+                # first opcode of this call, pulled from the generator the previous call left live
+                cur = [gen[0], gen[1], 0, 0]
                 segs.append(cur)
             cur[3] += 1
             self.stream_pos += TICK_OPCODE_BYTES
@@ -69,6 +90,19 @@ class MovieClock:
                     self.aux_bank = not self.aux_bank
                 self.stream_pos += ACK_BYTES
         return [tuple(s) for s in segs]
+
+
+def merge_generators(segments):
+    """[(frame, is_aux, n_ops)] per generator: restart == 0 segments folded into the
+    generator they continue (what a recorder around Video.encode_frame would see)."""
+    gens = []
+    for (f, a, r, n) in segments:
+        if r or not gens:
+            gens.append([f, a, n])
+        else:
+            assert gens[-1][0] == f and gens[-1][1] == a
+            gens[-1][2] += n
+    return [tuple(g) for g in gens if g[2] > 0]
 
 
 def frame_budgets(mode_is_dhgr, n_frames, **kw):
@@ -164,10 +198,11 @@ class StreamBatch:
             random.setstate(keep_py)
             np.random.set_state(keep_np)
 
-    def encode_frames(self, frames_main, frames_aux, n_video_frames, ops_out=None):
+    def encode_frames(self, frames_main, frames_aux, n_video_frames, ops_out=None, max_ticks=None):
         """Advance every stream by n_video_frames input frames (targets are
-        frames_*[:, clock.frame_number ...]); returns (ops tensor, segments)."""
-        segs = self.clock.segments(n_video_frames)
+        frames_*[:, clock.frame_number ...]) or max_ticks audio samples, whichever ends
+        first; returns (ops tensor, segments)."""
+        segs = self.clock.segments(n_video_frames, max_ticks=max_ticks)
         ops = self.enc.encode(frames_main, frames_aux, segs, ops_out)
         return ops, segs
 

@@ -204,6 +204,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scratch", default="/tmp/iiv_ref")
     ap.add_argument("--a2m-only", action="store_true")
+    ap.add_argument("--movie-only", action="store_true")
     args = ap.parse_args()
 
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -349,9 +350,10 @@ def main():
     np.savez_compressed(os.path.join(HERE, "g5_tables.npz"), **g5)
     print("g5 written")
     make_a2m_golden(args.scratch)
+    make_movie_golden(args.scratch)
 
 
-if __name__ == "__main__" and "--a2m-only" not in sys.argv:
+if __name__ == "__main__" and "--a2m-only" not in sys.argv and "--movie-only" not in sys.argv:
     main()
 
 
@@ -400,3 +402,114 @@ if __name__ == "__main__" and "--a2m-only" in sys.argv:
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     setup_reference("/tmp/iiv_ref")
     make_a2m_golden("/tmp/iiv_ref")
+
+
+def make_movie_golden(scratch):
+    """G7: the reference's OWN Movie.encode / emit_stream control flow (movie.py:56-150),
+    f1 of SURVEY 8f.  A movie.Movie object is made through __new__ (its __init__ opens an
+    audio file and ffmpeg); `audio` yields N zero samples (tick 34 each), `frame_grabber`
+    yields the synthetic memory maps, `video` is the reference's video.Video.  The byte
+    stream comes out of Movie.emit_stream(Movie.encode()) exactly as main.py:67-69 pulls it.
+    video.Video.encode_frame is wrapped (not changed) by a recorder that logs, per call,
+    (index of the target frame, is_aux, opcodes pulled from that generator)."""
+    import contextlib
+    import io
+    import machine
+    import movie
+    import palette
+    import screen
+    import video
+    import video_mode
+
+    out = {}
+    for tag, mode_name, every_n, n_frames, n_audio, dseed, rseed, pal_id in (
+            ("DHGR_n1", "DHGR", 1, 30, 30 * 490 + 200, 31, 4, 5),
+            ("DHGR_n2", "DHGR", 2, 30, 30 * 490 + 200, 31, 5, 5),
+            ("HGR_n1", "HGR", 1, 30, 30 * 490 + 200, 32, 6, 5),
+            ("HGR_n2", "HGR", 2, 30, 30 * 490 + 200, 32, 7, 5),
+            # audio runs out first (mid-frame, on a frame that is not encoded)
+            ("DHGR_n2_audio_end", "DHGR", 2, 8, 5 * 490 + 77, 33, 8, 0),
+    ):
+        t = time.time()
+        mode = video_mode.VideoMode[mode_name]
+        pal = palette.Palette(pal_id)
+        frames = synth_frames(mode_name, n_frames, dseed, coherent=True)
+
+        class Audio:
+            sample_rate = 14700.
+
+            def audio_stream(self):
+                for _ in range(n_audio):
+                    yield 0
+
+        class Grabber:
+            input_frame_rate = 30
+            video_mode = mode
+            served = []
+
+            def frames(self):
+                for f in range(n_frames):
+                    self.served.append(f)
+                    main = screen.MemoryMap(screen_page=1, page_offset=frames[f, 0].copy())
+                    main.frame_index = f   # (a tag for the recorder below; the reference never looks at it)
+                    aux = None
+                    if mode_name == "DHGR":
+                        aux = screen.MemoryMap(screen_page=1, page_offset=frames[f, 1].copy())
+                    yield main, aux
+
+        Grabber.served = []
+        random.seed(rseed)
+        np.random.seed(rseed)
+        m = movie.Movie.__new__(movie.Movie)
+        m.filename = None
+        m.every_n_video_frames = every_n
+        m.max_bytes_out = None
+        m.video_mode = mode
+        m.palette = pal
+        m.audio = Audio()
+        m.frame_grabber = Grabber()
+        m.video = video.Video(m.frame_grabber, ticks_per_second=m.audio.sample_rate, mode=mode, palette=pal)
+        m.stream_pos = 0
+        m.ticks = 0
+        m.state = machine.Machine()
+        m.aux_memory_bank = False
+
+        calls = []   # [frame index, is_aux, pulled]
+        real_encode_frame = m.video.encode_frame
+
+        def recording_encode_frame(target, is_aux, _calls=calls, _real=real_encode_frame):
+            rec = [target.main_memory.frame_index, int(bool(is_aux)), 0]
+            _calls.append(rec)
+            gen = _real(target, is_aux=is_aux)
+
+            def counted():
+                for item in gen:
+                    rec[2] += 1
+                    yield item
+            return counted()
+
+        m.video.encode_frame = recording_encode_frame
+        with contextlib.redirect_stdout(io.StringIO()):
+            stream = np.array(list(m.emit_stream(m.encode())), dtype=np.uint8)
+        v = m.video
+        out[tag + "/frames"] = frames
+        out[tag + "/meta"] = np.array([0 if mode_name == "HGR" else 1, pal_id, rseed, every_n, n_audio, m.ticks,
+                                       v.frame_number], dtype=np.int32)
+        out[tag + "/calls"] = np.array(calls, dtype=np.int32).reshape(-1, 3)
+        out[tag + "/stream"] = stream
+        out[tag + "/mem_main"] = v.memory_map.page_offset.copy()
+        out[tag + "/up_main"] = v.update_priority.copy()
+        if mode_name == "DHGR":
+            out[tag + "/mem_aux"] = v.aux_memory_map.page_offset.copy()
+            out[tag + "/up_aux"] = v.aux_update_priority.copy()
+        out[tag + "/py_next"] = np.array([random.getrandbits(8) for _ in range(4)], dtype=np.uint8)
+        out[tag + "/np_next"] = np.random.randint(0, 256, size=4).astype(np.uint8)
+        print("%s: %d calls, %d bytes, ticks %d, frame_number %d (%.1fs)" % (
+            tag, len(calls), len(stream), m.ticks, v.frame_number, time.time() - t))
+    np.savez_compressed(os.path.join(HERE, "g7_movie.npz"), **out)
+
+
+if __name__ == "__main__" and "--movie-only" in sys.argv:
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    setup_reference("/tmp/iiv_ref")
+    make_movie_golden("/tmp/iiv_ref")

@@ -123,3 +123,53 @@ def test_edit_distance_params_and_helper(O, dms):
     edp = M.EditDistanceParams()
     assert edp.insert_costs.shape == (128,) and edp.insert_costs[65] == 100000
     assert M.pixel_string((0, 15, 12)) == "0FC"
+
+
+def _movie_tags(g):
+    return sorted(set(k.split("/")[0] for k in g.files))
+
+
+def test_movie_clock_matches_reference_movie_encode(golden):
+    """f1: MovieClock equals the (target frame, bank, opcodes pulled) sequence recorded
+    around video.Video.encode_frame while the REFERENCE's own Movie.emit_stream(Movie.encode())
+    ran (tests/golden/make_golden.py:make_movie_golden; movie.py:56-150): 30 frames, HGR and
+    DHGR, every_n_video_frames 1 and 2, the clip-end StopIteration, and audio that ends first."""
+    g = golden.g7_movie
+    for t in _movie_tags(g):
+        mode, pal, seed, every_n, n_audio, ticks, frame_number = (int(x) for x in g[t + "/meta"])
+        n_frames = g[t + "/frames"].shape[0]
+        want = [tuple(int(x) for x in r) for r in g[t + "/calls"] if r[2] > 0]
+        clock = stream_batch.MovieClock(mode == 1, every_n_video_frames=every_n)
+        got = stream_batch.merge_generators(clock.segments(n_frames, max_ticks=n_audio))
+        assert got == want, t
+        # movie.ticks counts the tick whose next(video_frames) raised StopIteration (movie.py:68-74)
+        clip_ended = ticks < n_audio
+        assert clock.ticks + (1 if clip_ended else 0) == ticks, t
+        assert clock.frame_number + (1 if clip_ended else 0) == frame_number, t
+        assert sum(n for (_, _, n) in got) == clock.ticks
+
+
+@pytest.mark.parametrize("dhgr", [False, True])
+@pytest.mark.parametrize("every_n", [1, 2, 3])
+def test_movie_clock_split_calls_equal_one_call(dhgr, every_n):
+    """A generator that outlives a segments() call is continued (restart == 0), not
+    restarted: any split of the frames over calls gives the same generators."""
+    whole = stream_batch.MovieClock(dhgr, every_n_video_frames=every_n).segments(12)
+    for split in ([3, 3, 3, 3], [1] * 12, [5, 7], [2, 1, 4, 5]):
+        c = stream_batch.MovieClock(dhgr, every_n_video_frames=every_n)
+        parts = []
+        for n in split:
+            part = c.segments(n)
+            assert all(s[2] == 1 for s in part[1:])       # only a call's first segment may continue
+            parts += part
+        assert stream_batch.merge_generators(parts) == stream_batch.merge_generators(whole)
+    c = stream_batch.MovieClock(dhgr, every_n_video_frames=every_n)
+    parts = []
+    while sum(s[3] for s in parts) < sum(s[3] for s in whole):    # 377-tick slices of the same 12 frames
+        parts += c.segments(12 - c.frame_number, max_ticks=377)
+    assert stream_batch.merge_generators(parts) == stream_batch.merge_generators(whole)
+    if every_n == 2:
+        # ADVICE r1: the second call starts on frame 3 (not encoded) and must continue frame 2's generator
+        c = stream_batch.MovieClock(False, every_n_video_frames=2)
+        a, b = c.segments(3), c.segments(3)
+        assert a[-1] == (2, 0, 1, 490) and b[0] == (2, 0, 0, 490)
