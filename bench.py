@@ -82,8 +82,6 @@ def parse_args():
     ap.add_argument("--greedy", choices=["auto", "wave", "workgroup"], default="auto",
                     help="greedy kernel shape: one wave per stream, one 256-thread workgroup per stream, or auto")
     ap.add_argument("--full-sort", action="store_true", help="disable the prologue's prefix sort")
-    ap.add_argument("--packed-store", type=int, default=1, choices=[0, 1, 2],
-                    help="store-table form read by the wave kernel: 0 u16, 1 10-bit (default), 2 10-bit base + escape")
     ap.add_argument("--single-stream", action="store_true", help="also time one clip alone (latency-bound rate)")
     return ap.parse_args()
 
@@ -142,8 +140,6 @@ def main():
     batch.enc.set_greedy_kernel(None if args.greedy == "auto" else args.greedy == "wave")
     if args.full_sort:
         batch.enc.set_prefix_sort(False)
-    if args.packed_store != 1:
-        batch.enc.set_packed_store(args.packed_store)
     ops_buf = torch.empty((S, F * OPS_PER_FRAME, 6), dtype=torch.uint8, device="cuda")
 
     def barrier():

@@ -1,0 +1,595 @@
+// iiv_greedy.hip -- the greedy selection loop of video.Video._index_changes /
+// _compute_error (transcoder/video.py:121-187, 275-301) with Bitmap.apply
+// (transcoder/screen.py:256-293), one 64-lane wave per video stream.
+//
+// Lane l owns page bytes 4l..4l+3.  Everything that is uniform per opcode (pop, validity,
+// candidate counts, the two winners, RNG cursor, opcode emission) lives in SGPRs; the
+// control flow is scalar branches; there is no workgroup barrier and no LDS exchange in
+// the loop (LDS accesses of one wave execute in order).
+//
+// Store values come from the SPLIT store table (iiv_stream.h): value = min(l0 + r0,
+// l1 + r1) with (l0, l1) = left[offset][content bits][row bits] and (r0, r1) from the right
+// half.  A (offset, content) slice of either half is 1-2 KiB, so the 64 lanes of one load
+// fall into 8-16 cache lines (they fell into ~45 of the 86 lines of a 10-bit slice of the
+// dense table), and the whole table (0.5 MiB) stays in L2 in both modes.
+//
+// The loop over the sorted initial list is software-pipelined three deep.  What a step
+// loads depends only on immutable data of the live generator (the entry's row of wd[] and
+// the table slices of its content byte), never on the outcome of earlier steps -- only the
+// validity bits and the priorities do.  So while entry k is scored, the eight table loads of
+// entry k+1 and the row load of entry k+2 are in flight:
+//     take(k+2) -> row load | row(k+1) arrived -> 8 gathers | gathers(k) arrived -> score, apply
+// An entry whose priority was cleared after it was taken is skipped by the step itself
+// (video.py:130), exactly as the reference's lazy deletion does.
+//
+// Scoring, fast form.  The reference orders candidates by (delta, nonce, offset)
+// (video.py:290-301) and draws one nonce per candidate, eligible or not.  The two winners
+// depend on the nonces only if two eligible candidates share the smallest or the
+// second-smallest delta; otherwise the random stream just advances by the number of
+// candidates.  A step reduces signed keys delta << 18 | offset with two fused-DPP wave
+// minima and checks that no third eligible key shares the second delta; only on a tie
+// (2.7 % of the opcodes of the bench workload) it re-scores the entry with every nonce
+// materialised in reference order.  Exact either way.
+#include "iiv_host.h"
+#include "iiv_stream.h"
+
+namespace iiv {
+
+#ifndef IIV_WAVE_OCC
+#define IIV_WAVE_OCC 6     // waves per SIMD the register allocation is held to
+#endif
+
+#define IIV_SGPR(x) __builtin_amdgcn_readfirstlane((int)(x))
+
+// v_min_i32_dpp: `old` is the identity, so the mov folds into the min (one VALU op)
+template <int CTRL> __device__ static inline int min_dpp(int v)
+{
+    int o = __builtin_amdgcn_update_dpp(0x7fffffff, v, CTRL, 0xf, 0xf, false);
+    return o < v ? o : v;
+}
+
+// signed minimum over the wave, returned in an SGPR
+__device__ static inline int wave_min_i32(int v)
+{
+    v = min_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = min_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = min_dpp<0x141>(v);  // row_half_mirror
+    v = min_dpp<0x140>(v);  // row_mirror: every lane holds its row's minimum
+    v = min_dpp<0x142>(v);  // row_bcast:15
+    v = min_dpp<0x143>(v);  // row_bcast:31: lane 63 holds the wave's
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+template <int CTRL> __device__ static inline uint32_t dpp_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+
+// merge this lane's sorted pair (k1 <= k2) with the pair held by its DPP partner
+template <int CTRL> __device__ static inline void top2_step(uint32_t &k1, uint32_t &k2)
+{
+    uint32_t o1 = dpp_u32<CTRL>(k1), o2 = dpp_u32<CTRL>(k2);
+    uint32_t lo = k1 < o1 ? k1 : o1, hi = k1 < o1 ? o1 : k1;
+    uint32_t m2 = k2 < o2 ? k2 : o2;
+    k1 = lo;
+    k2 = hi < m2 ? hi : m2;
+}
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// min(l0 + r0, l1 + r1) of two packed halves: v_pk_add_u16 + one min
+__device__ static inline uint32_t combine(uint32_t l, uint32_t r)
+{
+    const u16x2 s = __builtin_bit_cast(u16x2, l) + __builtin_bit_cast(u16x2, r);
+    const uint32_t a = s.x, b = s.y;
+    return a < b ? a : b;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamState *__restrict__ states,
+                                                                   const uint8_t *__restrict__ frames_main,
+                                                                   const uint8_t *__restrict__ frames_aux, int n_frames,
+                                                                   const LaunchSeg *__restrict__ segs, int seg_stride,
+                                                                   const uint32_t *__restrict__ left,
+                                                                   const uint32_t *__restrict__ right,
+                                                                   uint8_t *__restrict__ ops_out, size_t ops_stride)
+{
+    using T = SplitTraits<MODE>;
+    constexpr uint32_t INF = 0xffffffffu;
+    typedef uint32_t __attribute__((aligned(2))) u32_a2;
+    // LDS per stream: two 1 KiB bitmaps + 1.4 MT19937 blocks + a compaction scratch (5.7 KiB)
+    __shared__ uint32_t nz[256];        // update_priority != 0
+    __shared__ uint32_t pdone[256];     // byte already emitted as a primary (its diff weight counts as 0)
+    __shared__ uint32_t mt[624 + 256];  // random's current MT19937 block + the first 256 words of the next one
+    __shared__ uint32_t xw[64];         // compaction of a list window
+
+    const int lane = threadIdx.x;
+    StreamState &S = states[blockIdx.x];
+    const LaunchSeg g = segs[(size_t)blockIdx.x * seg_stride];
+    const int n_ops = IIV_SGPR(g.n_ops), is_aux = IIV_SGPR(g.is_aux), frame = IIV_SGPR(g.frame);
+    if (n_ops <= 0) return;
+    uint8_t *out = ops_out + (size_t)blockIdx.x * ops_stride + (size_t)IIV_SGPR(g.ops_base) * 6;
+
+    if (!S.gen_active || S.error) {
+        if (lane == 0 && !S.error) S.error = kErrNoGenerator;
+        return;
+    }
+    for (int i = lane; i < 256; i += 64) {
+        nz[i] = S.nzbits[i];
+        pdone[i] = S.pdone[i];
+    }
+    for (int i = lane; i < 624; i += 64) mt[i] = S.mt_py[i];
+    __syncthreads();
+    // A step reads nonces at mt_idx + t, t <= 256 (one per candidate, then <= 2 for the
+    // re-queued bytes), so it can run at most 256 words into the next block: only that much
+    // of it is kept ahead (`ahead`, computable from the current block alone plus itself).
+    // When the current block is used up, the head moves down, the other 368 words are
+    // generated in place (word i needs the old words i, i + 1 and the new word i - 227) and
+    // a new head is generated.
+    uint32_t *ahead = mt + 624;
+    auto gen_ahead = [&]() {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = lane + 64 * k;
+            if (k < 3 || i < 227) ahead[i] = mt[i + 397] ^ mt_mix(mt[i], mt[i + 1]);
+        }
+        wave_lds_sync();
+        {
+            const int i = 192 + lane;
+            if (i >= 227) ahead[i] = ahead[i - 227] ^ mt_mix(mt[i], mt[i + 1]);
+        }
+        wave_lds_sync();
+    };
+    auto gen_rest = [&]() {
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int i = 256 + 64 * k + lane;
+            if (k < 5 || i < 624) {
+                const uint32_t nv = i < 483 ? ahead[i - 227] : mt[i - 227];
+                const uint32_t nx = i == 623 ? ahead[0] : mt[i + 1];
+                const uint32_t v = nv ^ mt_mix(mt[i], nx);
+                wave_lds_sync();  // every lane has read its old words before any lane overwrites one
+                mt[i] = v;
+            }
+            wave_lds_sync();
+        }
+    };
+    auto move_head = [&]() {
+#pragma unroll
+        for (int k = 0; k < 4; k++) mt[lane + 64 * k] = ahead[lane + 64 * k];
+        wave_lds_sync();
+    };
+    gen_ahead();
+    int mt_idx = IIV_SGPR(S.mt_py_idx);
+    if (mt_idx >= 624) {
+        move_head();
+        gen_rest();
+        gen_ahead();
+        mt_idx -= 624;
+    }
+    // after a block switch only words 0..255 of the current block are in place until twist_now()
+    bool twist_pending = false;
+    auto twist_now = [&]() {
+        if (twist_pending) {
+            gen_rest();
+            gen_ahead();
+            twist_pending = false;
+        }
+    };
+
+    const int n_sorted = IIV_SGPR(S.n_sorted);
+    const int truncated = IIV_SGPR(S.truncated);
+    int head = IIV_SGPR(S.head), n_pushed = IIV_SGPR(S.n_pushed), exhausted = IIV_SGPR(S.exhausted);
+    int done = 0, err = 0;
+    uint32_t draws = 0;
+    unsigned long long pad_ops = 0;
+    const uint32_t pad_content = (uint32_t)IIV_SGPR(S.pad_content);
+
+    // table slices of the even / odd page bytes of this bank
+    const int o_e = byte_offset<MODE>(0, is_aux), o_d = byte_offset<MODE>(1, is_aux);
+    const uint32_t *left_e = left + ((size_t)o_e << (T::kLeftCBits + T::kLeftRowBits));
+    const uint32_t *left_d = left + ((size_t)o_d << (T::kLeftCBits + T::kLeftRowBits));
+    const uint32_t *right_e = right + ((size_t)o_e << (T::kRightCBits + T::kRightRowBits));
+    const uint32_t *right_d = right + ((size_t)o_d << (T::kRightCBits + T::kRightRowBits));
+    const uint8_t *tgt_frames = (MODE == kDHGR && is_aux ? frames_aux : frames_main) +
+                                ((size_t)blockIdx.x * n_frames + frame) * 8192;
+    const uint4 *wd_rows = reinterpret_cast<const uint4 *>(S.wd);
+    int32_t *up = S.up[is_aux];
+    uint8_t *mem = S.mem[is_aux];
+    const int wsel = lane >> 3;          // this lane's word inside a page's 8 bitmap words
+    const int sh0 = (4 * lane) & 31;     // its 4 bits inside that word
+    const uint32_t y0 = 4u * (uint32_t)lane;
+
+    // What a step needs of one entry: its eight table words and the diff-weight fields of its
+    // row.  Two such sets alternate (one is scored while the other is being loaded); the loop
+    // below is written out twice so that no in-flight register is ever copied -- a copy
+    // would make the compiler wait for the load right there.
+    struct Loaded {
+        uint32_t gl[4], gr[4], dwm[4];
+    };
+    // the eight table loads of one entry (content c, row w): a lane's bytes 0, 2 are even page
+    // offsets, 1, 3 odd ones; both lookups of a slice back to back (the second finds the
+    // slice's lines in L1)
+    auto gather8 = [&](const uint4 &w, uint32_t c, Loaded &L) {
+        const char *le = reinterpret_cast<const char *>(left_e + (split_content_left<MODE>(c, 0) << T::kLeftRowBits));
+        const char *ld = reinterpret_cast<const char *>(left_d + (split_content_left<MODE>(c, 1) << T::kLeftRowBits));
+        const char *re = reinterpret_cast<const char *>(right_e + (split_content_right<MODE>(c, 0) << T::kRightRowBits));
+        const char *rd = reinterpret_cast<const char *>(right_d + (split_content_right<MODE>(c, 1) << T::kRightRowBits));
+        constexpr uint32_t LM = kWdRowMask << kWdLeftShift;   // byte offset of the left row's word
+        constexpr int RS = kWdRightShift - 2;                 // brings the right row to bit 2
+        const uint32_t wr[4] = {w.x, w.y, w.z, w.w};
+        L.gl[0] = *reinterpret_cast<const uint32_t *>(le + (wr[0] & LM));
+        L.gl[2] = *reinterpret_cast<const uint32_t *>(le + (wr[2] & LM));
+        L.gl[1] = *reinterpret_cast<const uint32_t *>(ld + (wr[1] & LM));
+        L.gl[3] = *reinterpret_cast<const uint32_t *>(ld + (wr[3] & LM));
+        L.gr[0] = *reinterpret_cast<const uint32_t *>(re + ((wr[0] >> RS) & LM));
+        L.gr[2] = *reinterpret_cast<const uint32_t *>(re + ((wr[2] >> RS) & LM));
+        L.gr[1] = *reinterpret_cast<const uint32_t *>(rd + ((wr[1] >> RS) & LM));
+        L.gr[3] = *reinterpret_cast<const uint32_t *>(rd + ((wr[3] >> RS) & LM));
+        // (the empty asm keeps the compiler from sinking these four ANDs to the scoring two
+        // half-iterations later, which would keep the whole row alive until then)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            L.dwm[r] = wr[r] & kWdDwMask;
+            asm volatile("" : "+v"(L.dwm[r]));
+        }
+    };
+
+    // opcodes emitted but not yet written: opcode ob_base + l sits in lane l of (ob0, ob1)
+    uint32_t ob0 = 0, ob1 = 0;
+    int ob_base = 0;
+    auto flush_ops = [&]() {
+        if (lane < done - ob_base) {
+            uint8_t *q = out + (size_t)(ob_base + lane) * 6;
+            *reinterpret_cast<u32_a2 *>(q) = ob0;
+            *reinterpret_cast<uint16_t *>(q + 4) = (uint16_t)ob1;
+        }
+        ob_base = done;
+    };
+
+    // video.py:140-144, 170-187; screen.py:256-293.  Lanes 0..2 carry (x, y1, y2); a
+    // missing secondary repeats the primary's stores.
+    auto apply = [&](int p, int x, uint32_t c, int y1, uint32_t nd1, int y2, uint32_t nd2, int C) {
+        const uint32_t v1 = y1 >= 0 ? nd1 : 0u, v2 = y2 >= 0 ? nd2 : 0u;
+        const int y1e = y1 >= 0 ? y1 : x, y2e = y2 >= 0 ? y2 : x;   // video.py:185-186
+        const int f1 = v1 ? 1 : 0, f2 = v2 ? 1 : 0;
+        if (n_pushed + f1 + f2 > kPushedCap) {
+            err = kErrPushedOverflow;
+            return;
+        }
+        if (mt_idx + C + 2 >= 256) twist_now();
+        if (lane < 3) {
+            const int off = lane == 0 ? x : lane == 1 ? y1e : y2e;
+            const uint32_t val = lane == 0 ? 0u : lane == 1 ? v1 : v2;
+            up[p * 256 + off] = (int32_t)val;  // byte_pair_difference == store-table value (screen.py:383-398)
+            mem[p * 256 + off] = (uint8_t)c;
+            if (val == 0) {
+                atomicAnd(&nz[p * 8 + (off >> 5)], ~(1u << (off & 31)));
+            } else {
+                const int k = lane == 2 ? f1 : 0;
+                const uint32_t nonce = mt_temper(mt[mt_idx + C + k]) >> 24;  // video.py:178
+                S.pushed[n_pushed + k] = ((2047u - val) << 21) | (nonce << 13) | ((uint32_t)p << 8) | (uint32_t)off;
+            }
+            if (lane == 0) atomicOr(&pdone[p * 8 + (x >> 5)], 1u << (x & 31));
+        }
+        // the opcode (page + 32, content, x, y1, y2, x) goes into lane (done - ob_base) of a
+        // register pair; 64 of them leave in two coalesced stores
+        const uint32_t w0 = (uint32_t)(p + 32) | (c << 8) | ((uint32_t)x << 16) | ((uint32_t)y1e << 24);
+        const uint32_t w1 = (uint32_t)y2e | ((uint32_t)x << 8);
+        const int ob_lane = IIV_SGPR(done - ob_base);
+        // (gfx9 VOP3 reads one SGPR only; v_writelane may take its lane select from m0 besides)
+        asm("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
+            : "+v"(ob0), "+v"(ob1)
+            : "s"(IIV_SGPR(w0)), "s"(ob_lane), "s"(IIV_SGPR(w1)));
+        mt_idx += C + f1 + f2;
+        draws += (uint32_t)(C + f1 + f2);
+        n_pushed += f1 + f2;
+        done++;
+        if (done - ob_base == 64) flush_ops();
+        if (mt_idx >= 624) {
+            // the next block becomes the current one: its head moves down now, the rest of it
+            // and the new head are generated later, while table loads are in flight
+            // (twist_now), at the latest before a step reads past word 255
+            move_head();
+            mt_idx -= 624;
+            twist_pending = true;
+        }
+    };
+
+    // One greedy step on list entry e = page << 8 | offset | content << 16 with what was loaded
+    // for it.  Returns false if the entry's priority is gone (video.py:130: nothing happens);
+    // otherwise an opcode is emitted or err is set.
+    auto step = [&](uint32_t e, const Loaded &L) -> bool {
+        const int p = (e >> 8) & 31, x = e & 255;
+        const uint32_t c = (e >> 16) & 0xffu;  // video.py:134
+        uint32_t nzw = nz[p * 8 + wsel], pdw = pdone[p * 8 + wsel];
+        const uint32_t xword = (uint32_t)__builtin_amdgcn_readlane((int)nzw, (x >> 5) * 8);
+        if (!((xword >> (x & 31)) & 1u)) return false;
+        if (MODE == kDHGR && c >= 0x80) {  // video.py:137
+            err = kErrPaletteBit;
+            return true;
+        }
+        // x itself leaves both sets before the page is scored (video.py:140-141)
+        const uint32_t xbit = wsel == (x >> 5) ? 1u << (x & 31) : 0u;
+        nzw &= ~xbit;
+        pdw |= xbit;
+        // per byte: d = delta << 20 | y (screen.py:547); kt = d for bytes whose diff weight
+        // still counts (not yet a primary, video.py:141), ke = d for bytes that may still be
+        // chosen (update_priority != 0, video.py:159); >= 0 otherwise
+        uint32_t nd[4];
+        int ke[4];
+        int C = 0;
+        unsigned long long cand[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            nd[r] = combine(L.gl[r], L.gr[r]);
+            const int d = (int)((nd[r] << kWdDwShift) | (y0 + r)) - (int)L.dwm[r];
+            const int gone = __builtin_amdgcn_sbfe((int)pdw, sh0 + r, 1);
+            const int live = __builtin_amdgcn_sbfe((int)nzw, sh0 + r, 1);
+            ke[r] = d & live;
+            cand[r] = __ballot((d & ~gone) < 0);  // video.py:283
+            C += (int)__popcll(cand[r]);           // one nonce each (video.py:290-293)
+        }
+        // two smallest eligible keys: in the lane, then across the wave
+        const int a0 = ke[0] < ke[1] ? ke[0] : ke[1], b0 = ke[0] < ke[1] ? ke[1] : ke[0];
+        const int a1 = ke[2] < ke[3] ? ke[2] : ke[3], b1 = ke[2] < ke[3] ? ke[3] : ke[2];
+        const int k1 = a0 < a1 ? a0 : a1, hi01 = a0 < a1 ? a1 : a0, mb = b0 < b1 ? b0 : b1;
+        const int k2 = hi01 < mb ? hi01 : mb;
+        // store values of byte pairs, for the scalar read-out of the winners' values
+        const uint32_t nd01 = nd[0] | (nd[1] << 16), nd23 = nd[2] | (nd[3] << 16);
+        auto nd_of = [&](int y) -> uint32_t {   // (scalar from here on: two readlanes, no branch)
+            const uint32_t pa = (uint32_t)__builtin_amdgcn_readlane((int)nd01, y >> 2);
+            const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane((int)nd23, y >> 2);
+            return (((y & 2) ? pb : pa) >> ((y & 1) * 16)) & 0xffffu;
+        };
+        const int K1 = wave_min_i32(k1);
+        int y1 = -1, y2 = -1;
+        uint32_t nd1 = 0, nd2 = 0;
+        bool tie = false;
+        if (K1 < 0) {
+            y1 = K1 & 255;
+            nd1 = nd_of(y1);
+            const int K2 = wave_min_i32(k1 == K1 ? k2 : k1);
+            if (K2 < 0) {
+                y2 = K2 & 255;
+                nd2 = nd_of(y2);
+                tie = (K1 >> kWdDwShift) == (K2 >> kWdDwShift);
+                if (!tie) {
+                    // does a third eligible byte share the second delta?  (then the nonces decide)
+                    int n2 = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        n2 += (int)__popcll(__ballot(((uint32_t)(ke[r] ^ K2) >> kWdDwShift) == 0u));
+                    tie = n2 > 1;
+                }
+            }
+        }
+        if (tie) {
+            // the reference's (delta, nonce, offset) heap order with every candidate's nonce
+            // materialised: one random.getrandbits(8) per candidate in ascending offset
+            // (video.py:290-293)
+            twist_now();
+            uint32_t key[4];
+            // candidates in lower lanes draw first, then this lane's bytes in ascending order
+            int run = mt_idx;
+#pragma unroll
+            for (int q = 0; q < 4; q++) run += prefix_popc(cand[q]);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t nonce = mt_temper(mt[run]) >> 24;
+                run += (int)((cand[r] >> lane) & 1ull);
+                const uint32_t k = ((uint32_t)((ke[r] >> kWdDwShift) + 2048) << 16) | (nonce << 8) | (y0 + r);
+                key[r] = ke[r] < 0 ? k : INF;  // video.py:159
+            }
+            // two smallest (delta, nonce, offset): lane, row of 16 (DPP), wave (readlane)
+            uint32_t ta0 = key[0] < key[1] ? key[0] : key[1], tb0 = key[0] < key[1] ? key[1] : key[0];
+            uint32_t ta1 = key[2] < key[3] ? key[2] : key[3], tb1 = key[2] < key[3] ? key[3] : key[2];
+            uint32_t t1 = ta0 < ta1 ? ta0 : ta1;
+            uint32_t thi = ta0 < ta1 ? ta1 : ta0, tmb = tb0 < tb1 ? tb0 : tb1;
+            uint32_t t2 = thi < tmb ? thi : tmb;
+            top2_step<0xB1>(t1, t2);   // quad_perm [1,0,3,2]
+            top2_step<0x4E>(t1, t2);   // quad_perm [2,3,0,1]
+            top2_step<0x141>(t1, t2);  // row_half_mirror
+            top2_step<0x140>(t1, t2);  // row_mirror
+            uint32_t T1 = INF, T2 = INF;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t r1 = __builtin_amdgcn_readlane(t1, 16 * q), r2 = __builtin_amdgcn_readlane(t2, 16 * q);
+                uint32_t lo = T1 < r1 ? T1 : r1, hi = T1 < r1 ? r1 : T1;
+                uint32_t m2 = T2 < r2 ? T2 : r2;
+                T1 = lo;
+                T2 = hi < m2 ? hi : m2;
+            }
+            y1 = T1 != INF ? (int)(T1 & 255) : -1;
+            y2 = T2 != INF ? (int)(T2 & 255) : -1;
+            nd1 = y1 >= 0 ? nd_of(y1) : 0u;
+            nd2 = y2 >= 0 ? nd_of(y2) : 0u;
+        }
+        apply(p, x, c, y1, nd1, y2, nd2, C);
+        return true;
+    };
+
+    int guard = n_ops + 8192 + 2 * kPushedCap + 64;
+
+    // ---- phase A: the sorted initial list (video.py:121-131), pipelined.
+    // The list is read 64 entries at a time (the next window's words are requested one window
+    // ahead); the entries of a window whose priority is still non-zero are compacted into one
+    // register (lane k = k-th live entry, through a 256 B LDS scatter), so that taking the
+    // next entry is one v_readlane with a scalar index.
+    // window entries: page << 8 | offset | content << 16 | (list position - win_base) << 24
+    if (head < n_sorted && !exhausted) {
+        int win_base = head, win_end = head;  // list positions [win_base, win_end) are in the window
+        int n_dense = 0, qi = 0;               // live entries of the window, next one to hand out
+        uint32_t dense_e = 0;
+        uint32_t ord_next = S.order[(head + lane) & 8191];  // the words of [win_end, win_end + 64)
+        auto refill = [&]() {
+            const int start = win_end;
+            const uint32_t e = ord_next;
+            const int idx = start + lane;
+            ord_next = S.order[(idx + 64) & 8191];   // (unconditional, see below; positions >= n_sorted are never used)
+            const uint32_t loc = e & 0x1fffu;
+            const bool v = idx < n_sorted && ((nz[loc >> 5] >> (loc & 31)) & 1u);
+            const unsigned long long mask = __ballot(v);
+            n_dense = (int)__popcll(mask);
+            qi = 0;
+            if (v) xw[prefix_popc(mask)] = (e & 0x00ffffffu) | ((uint32_t)lane << 24);
+            wave_lds_sync();
+            dense_e = xw[lane];
+            wave_lds_sync();
+            win_base = start;
+            win_end = start + 64 < n_sorted ? start + 64 : n_sorted;
+        };
+        // next live entry, or 0 when the list is used up; *next_head = list position after it
+        auto take = [&](int &next_head) -> uint32_t {
+            while (qi >= n_dense) {
+                if (win_end >= n_sorted) return 0u;
+                refill();
+            }
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)dense_e, qi++);
+            next_head = win_base + (int)(e >> 24) + 1;
+            return e | 0x80000000u;  // (bit 31 marks a real entry: page 0 / offset 0 / content 0 is a valid one)
+        };
+        auto row_of = [&](uint32_t e) -> uint4 { return wd_rows[((e >> 8) & 31) * 64 + lane]; };
+
+        // pipeline: entry A = next to be scored (its set is loaded or in flight), B = the one
+        // after it (its row has arrived or is about to), C = the one after that (row in flight).
+        // One half-iteration: issue B's eight table loads into the other set, take entry D and
+        // request its row into the row buffer B's loads have just consumed, then score A.
+        // Rows are requested two entries ahead of their use so that the wait for a row never
+        // has to cover the stores of the step before it: vmcnt counts loads and stores in one
+        // in-order queue, and between a row's load and its use there are always the eight table
+        // loads of another entry, whatever the steps in between stored.
+        // (Loads are issued unconditionally -- a missing entry reads page 0's row and content
+        // 0's slices, which is harmless -- because a conditionally assigned register would be
+        // merged with a copy, and the copy would wait for the load on the spot.)
+        uint32_t eA, eB, eC;
+        int hA = head, hB, hC;
+        uint4 rowP, rowQ;
+        Loaded set0, set1;
+        // (the prelude issues its loads in the loop's own order -- row, eight table loads, row --
+        // so that the wait counts the compiler derives at the loop header are the loop's)
+        eA = take(hA);
+        const uint4 rowA = row_of(eA);
+        hB = hA;
+        eB = eA ? take(hB) : 0u;
+        rowP = row_of(eB);
+        gather8(rowA, eA >> 16 & 0xffu, set0);
+        hC = hB;
+        eC = eB ? take(hC) : 0u;
+        rowQ = row_of(eC);
+        // `active` = false: the loop is about to end (the first half of this trip was the last
+        // step); the loads are still issued -- every path from a row's load to the loop header
+        // then crosses eight table loads and another row load, which is what keeps the
+        // compiler's wait for the row from covering the stores of the latest step -- but
+        // nothing is scored.
+        auto half = [&](const Loaded &cur, Loaded &nxt, uint4 &row, bool active) -> bool {
+            gather8(row, eB >> 16 & 0xffu, nxt);
+            // every use of the old row is scheduled before the new one is requested, so that the
+            // load can land in the same registers (otherwise: a copy, and a wait in front of it)
+            __builtin_amdgcn_sched_barrier(0);
+            int hD = hC;
+            const uint32_t eD = (active && eC) ? take(hD) : 0u;
+            row = row_of(eD);
+            if (!active) return false;
+            twist_now();  // (the MT19937 block generation hides behind the loads)
+            (void)step(eA, cur);
+            head = hA;
+            eA = eB;
+            hA = hB;
+            eB = eC;
+            hB = hC;
+            eC = eD;
+            hC = hD;
+            if (--guard < 0) err = kErrGuard;
+            return eA && done < n_ops && !err;
+        };
+        if (eA && done < n_ops) {
+            bool more;
+            do {
+                more = half(set0, set1, rowP, true);
+                more = half(set1, set0, rowQ, more);
+            } while (more);
+        }
+        if (!eA && !err) head = n_sorted;  // every entry of the list has been processed or was dead
+    }
+
+    // ---- phase B: the re-queued bag (video.py:124-131, 170-178), one entry at a time
+    while (done < n_ops && !err && !exhausted) {
+        if (--guard < 0) {
+            err = kErrGuard;
+            break;
+        }
+        if (truncated) {  // more initial entries exist than were ordered: host budget bug
+            err = kErrSortBudget;
+            break;
+        }
+        unsigned long long best = ~0ull;
+        for (int i = lane; i < n_pushed; i += 64) {
+            unsigned long long k = ((unsigned long long)S.pushed[i] << 32) | (unsigned)i;
+            best = k < best ? k : best;
+        }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            unsigned long long other = __shfl_xor(best, d, 64);
+            best = other < best ? other : best;
+        }
+        const uint32_t bk = (uint32_t)IIV_SGPR((uint32_t)(best >> 32));
+        const uint32_t bi = (uint32_t)IIV_SGPR((uint32_t)best);
+        if (bk == INF) {
+            exhausted = 1;  // video.py:189
+            break;
+        }
+        if (lane == 0) S.pushed[bi] = INF;
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // that store precedes the next scan of pushed[]
+        // pushed keys do not carry the content byte: it is the target byte of that offset
+        const uint32_t loc = bk & 0x1fffu;
+        const uint32_t c = (uint32_t)IIV_SGPR(tgt_frames[loc]);
+        const uint32_t e = loc | (c << 16);
+        const uint4 w = wd_rows[((e >> 8) & 31) * 64 + lane];
+        Loaded L;
+        gather8(w, c, L);
+        twist_now();
+        (void)step(e, L);
+    }
+
+    flush_ops();
+    if (exhausted && done < n_ops && !err) {
+        for (int i = done + lane; i < n_ops; i += 64) {  // video.py:249-251
+            uint8_t *q = out + (size_t)i * 6;
+            q[0] = 32; q[1] = (uint8_t)pad_content; q[2] = 0; q[3] = 0; q[4] = 0; q[5] = 0;
+        }
+        pad_ops += (unsigned long long)(n_ops - done);
+        done = n_ops;
+    }
+    twist_now();
+    __syncthreads();
+    for (int i = lane; i < 256; i += 64) {
+        S.nzbits[i] = nz[i];
+        S.pdone[i] = pdone[i];
+    }
+    for (int i = lane; i < 624; i += 64) S.mt_py[i] = mt[i];
+    if (lane == 0) {
+        S.mt_py_idx = mt_idx;
+        S.head = head;
+        S.n_pushed = n_pushed;
+        S.exhausted = exhausted;
+        if (exhausted) S.out_of_work[is_aux] = 1;
+        S.draws_py += (unsigned long long)draws;
+        S.ops += (unsigned long long)done;
+        S.pad_ops += pad_ops;
+        if (err && S.error == 0) S.error = err;
+    }
+}
+
+int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st)
+{
+    if (mode == kDHGR)
+        hipLaunchKernelGGL(greedy_wave_kernel<kDHGR>, dim3(a.n_streams), dim3(64), 0, st, a.states, a.frames_main,
+                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.left, a.right, a.ops_out, a.ops_stride);
+    else
+        hipLaunchKernelGGL(greedy_wave_kernel<kHGR>, dim3(a.n_streams), dim3(64), 0, st, a.states, a.frames_main,
+                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.left, a.right, a.ops_out, a.ops_stride);
+    return hip_check(hipGetLastError(), "greedy_wave_kernel launch");
+}
+
+}  // namespace iiv

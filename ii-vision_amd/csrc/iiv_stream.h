@@ -1,0 +1,189 @@
+// iiv_stream.h -- per-stream encoder state in HBM and the formats shared by the
+// prologue (iiv_encode.hip), the greedy kernels (iiv_greedy.hip, iiv_encode.hip) and the
+// split-table builder (iiv_tables.hip).
+// Reference: transcoder/video.py:16-301 (Video state), transcoder/screen.py:383-547.
+#pragma once
+
+#include "iiv_device.h"
+
+namespace iiv {
+
+constexpr int kPushedCap = 16384;  // >= 2 pushes x 7680 non-hole bytes
+
+// ---- wd[]: one word per byte of the live generator's bank, written once by the prologue
+// and immutable while the generator lives:
+//   bits  2..10  row index into the LEFT  half of the split store table  (split_row_left),
+//                i.e. bits 0..10 are the byte offset of the row's u32 inside a slice
+//   bits 11..19  row index into the RIGHT half                           (split_row_right)
+//   bits 20..30  diff weight of the byte (Bitmap.diff_weights, screen.py:400-449), <= 2047
+// Keys of the greedy step are `value << 20 | offset`, so `key - (wd & kWdDwMask)` is
+// `delta << 20 | offset` with delta = store value - diff weight (screen.py:547) in [-2047, 2047].
+constexpr int kWdDwShift = 20;
+constexpr uint32_t kWdDwMask = 0xffffffffu << kWdDwShift;
+constexpr int kWdLeftShift = 2, kWdRightShift = 11;
+constexpr uint32_t kWdRowMask = 0x1ffu;
+__host__ __device__ inline uint32_t wd_word(uint32_t row_left, uint32_t row_right, uint32_t dw)
+{
+    return (row_left << kWdLeftShift) | (row_right << kWdRightShift) | (dw << kWdDwShift);
+}
+constexpr int kMaxValue = 2047;  // every table value and diff weight must fit 11 bits
+
+struct StreamState {
+    uint8_t mem[2][8192];     // [is_aux] Video.memory_map / aux_memory_map
+    int32_t up[2][8192];      // [is_aux] Video.update_priority / aux_update_priority
+    uint32_t wd[8192];        // live generator: see above
+    uint32_t order[8192];     // sorted initial entries: page << 8 | offset | target content << 16
+    uint32_t nzbits[256];     // bit = update_priority != 0 (as left by the last launch)
+    uint32_t pdone[256];      // bit = byte was a primary in the live generator (its diff weight is 0)
+    uint32_t pushed[kPushedCap];  // (2047-p) << 21 | nonce << 13 | page << 8 | offset; ~0 = popped
+    uint32_t mt_py[624];      // random's MT19937 block
+    uint32_t mt_np[624];      // np.random's MT19937 block
+    int32_t mt_py_idx, mt_np_idx;
+    int32_t n_sorted, head, n_pushed, exhausted;
+    int32_t gen_active, gen_is_aux, gen_frame, error;
+    int32_t out_of_work[2];
+    int32_t pad_content;      // target[0,0] of the live generator's bank (video.py:249)
+    int32_t truncated;        // order[] holds only the top of the list (prefix sort)
+    unsigned long long draws_py, draws_np, ops, pad_ops;
+    unsigned long long stamps[32];  // diagnostic builds only (-DIIV_STAMPS): prologue s_memtime stamps [0,16), greedy phase cycles [16,24)
+};
+
+enum { kErrNone = 0, kErrHoles = 1, kErrNegative = 2, kErrPaletteBit = 3, kErrPushedOverflow = 4, kErrNoGenerator = 5, kErrGuard = 6, kErrSortBudget = 7 };
+
+// What one stream does in one launch round (iiv_encode builds these from the segment lists).
+// Shared schedule: every stream reads the same descriptor (stride 0); per-stream schedules:
+// descriptor [round][stream].
+struct LaunchSeg {
+    int32_t frame;     // target frame index
+    int32_t is_aux;    // bank
+    int32_t n_ops;     // opcodes to emit in this round (0: the stream idles)
+    int32_t ops_base;  // opcode index of this round's first opcode in the stream's output
+    int32_t need;      // prologue: -1 = no new generator in this round; 0 = order everything;
+                       // > 0 = order at least the `need` highest priorities (prefix sort)
+};
+
+// ---- the split store table -------------------------------------------------------------
+// The store value S[o][content][window] = ED(string(poke(window, content)), string(window))
+// (Bitmap.compute_delta_page / byte_pair_difference, screen.py:383-398, 525-547) is a
+// min-plus chain over the pixels of the two colour strings (E[k] = min(E[k-1] + sub_k,
+// E[k-2] + transposition_k), make_data_tables.py:92-108).  Cut after pixel M: the state
+// (E[M-1], E[M]) depends only on the window bits that reach pixels 1..M, and the cost of
+// finishing from either state component only on the bits that reach pixels M..N, so
+//     S = min(l0 + r0, l1 + r1)
+// with (l0, l1) from a LEFT table and (r0, r1) from a RIGHT table whose (content, row) slices
+// are 1-2 KiB instead of 11-32 KiB: the 256 lookups of a greedy step touch 48-64 cache
+// lines instead of ~135, and the whole table is 0.5 MiB instead of 8-16 MiB.
+// Exactness for every (offset, content, window) is tested against iiv_build_store_table.
+//   DHGR (10 pixels, M = 5): left bits 0..7 of the window, right bits 4..12
+//   HGR  (18 pixels, M = 9): even byte: left bits 0..7 and 10, right bits 5..13
+//                            odd byte:  left bits 0..8,        right bits 3 and 6..13
+template <int MODE> struct SplitTraits;
+template <> struct SplitTraits<kDHGR> {
+    static constexpr int kCut = 5, kLeftRowBits = 8, kRightRowBits = 9, kLeftCBits = 5, kRightCBits = 6;
+};
+template <> struct SplitTraits<kHGR> {
+    static constexpr int kCut = 9, kLeftRowBits = 9, kRightRowBits = 9, kLeftCBits = 6, kRightCBits = 6;
+};
+
+// window bits that feed each half (o = byte offset inside the packed column)
+template <int MODE> __host__ __device__ constexpr uint32_t split_mask_left(int o)
+{
+    return MODE == kDHGR ? 0x00ffu : ((o & 1) ? 0x01ffu : 0x04ffu);
+}
+template <int MODE> __host__ __device__ constexpr uint32_t split_mask_right(int o)
+{
+    return MODE == kDHGR ? 0x1ff0u : ((o & 1) ? 0x3fc8u : 0x3fe0u);
+}
+// the window bits a store replaces (masked_update, screen.py:792-816, 993-1007)
+template <int MODE> __host__ __device__ constexpr uint32_t split_mask_own() { return MODE == kDHGR ? 0x7fu << 3 : 0xffu << 3; }
+
+// row parts (prologue): the window bits of each half, compressed (ascending bit order)
+template <int MODE> __host__ __device__ inline uint32_t split_row_left(uint32_t win, int odd)
+{
+    if (MODE == kDHGR) return win & 0xffu;
+    return odd ? (win & 0x1ffu) : ((win & 0xffu) | (((win >> 10) & 1u) << 8));
+}
+template <int MODE> __host__ __device__ inline uint32_t split_row_right(uint32_t win, int odd)
+{
+    if (MODE == kDHGR) return win >> 4;
+    return odd ? (((win >> 3) & 1u) | ((win >> 6) << 1)) : (win >> 5);
+}
+// content parts (greedy step): the bits of the stored byte that reach each half
+template <int MODE> __host__ __device__ inline uint32_t split_content_left(uint32_t c, int odd)
+{
+    if (MODE == kDHGR) return c & 31u;
+    const uint32_t rc = ((c & 0x7fu) << 1) | (c >> 7);  // odd HGR bytes sit rotated in the column (screen.py:566-569)
+    return odd ? (rc & 63u) : ((c & 31u) | ((c >> 7) << 5));
+}
+template <int MODE> __host__ __device__ inline uint32_t split_content_right(uint32_t c, int odd)
+{
+    if (MODE == kDHGR) return (c >> 1) & 63u;
+    const uint32_t rc = ((c & 0x7fu) << 1) | (c >> 7);
+    return odd ? ((rc & 1u) | ((rc >> 3) << 1)) : (c >> 2);
+}
+template <int MODE> __host__ __device__ constexpr size_t split_left_entries()
+{
+    return (size_t)ModeTraits<MODE>::kOffsets << (SplitTraits<MODE>::kLeftCBits + SplitTraits<MODE>::kLeftRowBits);
+}
+template <int MODE> __host__ __device__ constexpr size_t split_right_entries()
+{
+    return (size_t)ModeTraits<MODE>::kOffsets << (SplitTraits<MODE>::kRightCBits + SplitTraits<MODE>::kRightRowBits);
+}
+constexpr uint32_t kSplitInf = 0x3fffu;  // "no path": finite sums stay below it, and INF + INF fits 16 bits
+
+// S from the two packed halves (lo 16 bits = component 0, hi = component 1)
+__host__ __device__ inline uint32_t split_combine(uint32_t l, uint32_t r)
+{
+    const uint32_t a = (l & 0xffffu) + (r & 0xffffu), b = (l >> 16) + (r >> 16);
+    return a < b ? a : b;
+}
+
+// LDS accesses of one wave execute in order: making one lane's LDS writes visible to the
+// other lanes of the same wave needs no s_barrier, only that the compiler keeps the order.
+__device__ static inline void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// next MT19937 block, one wave, fully unrolled (constant LDS offsets, no loop counters)
+__device__ static inline void mt_twist_wave(const uint32_t *src, uint32_t *dst, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = lane + 64 * k;
+        if (k < 3 || i < 227) dst[i] = src[i + 397] ^ mt_mix(src[i], src[i + 1]);
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = 227 + lane + 64 * k;
+        if (k < 3 || i < 454) dst[i] = dst[i - 227] ^ mt_mix(src[i], src[i + 1]);
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int i = 454 + lane + 64 * k;
+        if (k < 2 || i < 624) {
+            const uint32_t nx = (i == 623) ? dst[0] : src[i + 1];
+            dst[i] = dst[i - 227] ^ mt_mix(src[i], nx);
+        }
+    }
+    wave_lds_sync();
+}
+
+// launchers implemented in iiv_greedy.hip
+struct GreedyArgs {
+    StreamState *states;
+    const uint8_t *frames_main, *frames_aux;
+    int n_frames, n_streams;
+    const LaunchSeg *segs;   // device
+    int seg_stride;          // 0: one descriptor for every stream; 1: descriptor per stream
+    const uint32_t *left, *right;  // split store table
+    uint8_t *ops_out;
+    size_t ops_stride;       // bytes between the outputs of consecutive streams
+};
+int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st);
+
+}  // namespace iiv

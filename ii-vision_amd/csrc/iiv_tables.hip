@@ -12,6 +12,7 @@
 // min-plus recurrence per pair.
 #include "iiv_host.h"
 #include "iiv_edit.h"
+#include "iiv_stream.h"
 
 namespace iiv {
 
@@ -187,6 +188,94 @@ __global__ __launch_bounds__(256) void store_kernel(const ulonglong2 *__restrict
     out[idx] = (uint16_t)edit_distance<ND>(a.x, (uint32_t)a.y, b.x, (uint32_t)b.y, lut);
 }
 
+// ------------------------------------------------------------------ split store table
+// (see iiv_stream.h).  One thread per entry of either half: build a representative window
+// from the entry's row bits (all other bits zero -- they cannot reach this half's pixels),
+// poke the entry's content bits into it, and run the recurrence over this half's pixels:
+// LEFT  = (E[M-1], E[M]) after pixels 1..M;
+// RIGHT = cost of finishing pixels M+1..N from state (0, inf) and from state (inf, 0).
+
+__device__ static inline uint32_t pdep32(uint32_t v, uint32_t mask)
+{
+    uint32_t out = 0;
+    for (int b = 0, k = 0; b < 16; b++)
+        if ((mask >> b) & 1u) out |= ((v >> k++) & 1u) << b;
+    return out;
+}
+
+__device__ static inline uint32_t string_pixel(const ulonglong2 &s, int k)
+{
+    return k < 16 ? (uint32_t)(s.x >> (4 * k)) & 0xfu : (uint32_t)(s.y >> (4 * (k - 16))) & 0xfu;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void split_kernel(const ulonglong2 *__restrict__ strings,
+                                                    const uint16_t *__restrict__ sub, uint32_t *__restrict__ left,
+                                                    uint32_t *__restrict__ right)
+{
+    using T = SplitTraits<MODE>;
+    constexpr int BITS = ModeTraits<MODE>::kBits, ND = ModeTraits<MODE>::kDots;
+    __shared__ uint16_t lut[256];
+    load_cost_lut(lut, sub, threadIdx.x);
+    __syncthreads();
+    const size_t nl = split_left_entries<MODE>(), nr = split_right_entries<MODE>();
+    size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool is_left = idx < nl;
+    if (!is_left) idx -= nl;
+    if (!is_left && idx >= nr) return;
+    const int rb = is_left ? T::kLeftRowBits : T::kRightRowBits, cb = is_left ? T::kLeftCBits : T::kRightCBits;
+    const uint32_t row = idx & ((1u << rb) - 1), cpart = (idx >> rb) & ((1u << cb) - 1);
+    const int o = (int)(idx >> (rb + cb));
+    const uint32_t mask = is_left ? split_mask_left<MODE>(o) : split_mask_right<MODE>(o);
+    const uint32_t own = mask & split_mask_own<MODE>();
+    const uint32_t wt = pdep32(row, mask);
+    const uint32_t ws = (wt & ~own) | pdep32(cpart, own);
+    const ulonglong2 a = strings[((size_t)o << BITS) + ws], b = strings[((size_t)o << BITS) + wt];
+    auto step = [&](int k, uint32_t &e1, uint32_t &e2) {   // pixel k (0-based) of both strings
+        const uint32_t ak = string_pixel(a, k), bk = string_pixel(b, k);
+        uint32_t e = e1 + lut[ak * 16 + bk];
+        if (k >= 1) {
+            const uint32_t ap = string_pixel(a, k - 1), bp = string_pixel(b, k - 1);
+            if (ap == bk && ak == bp && e2 + 1 < e) e = e2 + 1;
+        }
+        e = e < kSplitInf ? e : kSplitInf;
+        e2 = e1;
+        e1 = e;
+    };
+    if (is_left) {
+        uint32_t e1 = 0, e2 = kSplitInf;
+        for (int k = 0; k < T::kCut; k++) step(k, e1, e2);
+        left[idx] = e2 | (e1 << 16);
+    } else {
+        uint32_t r[2];
+        for (int j = 0; j < 2; j++) {
+            uint32_t e2 = j == 0 ? 0u : kSplitInf, e1 = j == 0 ? kSplitInf : 0u;
+            for (int k = T::kCut; k < ND; k++) step(k, e1, e2);
+            r[j] = e1;
+        }
+        right[idx] = r[0] | (r[1] << 16);
+    }
+}
+
+// the dense store table rebuilt from the two halves with the index arithmetic the encoder
+// kernels use (tests compare it with store_kernel's output, entry for entry)
+template <int MODE>
+__global__ __launch_bounds__(256) void split_expand_kernel(const uint32_t *__restrict__ left,
+                                                           const uint32_t *__restrict__ right, uint16_t *__restrict__ out)
+{
+    using T = SplitTraits<MODE>;
+    constexpr int BITS = ModeTraits<MODE>::kBits, CB = ModeTraits<MODE>::kContentBits;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // ((o << CB) + content) << BITS) + m
+    if (idx >= ((size_t)ModeTraits<MODE>::kOffsets << (CB + BITS))) return;
+    const uint32_t m = idx & ((1u << BITS) - 1), c = (idx >> BITS) & ((1u << CB) - 1);
+    const int o = (int)(idx >> (BITS + CB)), odd = o & 1;
+    const uint32_t l = left[(((size_t)o << T::kLeftCBits) + split_content_left<MODE>(c, odd) << T::kLeftRowBits) +
+                            split_row_left<MODE>(m, odd)];
+    const uint32_t r = right[(((size_t)o << T::kRightCBits) + split_content_right<MODE>(c, odd) << T::kRightRowBits) +
+                             split_row_right<MODE>(m, odd)];
+    out[idx] = (uint16_t)split_combine(l, r);
+}
+
 // ------------------------------------------------------------------ host side
 
 // compute_substitute_costs (make_data_tables.py:73-89): the fill loop writes
@@ -283,6 +372,56 @@ int build_store_table(int mode, const int32_t dm[256], uint16_t *d_out, hipStrea
     if (rc) return rc;
     IIV_HIP(hipStreamSynchronize(st));
     return IIV_OK;
+}
+
+// left / right: device buffers of split_left_entries / split_right_entries u32 (iiv_stream.h)
+int build_split_tables(int mode, const ulonglong2 *d_strings, const uint16_t *d_sub, uint32_t *d_left, uint32_t *d_right,
+                       hipStream_t st)
+{
+    const size_t n = mode == kDHGR ? split_left_entries<kDHGR>() + split_right_entries<kDHGR>()
+                                   : split_left_entries<kHGR>() + split_right_entries<kHGR>();
+    dim3 grid((unsigned)((n + 255) / 256));
+    if (mode == kDHGR)
+        hipLaunchKernelGGL(split_kernel<kDHGR>, grid, dim3(256), 0, st, d_strings, d_sub, d_left, d_right);
+    else
+        hipLaunchKernelGGL(split_kernel<kHGR>, grid, dim3(256), 0, st, d_strings, d_sub, d_left, d_right);
+    return hip_check(hipGetLastError(), "split_kernel launch");
+}
+
+size_t split_entries(int mode, int right)
+{
+    if (mode == kDHGR) return right ? split_right_entries<kDHGR>() : split_left_entries<kDHGR>();
+    return right ? split_right_entries<kHGR>() : split_left_entries<kHGR>();
+}
+
+int build_split_store_table(int mode, const int32_t dm[256], uint32_t *d_left, uint32_t *d_right, uint16_t *d_expanded,
+                            hipStream_t st)
+{
+    TableScratch sc;
+    int rc = prepare_scratch(mode, dm, sc, st);
+    if (rc) return rc;
+    uint32_t *tmp_l = nullptr, *tmp_r = nullptr;
+    if (!d_left) { IIV_HIP(hipMalloc(&tmp_l, split_entries(mode, 0) * 4)); d_left = tmp_l; }
+    if (!d_right) {
+        hipError_t he = hipMalloc(&tmp_r, split_entries(mode, 1) * 4);
+        if (he != hipSuccess) { if (tmp_l) (void)hipFree(tmp_l); return hip_check(he, "hipMalloc(split right)"); }
+        d_right = tmp_r;
+    }
+    rc = build_split_tables(mode, sc.strings, sc.sub, d_left, d_right, st);
+    if (!rc && d_expanded) {
+        size_t n = (size_t)num_offsets(mode) << (content_bits(mode) + masked_bits(mode));
+        dim3 grid((unsigned)((n + 255) / 256));
+        if (mode == kDHGR)
+            hipLaunchKernelGGL(split_expand_kernel<kDHGR>, grid, dim3(256), 0, st, d_left, d_right, d_expanded);
+        else
+            hipLaunchKernelGGL(split_expand_kernel<kHGR>, grid, dim3(256), 0, st, d_left, d_right, d_expanded);
+        rc = hip_check(hipGetLastError(), "split_expand_kernel launch");
+    }
+    hipError_t he = hipStreamSynchronize(st);  // scratch is freed on return
+    if (tmp_l) (void)hipFree(tmp_l);
+    if (tmp_r) (void)hipFree(tmp_r);
+    if (rc) return rc;
+    return hip_check(he, "sync");
 }
 
 int cie2000_matrix(const uint8_t rgb[48], double out_f[256], int32_t out_i[256], hipStream_t st)

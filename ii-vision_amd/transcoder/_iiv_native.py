@@ -24,7 +24,6 @@ STATE_RNG_PY, STATE_RNG_NP, STATE_OUT_OF_WORK, STATE_PACKED, STATE_COUNTERS = 4,
 OPT_DIFF_WEIGHTS, DW_TABLE, DW_RECURRENCE = 1, 0, 1
 OPT_GREEDY_KERNEL, GREEDY_WAVE, GREEDY_WORKGROUP, GREEDY_AUTO = 2, 0, 1, 2
 OPT_PREFIX_SORT = 3
-OPT_PACKED_STORE = 4
 
 # every symbol include/iivision.h declares
 SYMBOLS = [
@@ -35,7 +34,9 @@ SYMBOLS = [
     "iiv_pack", "iiv_diff_weights", "iiv_compute_delta_pages",
     "iiv_encoder_create", "iiv_encoder_destroy", "iiv_encoder_set_option",
     "iiv_encoder_snapshot", "iiv_encoder_rollback", "iiv_encoder_get_state", "iiv_encoder_set_state",
-    "iiv_encode", "iiv_encoder_check", "iiv_encoder_profile", "iiv_encoder_profile_read",
+    "iiv_encoder_set_state_range", "iiv_encode", "iiv_encode_streams",
+    "iiv_encoder_check", "iiv_encoder_profile", "iiv_encoder_profile_read",
+    "iiv_build_split_store_table", "iiv_split_table_entries",
     "iiv_emit_stream",
 ]
 
@@ -96,7 +97,12 @@ def lib():
     L.iiv_encoder_destroy.restype = None
     L.iiv_encoder_get_state.argtypes = [vp, i32, i32, vp, sz]
     L.iiv_encoder_set_state.argtypes = [vp, i32, i32, vp, sz]
+    L.iiv_encoder_set_state_range.argtypes = [vp, i32, i32, i32, vp, sz]
     L.iiv_encode.argtypes = [vp, vp, vp, i32, C.POINTER(Segment), i32, vp, vp]
+    L.iiv_encode_streams.argtypes = [vp, vp, vp, i32, C.POINTER(Segment), C.POINTER(C.c_int32), vp, sz, vp]
+    L.iiv_build_split_store_table.argtypes = [i32, vp, vp, vp, vp, vp]
+    L.iiv_split_table_entries.restype = sz
+    L.iiv_split_table_entries.argtypes = [i32, i32]
     L.iiv_encoder_check.argtypes = [vp, C.POINTER(i32), vp]
     L.iiv_encoder_profile.argtypes = [vp, i32]
     L.iiv_encoder_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -182,6 +188,19 @@ def build_store_table(mode, dm):
     return out
 
 
+def build_split_store_table(mode, dm, expanded=True):
+    """(left, right, expanded) device tensors: the two halves of the split store table and
+    (optionally) the dense store table rebuilt from them with the encoder's index arithmetic."""
+    torch = _torch()
+    L = lib()
+    dm = np.ascontiguousarray(dm, dtype=np.int32).reshape(256)
+    left = torch.empty(L.iiv_split_table_entries(mode, 0), dtype=torch.int32, device="cuda")
+    right = torch.empty(L.iiv_split_table_entries(mode, 1), dtype=torch.int32, device="cuda")
+    exp = torch.empty(L.iiv_store_table_entries(mode), dtype=torch.int16, device="cuda") if expanded else None
+    check(L.iiv_build_split_store_table(mode, hptr(dm), dptr(left), dptr(right), dptr(exp), stream_ptr()))
+    return left, right, exp
+
+
 def table_to_numpy(t):
     """u16 view of a table tensor on the host."""
     return t.cpu().numpy().view(np.uint16)
@@ -257,10 +276,6 @@ class Encoder:
     def set_prefix_sort(self, enable):
         check(lib().iiv_encoder_set_option(self._h, OPT_PREFIX_SORT, 1 if enable else 0))
 
-    def set_packed_store(self, enable):
-        """False / True, or 2 = packed in the base + escape form even if 10 bits suffice."""
-        check(lib().iiv_encoder_set_option(self._h, OPT_PACKED_STORE, int(enable)))
-
     def set_diff_weights_mode(self, recurrence):
         check(lib().iiv_encoder_set_option(self._h, OPT_DIFF_WEIGHTS, DW_RECURRENCE if recurrence else DW_TABLE))
 
@@ -296,6 +311,35 @@ class Encoder:
         shape, dt = self._ITEMS[what]
         a = np.ascontiguousarray(value, dtype=dt).reshape(shape)
         check(lib().iiv_encoder_set_state(self._h, int(stream), what, hptr(a), a.nbytes))
+
+    def set_state_all(self, what, values, first=0):
+        """values: (n, ...) array, item `what` of streams first .. first + n - 1 in one upload."""
+        shape, dt = self._ITEMS[what]
+        a = np.ascontiguousarray(values, dtype=dt)
+        n = a.shape[0]
+        a = a.reshape((n,) + shape)
+        check(lib().iiv_encoder_set_state_range(self._h, int(first), int(n), what, hptr(a), a[0].nbytes))
+
+    def encode_streams(self, frames_main, frames_aux, schedules, ops_out=None):
+        """Per-stream schedules: schedules[s] = list of (frame, is_aux, restart, n_ops) of stream s.
+        Returns (ops tensor (n_streams, max total, 6), per-stream totals).  Asynchronous."""
+        torch = _torch()
+        n_frames = frames_main.shape[1]
+        assert frames_main.shape[0] == self.n_streams and frames_main.is_contiguous()
+        assert len(schedules) == self.n_streams
+        flat = [g for sch in schedules for g in sch]
+        segs = (Segment * max(len(flat), 1))(*[Segment(int(f), int(a), int(r), int(k)) for (f, a, r, k) in flat])
+        begin = np.zeros(self.n_streams + 1, dtype=np.int32)
+        begin[1:] = np.cumsum([len(sch) for sch in schedules])
+        totals = [sum(int(g[3]) for g in sch) for sch in schedules]
+        width = max(max(totals), 1)
+        if ops_out is None:
+            ops_out = torch.zeros((self.n_streams, width, 6), dtype=torch.uint8, device="cuda")
+        assert ops_out.is_contiguous() and ops_out.shape[0] == self.n_streams
+        stride = ops_out.shape[1] * 6
+        check(lib().iiv_encode_streams(self._h, dptr(frames_main), dptr(frames_aux), int(n_frames), segs,
+                                       begin.ctypes.data_as(C.POINTER(C.c_int32)), dptr(ops_out), stride, stream_ptr()))
+        return ops_out, totals
 
     def encode(self, frames_main, frames_aux, segments, ops_out=None):
         """frames_*: CUDA uint8 tensors (n_streams, n_frames, 32, 256); segments: list of
@@ -350,7 +394,8 @@ def emit_stream(mode, ops, ticks, tick_addr, ack_addr, terminate_addr, max_bytes
     length = emit_stream_size(mode, n, ta, ack_addr, terminate_addr, max_bytes_out)
     out = torch.empty((S, length), dtype=torch.uint8, device="cuda")
     got = C.c_size_t(0)
-    check(lib().iiv_emit_stream(mode, S, n, dptr(ops.contiguous()), dptr(ticks.contiguous()), hptr(ta), int(ack_addr),
+    ops_c, ticks_c = ops.contiguous(), ticks.contiguous()   # (kept in locals: the call reads their storage)
+    check(lib().iiv_emit_stream(mode, S, n, dptr(ops_c), dptr(ticks_c), hptr(ta), int(ack_addr),
                                 int(terminate_addr), int(max_bytes_out or 0), dptr(out), length, C.byref(got),
                                 stream_ptr()))
     return out

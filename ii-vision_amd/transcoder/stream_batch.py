@@ -186,17 +186,23 @@ class StreamBatch:
         """seeds[i] = (random.seed value, np.random.seed value) of stream i."""
         import random
         keep_py, keep_np = random.getstate(), np.random.get_state()
+        n = len(seeds)
+        py = np.empty((n, 625), dtype=np.uint32)
+        nps = np.empty((n, 625), dtype=np.uint32)
         try:
             for i, (sp, sn) in enumerate(seeds):
                 random.seed(int(sp))
                 np.random.seed(int(sn))
                 st = np.random.get_state()
-                self.enc.set_state(native.STATE_RNG_PY, np.array(random.getstate()[1], dtype=np.uint32), i)
-                self.enc.set_state(native.STATE_RNG_NP, np.concatenate(
-                    [np.asarray(st[1], dtype=np.uint32), np.array([st[2]], dtype=np.uint32)]), i)
+                py[i] = random.getstate()[1]
+                nps[i, :624] = st[1]
+                nps[i, 624] = st[2]
         finally:
             random.setstate(keep_py)
             np.random.set_state(keep_np)
+        # one upload per RNG stream for the whole batch
+        self.enc.set_state_all(native.STATE_RNG_PY, py)
+        self.enc.set_state_all(native.STATE_RNG_NP, nps)
 
     def encode_frames(self, frames_main, frames_aux, n_video_frames, ops_out=None, max_ticks=None):
         """Advance every stream by n_video_frames input frames (targets are

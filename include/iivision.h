@@ -101,14 +101,30 @@ int iiv_compute_delta_pages(int mode, const uint16_t *d_table, int n, const uint
 
 typedef struct iiv_encoder iiv_encoder;
 
+/* The store table split in two halves whose (content, row) slices are 1-2 KiB (see
+ * csrc/iiv_stream.h): value = min(l0 + r0, l1 + r1) of a LEFT and a RIGHT entry, the two
+ * halves of the min-plus recurrence behind every table value (make_data_tables.py:92-108).
+ * It is what the one-wave greedy kernel reads; iiv_encoder_create builds its own copy.
+ * d_left / d_right: iiv_split_table_entries(mode, 0 / 1) u32 each, may be NULL;
+ * d_expanded (may be NULL): the dense table rebuilt from the halves with the encoder's own
+ * index arithmetic, [iiv_store_table_entries] u16 -- equal to iiv_build_store_table's output,
+ * entry for entry (tests).  Synchronises. */
+int iiv_build_split_store_table(int mode, const int32_t dm[256], uint32_t *d_left, uint32_t *d_right,
+                                uint16_t *d_expanded, void *stream);
+size_t iiv_split_table_entries(int mode, int right_half);
+
 /* One encoder = n_streams independent Video objects of one (mode, palette),
  * all state resident in HBM.  d_table = full symmetric table (iiv_build_table),
  * d_store_table = iiv_build_store_table output; both must outlive the encoder.
  * dm = the 16x16 int CIE2000 matrix the tables were built from, or NULL.
  *   dm != NULL (default mode IIV_DW_RECURRENCE): Bitmap.diff_weights values are
  *     recomputed on the fly with the same recurrence that built the table
- *     (bit-identical, no HBM table traffic); d_table may then be NULL.
- *   dm == NULL (IIV_DW_TABLE): they are gathered from d_table (screen.py:436-443).
+ *     (bit-identical, no HBM table traffic); d_table may then be NULL.  The split
+ *     store table of the one-wave greedy kernel is built from dm as well.
+ *   dm == NULL (IIV_DW_TABLE): they are gathered from d_table (screen.py:436-443);
+ *     only the workgroup greedy kernel (which reads d_store_table) is available.
+ * Every table value, and max(dm) * MASKED_DOTS, must be <= 2047 (the kernels pack diff
+ * weights and store values into 11-bit fields): IIV_ERR_INVALID otherwise.
  * Initial state = Video.__init__ (video.py:21-62): blank screen, zero
  * priorities; both RNG streams seeded as random.seed(0) / np.random.seed(0)
  * until set with iiv_encoder_set_state. */
@@ -122,18 +138,11 @@ void iiv_encoder_destroy(iiv_encoder *enc);
 #define IIV_OPT_GREEDY_KERNEL 2 /* shape of the greedy-selection kernel         */
 #define IIV_GREEDY_WAVE 0       /*   one 64-lane wave per stream (throughput)    */
 #define IIV_GREEDY_WORKGROUP 1  /*   one 256-thread workgroup per stream (latency) */
-#define IIV_GREEDY_AUTO 2       /*   default: WAVE when n_streams >= 1536        */
+#define IIV_GREEDY_AUTO 2       /*   default: WAVE when n_streams >= 1536 (and dm was given) */
 #define IIV_OPT_PREFIX_SORT 3    /* 1 (default): when a generator's opcode budget B is known
                                  * (another restart follows in the same iiv_encode call) and
                                  * 3B <= 2048, only that many highest priorities are ordered;
                                  * 0: always order the whole list.  Same output either way. */
-#define IIV_OPT_PACKED_STORE 4   /* 1 (default): the one-wave greedy kernel reads a 10-bit repack of
-                                 * the store table made at creation (3 values per 32-bit word, a
-                                 * per-word base and an escape to d_store where 10 bits do not do;
-                                 * HGR lookups are also folded onto one half of the symmetric
-                                 * table).  d_store must not change while the encoder lives.
-                                 * 0: it reads d_store itself.  2: like 1, but always in the
-                                 * base + escape form (tests).  Same output either way. */
 int iiv_encoder_set_option(iiv_encoder *enc, int option, int value);
 
 /* state items, per stream */
@@ -148,6 +157,10 @@ int iiv_encoder_set_option(iiv_encoder *enc, int option, int value);
 #define IIV_STATE_COUNTERS 8 /* get only: u64[4] = draws_py, draws_np, ops, pad_ops */
 int iiv_encoder_get_state(iiv_encoder *enc, int stream_index, int what, void *host_buf, size_t bytes);
 int iiv_encoder_set_state(iiv_encoder *enc, int stream_index, int what, const void *host_buf, size_t bytes);
+/* the same item of n_streams consecutive streams in one upload: host_buf holds n_streams
+ * items of bytes_per_stream back to back (e.g. the seeds of every stream of a batch) */
+int iiv_encoder_set_state_range(iiv_encoder *enc, int first_stream, int n_streams, int what, const void *host_buf,
+                                size_t bytes_per_stream);
 
 /* Copy / restore the complete state of every stream (screen, priorities, live
  * generator, both RNG streams) on the device.  A caller that must not run ahead of
@@ -180,6 +193,17 @@ typedef struct {
 int iiv_encode(iiv_encoder *enc, const uint8_t *d_frames_main, const uint8_t *d_frames_aux,
                int n_frames, const iiv_segment *segments, int n_segments, uint8_t *d_ops_out,
                void *stream);
+
+/* The same for streams that do NOT share a schedule -- clips of different length, frame
+ * rate or every_n_video_frames, each with its own movie.Movie clock (movie.py:16-54):
+ * stream s runs segments[seg_begin[s] .. seg_begin[s + 1]) (seg_begin has n_streams + 1
+ * entries).  The r-th opcode-emitting segments of all streams share a launch; streams with
+ * fewer segments idle.  d_ops_out: stream s writes at d_ops_out + s * ops_stride (bytes),
+ * which must hold 6 * (its total n_ops) bytes.  After this call the streams' generators
+ * differ, so keep using iiv_encode_streams for this encoder. */
+int iiv_encode_streams(iiv_encoder *enc, const uint8_t *d_frames_main, const uint8_t *d_frames_aux,
+                       int n_frames, const iiv_segment *segments, const int32_t *seg_begin,
+                       uint8_t *d_ops_out, size_t ops_stride, void *stream);
 
 /* Synchronises `stream` and returns IIV_ERR_ASSERT / IIV_ERR_OVERFLOW if any
  * stream hit one of the reference's asserts (video.py:87,117,124,137,154-155)

@@ -47,12 +47,11 @@ for rnd in range(rounds):
             ia = int(rng.integers(0, 2)) if mode == 1 else 0
         sched.append((f, ia, restart, k))
     wave = bool(rng.random() < 0.75)
-    packed = int(rng.choice([0, 1, 1, 2]))
     recurrence = bool(rng.random() < 0.8)
     prefix = bool(rng.random() < 0.7)
-    enc = native.Encoder(mode, dtab[key][0], dtab[key][1], n, dm=dms[pal] if recurrence else None)
+    enc = native.Encoder(mode, dtab[key][0], dtab[key][1], n, dm=dms[pal])
+    enc.set_diff_weights_mode(recurrence)
     enc.set_greedy_kernel(wave)
-    enc.set_packed_store(packed)
     enc.set_prefix_sort(prefix)
     seeds = [(int(rng.integers(1 << 20)), int(rng.integers(1 << 20))) for _ in range(n)]
     for i, (sp, sn) in enumerate(seeds):
@@ -69,7 +68,7 @@ for rnd in range(rounds):
             if k:
                 exp.append(v.next(k))
         exp = np.concatenate(exp) if exp else np.zeros((0, 6), np.uint8)
-        assert (got[i] == exp).all(), ("opcodes", rnd, i, mode, pal, kind, wave, packed, recurrence, prefix, sched)
+        assert (got[i] == exp).all(), ("opcodes", rnd, i, mode, pal, kind, wave, recurrence, prefix, sched)
         assert (enc.get_state(native.STATE_UP_MAIN, i) == v.update_priority(0)).all(), ("up", rnd, i)
         assert (enc.get_state(native.STATE_MEM_MAIN, i) == v.memory(0)).all(), ("mem", rnd, i)
         if mode == 1:
@@ -78,6 +77,6 @@ for rnd in range(rounds):
         assert (int(cnt[0]), int(cnt[1])) == v.draws(), ("draws", rnd, i)
         total_ops += exp.shape[0]
     enc.close()
-    print("round %2d ok: mode=%s pal=%d %s wave=%d packed=%d rec=%d prefix=%d segs=%s" % (
-        rnd, "DHGR" if mode else "HGR", pal, kind, wave, packed, recurrence, prefix, [s[3] for s in sched]), flush=True)
+    print("round %2d ok: mode=%s pal=%d %s wave=%d rec=%d prefix=%d segs=%s" % (
+        rnd, "DHGR" if mode else "HGR", pal, kind, wave, recurrence, prefix, [s[3] for s in sched]), flush=True)
 print("fuzz parity: %d rounds, %d opcodes compared, all equal (%.0f s)" % (rounds, total_ops, time.time() - t_start))

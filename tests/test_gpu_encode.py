@@ -23,21 +23,20 @@ def _seed_states(O, seed_py, seed_np):
 
 
 def _run_device(native, device_tables, mode, pal, frames_list, sched, seeds, recurrence=True, wave=True,
-                prefix_sort=True, packed_store=True):
+                prefix_sort=True):
     """frames_list: list (per stream) of (n_frames, banks, 32, 256) arrays."""
     import torch
     t, s = device_tables.get(mode, pal)
     n = len(frames_list)
-    enc = native.Encoder(mode, t, s, n, dm=device_tables.dm[(mode, pal)] if recurrence else None)
+    enc = native.Encoder(mode, t, s, n, dm=device_tables.dm[(mode, pal)])
+    enc.set_diff_weights_mode(recurrence)
     enc.set_greedy_kernel(wave)
     enc.set_prefix_sort(prefix_sort)
-    enc.set_packed_store(packed_store)
     fr = np.stack(frames_list)
     fm = torch.from_numpy(np.ascontiguousarray(fr[:, :, 0])).cuda()
     fa = torch.from_numpy(np.ascontiguousarray(fr[:, :, 1])).cuda() if mode == 1 else None
-    for i, (py, npw) in enumerate(seeds):
-        enc.set_state(native.STATE_RNG_PY, py, i)
-        enc.set_state(native.STATE_RNG_NP, npw, i)
+    enc.set_state_all(native.STATE_RNG_PY, np.stack([py for py, _ in seeds]))
+    enc.set_state_all(native.STATE_RNG_NP, np.stack([npw for _, npw in seeds]))
     segs = [(int(f), int(a), 1, int(k)) for (f, a, k) in sched]
     ops = enc.encode(fm, fa, segs)
     enc.check()
@@ -52,19 +51,18 @@ def _next_draws(O, words, n, high):
     return [f(C.byref(m)) for _ in range(n)]
 
 
-@pytest.mark.parametrize("recurrence,wave,packed", [(True, True, True), (False, True, True), (True, False, True),
-                                                    (True, True, False), (True, True, 2)])
-def test_golden_runs(native, O, golden, device_tables, recurrence, wave, packed):
+@pytest.mark.parametrize("recurrence,wave", [(True, True), (False, True), (True, False), (False, False)])
+def test_golden_runs(native, O, golden, device_tables, recurrence, wave):
     """recurrence=True: diff weights recomputed in the prologue; False: gathered from
-    the HBM table.  wave=True: one wave per stream; False: one 256-thread workgroup
-    per stream.  packed: the wave kernel reads the 10-bit repack of the store table (2: in its
-    base + escape form even where 10 bits suffice) or the u16 table itself.  Every combination must reproduce the reference bit for bit."""
+    the HBM table.  wave=True: one wave per stream reading the split store table; False: one
+    256-thread workgroup per stream reading the dense u16 store table.  Every combination must
+    reproduce the reference bit for bit."""
     g3 = golden.g3_encode_runs
     for tag in _tags(g3):
         mode, pal, sp, sn = (int(x) for x in g3[tag + "/meta"])
         frames, sched, ops = g3[tag + "/frames"], g3[tag + "/schedule"], g3[tag + "/ops"]
         enc, got = _run_device(native, device_tables, mode, pal, [frames], sched, [_seed_states(O, sp, sn)],
-                               recurrence=recurrence, wave=wave, packed_store=packed)
+                               recurrence=recurrence, wave=wave)
         bad = np.nonzero((got[0] != ops).any(axis=1))[0]
         assert len(bad) == 0, "%s: first mismatch at op %d: got %s want %s" % (
             tag, bad[0], got[0][bad[0]], ops[bad[0]])
@@ -110,10 +108,9 @@ def _oracle_run(O, oracle_tables, mode, pal, frames, sched, sp, sn):
     return v, np.concatenate(out)
 
 
-@pytest.mark.parametrize("mode,wave,prefix,packed", [(1, True, True, True), (0, True, True, True),
-                                                     (1, False, True, True), (1, True, False, True),
-                                                     (1, True, True, False)])
-def test_batch_of_independent_streams(native, O, oracle_tables, device_tables, mode, wave, prefix, packed):
+@pytest.mark.parametrize("mode,wave,prefix", [(1, True, True), (0, True, True), (1, False, True), (1, True, False),
+                                              (0, False, False)])
+def test_batch_of_independent_streams(native, O, oracle_tables, device_tables, mode, wave, prefix):
     """12 streams with different data / seeds / coherence in ONE launch sequence,
     ragged segment lengths incl. bank flips; every stream equals its own oracle run."""
     n = 12
@@ -121,8 +118,7 @@ def test_batch_of_independent_streams(native, O, oracle_tables, device_tables, m
     frames = [_synth(mode, 3, 100 + i, coherent=(i % 2 == 1)) for i in range(n)]
     seeds = [(i + 1, 1000 + i) for i in range(n)]
     enc, got = _run_device(native, device_tables, mode, 5, frames, sched,
-                           [_seed_states(O, a, b) for a, b in seeds], wave=wave, prefix_sort=prefix,
-                           packed_store=packed)
+                           [_seed_states(O, a, b) for a, b in seeds], wave=wave, prefix_sort=prefix)
     for i in range(n):
         v, exp = _oracle_run(O, oracle_tables, mode, 5, frames[i], sched, *seeds[i])
         assert (got[i] == exp).all(), "stream %d" % i
@@ -225,4 +221,57 @@ def test_image_like_streams(native, O, oracle_tables, device_tables, mode, wave)
         assert (enc.get_state(native.STATE_PACKED, i) == v.packed).all()
         cnt = enc.get_state(native.STATE_COUNTERS, i)
         assert (int(cnt[0]), int(cnt[1])) == v.draws()
+    enc.close()
+
+
+@pytest.mark.parametrize("mode,wave", [(1, True), (0, True), (1, False)])
+def test_per_stream_schedules(native, O, oracle_tables, device_tables, mode, wave):
+    """iiv_encode_streams: every stream has its own movie clock (movie.py:16-54) -- different
+    clip lengths, every_n_video_frames and frame rates in ONE batch, over two calls so that
+    generators are continued across calls.  Each stream equals its own oracle run."""
+    import torch
+    import stream_batch
+    n, nf = 7, 6
+    frames = [_synth(mode, nf, 300 + i, coherent=(i % 3 == 0)) for i in range(n)]
+    seeds = [(11 + i, 500 + i) for i in range(n)]
+    t, s = device_tables.get(mode)
+    enc = native.Encoder(mode, t, s, n, dm=device_tables.dm[(mode, 5)])
+    enc.set_greedy_kernel(wave)
+    st = [_seed_states(O, a, b) for a, b in seeds]
+    enc.set_state_all(native.STATE_RNG_PY, np.stack([x for x, _ in st]))
+    enc.set_state_all(native.STATE_RNG_NP, np.stack([y for _, y in st]))
+    fr = np.stack(frames)
+    fm = torch.from_numpy(np.ascontiguousarray(fr[:, :, 0])).cuda()
+    fa = torch.from_numpy(np.ascontiguousarray(fr[:, :, 1])).cuda() if mode == 1 else None
+    clocks = [stream_batch.MovieClock(mode == 1, every_n_video_frames=1 + i % 3, input_frame_rate=(30.0, 24.0, 60.0)[i % 3])
+              for i in range(n)]
+    lengths = [nf - (i % 3) for i in range(n)]              # clips of 6, 5, 4 frames
+    got = [[] for _ in range(n)]
+    scheds = [[] for _ in range(n)]
+    for part in range(2):
+        sch = []
+        for i in range(n):
+            k = lengths[i] // 2 if part == 0 else lengths[i] - lengths[i] // 2
+            sch.append(clocks[i].segments(k))
+            scheds[i] += sch[-1]
+        ops, totals = enc.encode_streams(fm, fa, sch)
+        enc.check()
+        ops = ops.cpu().numpy()
+        for i in range(n):
+            got[i].append(ops[i, :totals[i]])
+    assert len(set(len(x) for x in scheds)) > 1              # really different schedules
+    for i in range(n):
+        v = O.Video(mode, oracle_tables.get(mode), seed_py=seeds[i][0], seed_np=seeds[i][1])
+        exp = []
+        for (f, ia, restart, k) in scheds[i]:
+            if restart:
+                v.encode_frame(frames[i][f, 0], frames[i][f, 1] if mode == 1 else None, ia)
+            exp.append(v.next(k))
+        exp = np.concatenate(exp)
+        g = np.concatenate(got[i])
+        assert g.shape == exp.shape and (g == exp).all(), "stream %d" % i
+        assert (enc.get_state(native.STATE_UP_MAIN, i) == v.update_priority(0)).all()
+        assert (enc.get_state(native.STATE_MEM_MAIN, i) == v.memory(0)).all()
+    with pytest.raises(native.IIVError):
+        enc.encode(fm, fa, [(0, 0, 1, 5)])                   # the streams no longer share a schedule
     enc.close()

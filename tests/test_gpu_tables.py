@@ -84,26 +84,45 @@ def test_table_symmetry_properties(native, device_tables):
         assert int(torch.diagonal(m).abs().sum()) == 0
 
 
-@pytest.mark.parametrize("mode", [0, 1])
-def test_store_table_content_body_symmetry(native, device_tables, mode):
-    """The property the HGR wave kernel relies on to touch only half of its store table:
-    S[o][c][(h, B, f)] == S[o][c'][(h, C, f)], C = content c in window form, c' = the byte whose
-    window form is the body B (HGR odd bytes sit rotated by one bit in their window)."""
-    _, s = device_tables.get(mode)
+@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("pal", [5, 0])
+def test_split_store_table_is_exact(native, device_tables, dms, mode, pal):
+    """The split store table the one-wave greedy kernel reads (csrc/iiv_stream.h): the
+    min-plus recurrence behind every value is cut in the middle of the colour string, and
+    value = min(l0 + r0, l1 + r1) of a left and a right entry.  Expanded with the encoder's
+    own index arithmetic it must equal the dense store table for EVERY (offset, content,
+    window) -- both modes, both palettes."""
+    import torch
+    _, dense = device_tables.get(mode, pal)
+    left, right, exp = native.build_split_store_table(mode, dms[pal])
+    assert bool((exp == dense).all())
     L = native.lib()
-    bits, noff = L.iiv_masked_bits(mode), L.iiv_num_offsets(mode)
-    cb = 7 if mode == 1 else 8
-    S = native.table_to_numpy(s).reshape(noff, 1 << cb, 1 << bits)
-    bm = (1 << cb) - 1
-    t = np.arange(1 << bits, dtype=np.int64)
-    B = (t >> 3) & bm
-    for o in range(noff):
-        rot = mode == 0 and o == 1
-        cprime = ((B >> 1) | ((B & 1) << 7)) if rot else B
-        for c in range(0, 1 << cb, 5):
-            C = (((c & 0x7f) << 1) | (c >> 7)) if rot else c
-            tprime = (t & ~(bm << 3)) | (C << 3)
-            assert np.array_equal(S[o, c, t], S[o, cprime, tprime]), (o, c)
+    assert left.numel() == L.iiv_split_table_entries(mode, 0) and right.numel() == L.iiv_split_table_entries(mode, 1)
+    # the halves are what makes the table small: 0.5 - 0.6 MiB instead of 8 / 16 MiB
+    assert 4 * (left.numel() + right.numel()) <= (640 << 10)
+    # left = (E[M-1], E[M]) are finite; right component 0 is "no path" (0x3fff) unless the pixels
+    # across the cut can be transposed
+    l, r = left.cpu().numpy().view(np.uint32), right.cpu().numpy().view(np.uint32)
+    assert int((l & 0xffff).max()) <= 2047 and int((l >> 16).max()) <= 2047 and int((r >> 16).max()) <= 2047
+    assert set(np.unique(r & 0xffff)) - set(range(2048)) <= {0x3fff}
+
+
+def test_encoder_rejects_values_beyond_its_key_fields(native, device_tables):
+    """diff weights and store values are packed into 11-bit fields; a diff matrix
+    or a table that exceeds them must be refused at creation instead of reordering opcodes."""
+    import torch
+    t, s = device_tables.get(1)
+    with pytest.raises(native.IIVError):
+        native.Encoder(1, t, s, 1, dm=np.full(256, 205, np.int32))    # 205 * 10 dots > 2047
+    big = s.clone()
+    big.view(-1)[12345] = 2048
+    with pytest.raises(native.IIVError):
+        native.Encoder(1, t, big, 1, dm=device_tables.dm[(1, 5)])
+    bigt = torch.zeros_like(t)
+    bigt.view(-1)[777] = 3000
+    with pytest.raises(native.IIVError):
+        native.Encoder(1, bigt, s, 1)                                   # table mode: the table is scanned too
+    native.Encoder(1, t, s, 1, dm=device_tables.dm[(1, 5)]).close()     # (the real ones are fine)
 
 
 def test_rejects_bad_arguments(native):
