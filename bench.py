@@ -82,6 +82,7 @@ def parse_args():
     ap.add_argument("--greedy", choices=["auto", "wave", "workgroup"], default="auto",
                     help="greedy kernel shape: one wave per stream, one 256-thread workgroup per stream, or auto")
     ap.add_argument("--full-sort", action="store_true", help="disable the prologue's prefix sort")
+    ap.add_argument("--lds-pad", type=int, default=-1, help="tuning: extra LDS bytes per greedy wave (caps streams per CU)")
     ap.add_argument("--single-stream", action="store_true", help="also time one clip alone (latency-bound rate)")
     return ap.parse_args()
 
@@ -140,6 +141,8 @@ def main():
     batch.enc.set_greedy_kernel(None if args.greedy == "auto" else args.greedy == "wave")
     if args.full_sort:
         batch.enc.set_prefix_sort(False)
+    if args.lds_pad >= 0:
+        batch.enc.set_greedy_lds_pad(args.lds_pad)
     ops_buf = torch.empty((S, F * OPS_PER_FRAME, 6), dtype=torch.uint8, device="cuda")
 
     def barrier():

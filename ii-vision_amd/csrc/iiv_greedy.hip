@@ -584,10 +584,10 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
 int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st)
 {
     if (mode == kDHGR)
-        hipLaunchKernelGGL(greedy_wave_kernel<kDHGR>, dim3(a.n_streams), dim3(64), 0, st, a.states, a.frames_main,
+        hipLaunchKernelGGL(greedy_wave_kernel<kDHGR>, dim3(a.n_streams), dim3(64), (size_t)a.lds_pad, st, a.states, a.frames_main,
                            a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.left, a.right, a.ops_out, a.ops_stride);
     else
-        hipLaunchKernelGGL(greedy_wave_kernel<kHGR>, dim3(a.n_streams), dim3(64), 0, st, a.states, a.frames_main,
+        hipLaunchKernelGGL(greedy_wave_kernel<kHGR>, dim3(a.n_streams), dim3(64), (size_t)a.lds_pad, st, a.states, a.frames_main,
                            a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.left, a.right, a.ops_out, a.ops_stride);
     return hip_check(hipGetLastError(), "greedy_wave_kernel launch");
 }

@@ -183,6 +183,7 @@ struct GreedyArgs {
     const uint32_t *left, *right;  // split store table
     uint8_t *ops_out;
     size_t ops_stride;       // bytes between the outputs of consecutive streams
+    int lds_pad;             // extra dynamic LDS per stream (bytes): caps the streams resident per CU
 };
 int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st);
 

@@ -24,6 +24,7 @@ STATE_RNG_PY, STATE_RNG_NP, STATE_OUT_OF_WORK, STATE_PACKED, STATE_COUNTERS = 4,
 OPT_DIFF_WEIGHTS, DW_TABLE, DW_RECURRENCE = 1, 0, 1
 OPT_GREEDY_KERNEL, GREEDY_WAVE, GREEDY_WORKGROUP, GREEDY_AUTO = 2, 0, 1, 2
 OPT_PREFIX_SORT = 3
+OPT_GREEDY_LDS_PAD = 5
 
 # every symbol include/iivision.h declares
 SYMBOLS = [
@@ -275,6 +276,9 @@ class Encoder:
 
     def set_prefix_sort(self, enable):
         check(lib().iiv_encoder_set_option(self._h, OPT_PREFIX_SORT, 1 if enable else 0))
+
+    def set_greedy_lds_pad(self, n_bytes):
+        check(lib().iiv_encoder_set_option(self._h, OPT_GREEDY_LDS_PAD, int(n_bytes)))
 
     def set_diff_weights_mode(self, recurrence):
         check(lib().iiv_encoder_set_option(self._h, OPT_DIFF_WEIGHTS, DW_RECURRENCE if recurrence else DW_TABLE))

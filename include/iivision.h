@@ -143,6 +143,10 @@ void iiv_encoder_destroy(iiv_encoder *enc);
                                  * (another restart follows in the same iiv_encode call) and
                                  * 3B <= 2048, only that many highest priorities are ordered;
                                  * 0: always order the whole list.  Same output either way. */
+#define IIV_OPT_GREEDY_LDS_PAD 5 /* tuning: extra LDS bytes per stream of the one-wave greedy kernel
+                                  * (default 0), which caps how many streams are resident per CU:
+                                  * a batch whose size is a whole multiple of the resident streams
+                                  * finishes its launches without a half-empty last round */
 int iiv_encoder_set_option(iiv_encoder *enc, int option, int value);
 
 /* state items, per stream */
