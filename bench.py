@@ -1,26 +1,33 @@
 #!/usr/bin/env python3
-"""DHGR frames transcoded per second on MI355X (BASELINE.json metric).
+"""DHGR frames transcoded per second on MI355X (BASELINE.json metric) + make_data_tables wall-clock.
 
-    python bench.py --gpus N --steps K --warmup W [--streams S] [--frames-per-step F]
+    python bench.py --gpus N --steps K --warmup W [--mode DHGR|HGR] [--palette NTSC|IIGS] [--streams S] [--emit]
 
-Workload (BASELINE.json configs[3]): DHGR, NTSC palette, synthetic
-560x192 S-iid clips, driver = movie.Movie.encode control flow without audio (490
-opcodes per 30 fps frame, bank flip every 2 KiB of output).  One video is a strictly
-sequential chain, so a GPU is filled with S independent clips (one workgroup each,
-no exchange between them); N GPUs run N*S clips with no collective on the data path
-("weak" scaling).  A step = --frames-per-step consecutive frames of every clip; the
-defaults (20 steps x 50 frames) make each clip 1000 frames long.
+Workload (BASELINE.json configs[3]; configs[2] with --mode HGR; configs[4] with --palette IIGS
+under torchrun on 8 GPUs): synthetic 560x192 (280x192) S-iid clips, driver =
+movie.Movie.encode control flow without audio (490 opcodes per 30 fps frame, DHGR bank flip
+every 2 KiB of output).  One video is a strictly sequential chain, so a GPU is filled with S
+independent clips (one wave each, no exchange between them); N GPUs run N*S clips with no
+collective on the data path ("weak" scaling).  A step = --frames-per-step consecutive frames
+of every clip; the defaults (20 steps x 50 frames) make each clip 1000 frames long.
 
-Inputs (targets, tables, stream state) are resident in HBM before the timed
-region.  The timed region is exactly K steps, bracketed by barrier +
-torch.cuda.synchronize() on both sides; the reported time is the MAX over ranks.
+Inputs (targets, tables, stream state) are resident in HBM before the timed region.  The timed
+region is exactly K steps, bracketed by barrier + torch.cuda.synchronize() on both sides; the
+reported time is the MAX over ranks.
 
 Extra objects on the JSON line:
-  roofline      greedy_kernel (dominant): algorithmic bytes per launch (534 B per
-                opcode) / mean launch duration from HIP events
-                recorded on the launch stream, against the 8 TB/s HBM peak.
-  cpu_baseline  the oracle (C port of the reference path, single thread) timed on
-                this host on a bounded sample of the same workload.
+  roofline            greedy_wave_kernel (dominant): algorithmic bytes per launch (534 B per opcode,
+                      SURVEY.md 8d) / mean launch duration from HIP events recorded on the launch
+                      stream, against the 8 TB/s HBM peak; traffic from profiles/pmc_latest.json.
+  cpu_baseline        the oracle (C port of the reference path, one thread) timed on this host on a
+                      bounded sample of the same workload; it also checks the GPU's opcodes of clip 0.
+  vs_reference_python GPU / port-on-this-box x (port / reference Python, measured in the build
+                      container: profiles/reference_ratio.json).
+  make_data_tables_s  wall-clock of make_data_tables.main(): both palettes, HGR + DHGR, four files in
+                      the reference's format (BASELINE metric M2; README: ~90 min).
+  single_stream       one clip alone (latency-bound rate).
+  emit (with --emit)  the same K steps again with the opcodes turned into the .a2m byte stream on the
+                      device (iiv_emit_chunk) and copied to pinned host memory, double-buffered.
 """
 
 import argparse
@@ -39,7 +46,7 @@ BYTES_PER_OPCODE = 534             # 256 x 2 B gathers + 6 B out
 BYTES_PER_PROLOGUE = 147456        # 2 x 32 KiB packed + 16 KiB gathers + 64 KiB priority r/w
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
 HBM_MEASURED_READ_GBS = 5990.0     # tools/hbm_copy_bench.py on the same box (profiles/r01f_hbm_copy.txt); copy 4610, write 6900
-GATHER_CEILING_LINES_PER_S = 265e9  # tools/gather_bench.hip, MI355X: 0.43 distinct lines / CU / cycle
+PALETTE_IDS = {"NTSC": 5, "IIGS": 0}   # palette.py:18-23
 
 
 def rank_seeds(rank, streams):
@@ -62,19 +69,22 @@ def max_over_ranks(elapsed, device, world):
     return float(t.item())
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("IIV_BENCH_STREAMS", "0")),
                     help="independent clips per GPU (0 = the largest of 12288 / 6144 / 3072 / 1536 whose clips fit "
-                         "the free HBM: 6144 fill the GPU at 24 per CU, twice as many hide the tail of a launch)")
+                         "the free HBM: ~7000 fill the GPU, more hide the tail of a launch)")
     ap.add_argument("--frames-per-step", type=int, default=50)
     ap.add_argument("--mode", choices=["DHGR", "HGR"], default="DHGR")
+    ap.add_argument("--palette", choices=sorted(PALETTE_IDS), default="NTSC",
+                    help="NTSC (main.py's default) or IIGS = the //gs RGB palette of BASELINE config 5")
     ap.add_argument("--coherent", action="store_true", help="S-coh input instead of S-iid")
     ap.add_argument("--img", action="store_true", help="S-img input (dithered moving bars) instead of S-iid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip make_data_tables / single-stream (profiling runs)")
     ap.add_argument("--cpu-frames", type=int, default=600, help="frames of stream 0 the CPU baseline encodes")
     ap.add_argument("--cpu-frames-all", type=int, default=60, help="frames per stream of the all-cores CPU baseline")
     ap.add_argument("--dw-table", action="store_true",
@@ -83,101 +93,155 @@ def parse_args():
                     help="greedy kernel shape: one wave per stream, one 256-thread workgroup per stream, or auto")
     ap.add_argument("--full-sort", action="store_true", help="disable the prologue's prefix sort")
     ap.add_argument("--lds-pad", type=int, default=-1, help="tuning: extra LDS bytes per greedy wave (caps streams per CU)")
-    ap.add_argument("--single-stream", action="store_true", help="also time one clip alone (latency-bound rate)")
-    return ap.parse_args()
+    ap.add_argument("--emit", action="store_true",
+                    help="also time encode -> .a2m byte emission -> pinned host memory (end to end)")
+    return ap.parse_args(argv)
 
 
-def main():
-    args = parse_args()
-    import numpy as np
-    import torch
+class GpuBackend:
+    """Everything bench.main() does on the device.  tests/test_multiprocess_gloo.py runs main() with
+    a CPU stand-in for this class, so that the multi-rank control flow is executed before hardware sees it."""
+
+    dist_backend = "nccl"
+    is_gpu = True
+
+    def __init__(self, args, local_rank, world):
+        import torch
+        import _iiv_native as native
+        import stream_batch
+        self.torch, self.native, self.sb = torch, native, stream_batch
+        torch.cuda.set_device(local_rank if world > 1 else 0)
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.args = args
+        self.mode = native.DHGR if args.mode == "DHGR" else native.HGR
+        self.dhgr = self.mode == native.DHGR
+
+    def dist_kwargs(self):
+        return {"device_id": self.device}
+
+    def free_bytes(self):
+        return self.torch.cuda.mem_get_info()[0]
+
+    def synchronize(self):
+        self.torch.cuda.synchronize()
+
+    def build_tables(self):
+        import palette
+        t = time.time()
+        pal = palette.PALETTES[palette.Palette(PALETTE_IDS[self.args.palette])]
+        _, self.dm = self.native.cie2000_matrix(pal.rgb_array())
+        self.table = self.native.build_table(self.mode, self.dm, True)
+        self.store = self.native.build_store_table(self.mode, self.dm)
+        self.synchronize()
+        return time.time() - t
+
+    def make_clips(self, S, n_frames, seed):
+        a = self.args
+        if a.img:
+            self.fm, self.fa = self.sb.synth_frames_img(S, n_frames, self.dhgr, seed=seed)
+        else:
+            self.fm, self.fa = self.sb.synth_frames_torch(S, n_frames, self.dhgr, seed=seed, coherent=a.coherent)
+
+    def make_batch(self, S, seeds):
+        a = self.args
+        b = self.sb.StreamBatch(self.mode, self.table, self.store, S, seeds=seeds, dm=self.dm)
+        if a.dw_table:
+            b.enc.set_diff_weights_mode(False)
+        b.enc.set_greedy_kernel(None if a.greedy == "auto" else a.greedy == "wave")
+        if a.full_sort:
+            b.enc.set_prefix_sort(False)
+        if a.lds_pad >= 0:
+            b.enc.set_greedy_lds_pad(a.lds_pad)
+        self.batch = b
+        self.S = S
+        self.ops_buf = self.torch.empty((S, a.frames_per_step * OPS_PER_FRAME, 6), dtype=self.torch.uint8, device="cuda")
+        return b
+
+    def step(self):
+        """One step of every clip; returns the segments it ran."""
+        _, segs = self.batch.encode_frames(self.fm, self.fa, self.args.frames_per_step, self.ops_buf)
+        return segs
+
+    def first_ops(self, segs):
+        """Clip 0's opcodes of the step just run (streams are packed at the call's own opcode count)."""
+        n = sum(s[3] for s in segs)
+        return self.ops_buf.view(-1)[: 6 * n].clone().view(-1, 6)
+
+    def check(self):
+        self.batch.enc.check()
+
+    def profile(self, on):
+        self.batch.enc.profile(on)
+
+    def profile_read(self):
+        return self.batch.enc.profile_read()
+
+    def uses_wave_kernel(self):
+        return self.args.greedy == "wave" or (self.args.greedy == "auto" and self.S >= 1536)
+
+
+def main(argv=None, backend_cls=GpuBackend):
+    args = parse_args(argv)
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    be = backend_cls(args, local_rank, world)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
+        dist.init_process_group(be.dist_backend, **be.dist_kwargs())
     n_gpus = max(world, 1)
-
-    import _iiv_native as native
-    import stream_batch
-
-    mode = native.DHGR if args.mode == "DHGR" else native.HGR
-    dhgr = mode == native.DHGR
+    dhgr = args.mode == "DHGR"
     F = args.frames_per_step
     total_steps = args.warmup + args.steps
     n_frames = total_steps * F
     S = args.streams
     if S <= 0:
-        free_b, _ = torch.cuda.mem_get_info()
-        per_clip = n_frames * 8192 * (2 if dhgr else 1) + 260 * 1024 + F * 490 * 6   # frames + stream state + opcodes
-        S = next((c for c in (12288, 6144, 3072, 1536) if c * per_clip + (3 << 30) <= 0.85 * free_b), 1536)
+        per_clip = n_frames * 8192 * (2 if dhgr else 1) + 260 * 1024 + F * OPS_PER_FRAME * 6   # frames + stream state + opcodes
+        S = next((c for c in (12288, 6144, 3072, 1536) if c * per_clip + (3 << 30) <= 0.85 * be.free_bytes()), 1536)
         if world > 1:   # every rank runs the same number of clips
-            t = torch.tensor([S], dtype=torch.int64, device="cuda")
+            import torch
+            t = torch.tensor([S], dtype=torch.int64, device=be.device)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             S = int(t.item())
 
     # ---- setup (untimed): tables, synthetic clips, stream state, all in HBM
-    t_tab = time.time()
-    import palette
-    _, dm = native.cie2000_matrix(palette.NTSCPalette.rgb_array())
-    table = native.build_table(mode, dm, True)
-    store = native.build_store_table(mode, dm)
-    torch.cuda.synchronize()
-    t_tab = time.time() - t_tab
-    if args.img:
-        fm, fa = stream_batch.synth_frames_img(S, n_frames, dhgr, seed=data_seed(rank))
-    else:
-        fm, fa = stream_batch.synth_frames_torch(S, n_frames, dhgr, seed=data_seed(rank), coherent=args.coherent)
+    t_tab = be.build_tables()
+    be.make_clips(S, n_frames, data_seed(rank))
     seeds = rank_seeds(rank, S)
-    batch = stream_batch.StreamBatch(mode, table, store, S, seeds=seeds, dm=dm)
-    if args.dw_table:
-        batch.enc.set_diff_weights_mode(False)
-    batch.enc.set_greedy_kernel(None if args.greedy == "auto" else args.greedy == "wave")
-    if args.full_sort:
-        batch.enc.set_prefix_sort(False)
-    if args.lds_pad >= 0:
-        batch.enc.set_greedy_lds_pad(args.lds_pad)
-    ops_buf = torch.empty((S, F * OPS_PER_FRAME, 6), dtype=torch.uint8, device="cuda")
+    be.make_batch(S, seeds)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    def run_step():
-        return batch.encode_frames(fm, fa, F, ops_buf)
-
     first_ops = None   # stream 0's opcodes of the first F frames, checked against the oracle below
     for i in range(args.warmup):
-        _, segs0 = run_step()
-        if i == 0:   # (streams are packed at the call's own opcode count, see iiv_encode)
-            first_ops = ops_buf.view(-1)[: 6 * sum(s[3] for s in segs0)].clone().view(-1, 6)
-    batch.enc.check()
-    batch.enc.profile(True)
+        segs0 = be.step()
+        if i == 0:
+            first_ops = be.first_ops(segs0)
+    be.check()
+    be.profile(True)
     barrier()
-    torch.cuda.synchronize()
+    be.synchronize()
     t0 = time.perf_counter()
     op_count, seg_count = 0, 0
     for i in range(args.steps):
-        _, segs = run_step()
+        segs = be.step()
         if first_ops is None and i == 0:   # (only when there is no warm-up step; async D2D copy)
-            first_ops = ops_buf.view(-1)[: 6 * sum(s[3] for s in segs)].clone().view(-1, 6)
+            first_ops = be.first_ops(segs)
         op_count += sum(s[3] for s in segs)
         seg_count += len(segs)
-    torch.cuda.synchronize()
+    be.synchronize()
     barrier()
     t1 = time.perf_counter()
-    batch.enc.check()
+    be.check()
     elapsed = t1 - t0
-    prof = batch.enc.profile_read()
-    batch.enc.profile(False)
+    prof = be.profile_read()
+    be.profile(False)
 
-    elapsed = max_over_ranks(elapsed, torch.device("cuda"), world)
+    elapsed = max_over_ranks(elapsed, be.device, world)
 
     frames_done = args.steps * F * S * n_gpus
     fps = frames_done / elapsed
@@ -196,10 +260,12 @@ def main():
         "dtype": "u16",
         "data": "synthetic",
         "config": {
-            "workload": "%s NTSC %dx192 S-%s synthetic clips, %d frames each, %d independent clips per GPU, "
+            "workload": "%s %s palette %dx192 S-%s synthetic clips, %d frames each, %d independent clips per GPU, "
                         "Movie.encode control flow (490 opcodes/frame%s)" % (
-                            args.mode, 560 if dhgr else 280, "img" if args.img else "coh" if args.coherent else "iid",
+                            args.mode, "//gs RGB (IIGS)" if args.palette == "IIGS" else "NTSC", 560 if dhgr else 280,
+                            "img" if args.img else "coh" if args.coherent else "iid",
                             args.steps * F, S, ", bank flip per 2 KiB" if dhgr else ""),
+            "palette": args.palette,
             "streams_per_gpu": S,
             "frames_per_step": F,
             "opcodes_per_frame": OPS_PER_FRAME,
@@ -216,26 +282,21 @@ def main():
         p_ms, p_n = prof["prologue_ms"], max(prof["prologue_launches"], 1)
         greedy_bytes = float(op_count) * S * BYTES_PER_OPCODE       # all launches of the timed region
         achieved = greedy_bytes / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
+        traffic, traffic_source = _pmc_traffic()
         out["roofline"] = {
-            "kernel": "greedy_wave_kernel" if (args.greedy == "wave" or (args.greedy == "auto" and S >= 1536)) else "greedy_kernel",
+            "kernel": "greedy_wave_kernel" if be.uses_wave_kernel() else "greedy_kernel",
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "peak_measured_read": HBM_MEASURED_READ_GBS,
-            "traffic": _pmc_traffic(),
+            "traffic": traffic,
+            "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": greedy_bytes / g_n,
             "avg_launch_ms": g_ms / g_n,
             "launches": prof["greedy_launches"],
-            # what actually bounds this kernel: 256 random store-table lookups per opcode through the
-            # CU's L1 (TCP).  Ceiling = tools/gather_bench.hip on this GPU model, L2-resident table,
-            # fully divergent wave64 loads (profiles/*gather_bench.txt): distinct lines per second.
-            "gather": {
-                "lookups_per_s": float(op_count) * S * 256 / (g_ms * 1e-3) if g_ms > 0 else 0.0,
-                "ceiling_divergent_lines_per_s": GATHER_CEILING_LINES_PER_S,
-                "note": "lookups that share a 128 B line inside one load instruction count once against the ceiling",
-            },
+            "lookups_per_s": float(op_count) * S * 256 / (g_ms * 1e-3) if g_ms > 0 else 0.0,
         }
         pro_bytes = float(seg_count) * S * BYTES_PER_PROLOGUE
         out["roofline_prologue"] = {
@@ -249,34 +310,61 @@ def main():
         }
         out["kernel_time_share"] = {"greedy": g_ms / (1000 * elapsed), "prologue": p_ms / (1000 * elapsed)}
 
-        if args.single_stream:
-            out["single_stream"] = _single_stream(native, stream_batch, mode, table, store, dm, dhgr, args)
-
-        if not args.no_cpu_baseline and n_gpus == 1:
-            out["cpu_baseline"] = _cpu_baseline(mode, dhgr, fm, fa, seeds[0], args,
-                                                ops_check=(first_ops.cpu().numpy(), F))
-            out["cpu_baseline_all_cores"] = _cpu_baseline_all_cores(mode, dhgr, fm, fa, seeds, args)
+        if n_gpus == 1 and not args.no_extras and be.is_gpu:
+            out["single_stream"] = _single_stream(be, args)
+            if args.emit:
+                out["emit"] = _emit_end_to_end(be, args, fps)
+            out["make_data_tables_s"] = _make_data_tables_seconds()
+        if not args.no_cpu_baseline and n_gpus == 1 and be.is_gpu:
+            out["cpu_baseline"] = _cpu_baseline(be, seeds[0], args, ops_check=(first_ops.cpu().numpy(), F))
+            out["cpu_baseline_all_cores"] = _cpu_baseline_all_cores(be, seeds, args)
+            out["vs_reference_python"] = _vs_reference(args.mode, fps, out["cpu_baseline"]["value"])
 
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    return out
 
 
 def _pmc_traffic():
-    """HBM bytes per greedy_kernel launch from the committed rocprofv3 PMC summary
-    (profiles/pmc_latest.json), or None when no counter run has been recorded."""
+    """HBM bytes per greedy kernel launch from the committed rocprofv3 PMC summary
+    (profiles/pmc_latest.json) and where that number comes from -- it is NOT measured in this run."""
     p = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         with open(p) as f:
-            return json.load(f).get("greedy_kernel_hbm_bytes_per_launch")
+            d = json.load(f)
+        return d.get("greedy_kernel_hbm_bytes_per_launch"), \
+            "profiles/pmc_latest.json (%s, bench args %s): a committed counter run, not this run" % (
+                d.get("kernel", "?"), " ".join(d.get("bench_args", [])))
+    except Exception:
+        return None, None
+
+
+def _vs_reference(mode, gpu_fps, port_fps_here):
+    """Speed-up over the reference's own Python: the reference cannot run on the GPU box, so
+    (GPU / port on this box) x (port / reference, both measured in the build container by
+    tools/measure_reference_ratio.py and committed as profiles/reference_ratio.json)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "reference_ratio.json")) as f:
+            d = json.load(f)
+        r = d[mode]
     except Exception:
         return None
+    return {
+        "value": gpu_fps / port_fps_here * r["port_over_reference"],
+        "gpu_over_port_on_this_box": gpu_fps / port_fps_here,
+        "port_over_reference_python": r["port_over_reference"],
+        "reference_python_frames_per_s_in_build_container": r["reference_python_frames_per_s"],
+        "provenance": "profiles/reference_ratio.json: tools/measure_reference_ratio.py, %s, %s, measured %s" % (
+            d.get("model", "?"), d.get("workload", "?"), d.get("measured", "?")),
+    }
 
 
-def _single_stream(native, stream_batch, mode, table, store, dm, dhgr, args):
+def _single_stream(be, args):
+    """One clip alone (a video is a sequential chain: latency-bound)."""
     import torch
-    fm, fa = stream_batch.synth_frames_torch(1, 60, dhgr, seed=99, coherent=args.coherent)
-    b = stream_batch.StreamBatch(mode, table, store, 1, seeds=[(1, 1)], dm=dm)
+    fm, fa = be.sb.synth_frames_torch(1, 60, be.dhgr, seed=99, coherent=args.coherent)
+    b = be.sb.StreamBatch(be.mode, be.table, be.store, 1, seeds=[(1, 1)], dm=be.dm)
     b.enc.set_greedy_kernel(None if args.greedy == "auto" else args.greedy == "wave")
     b.encode_frames(fm, fa, 10)
     torch.cuda.synchronize()
@@ -288,22 +376,108 @@ def _single_stream(native, stream_batch, mode, table, store, dm, dhgr, args):
     return {"value": 50 / dt, "unit": "frames/s", "us_per_opcode": 1e6 * dt / (50 * OPS_PER_FRAME)}
 
 
-def _cpu_baseline(mode, dhgr, fm, fa, seed, args, ops_check):
+def _make_data_tables_seconds():
+    """BASELINE metric M2: make_data_tables.main() -- both palettes, HGR + DHGR, four .npz files in the
+    reference's own format (lower triangle, key edit_distance) -- in a scratch directory."""
+    import shutil
+    import tempfile
+    import make_data_tables
+    cwd = os.getcwd()
+    d = tempfile.mkdtemp(prefix="iiv_tables_")
+    try:
+        os.chdir(d)
+        import contextlib
+        import io
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()):
+            make_data_tables.main()
+        dt = time.perf_counter() - t0
+        files = sorted(os.listdir(os.path.join(d, make_data_tables.DATA_DIR)))
+        assert len(files) == 4, files
+        return {"value": dt, "unit": "s", "files": files,
+                "bytes": sum(os.path.getsize(os.path.join(d, make_data_tables.DATA_DIR, f)) for f in files),
+                "reference": "README.md:67 'about 90 minutes on my machine'"}
+    except Exception as e:   # (e.g. a scratch disk too small for 3 GiB: report, do not fail the line)
+        return {"value": None, "error": repr(e)}
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def _emit_end_to_end(be, args, resident_fps):
+    """The same workload with the output leaving the device: encode (iiv_encode) -> .a2m bytes
+    (iiv_emit_chunk, header / ACK framing, silence as the audio) -> pinned host memory, the copy of
+    step k overlapping the encode of step k + 1.  A fresh batch over the same clips."""
+    import numpy as np
+    import torch
+    native = be.native
+    S, F = be.S, args.frames_per_step
+    rng = np.random.default_rng(0)
+    tick_addr = torch.from_numpy(rng.integers(0x4000, 0x7fff, 1024).astype(np.int16)).cuda()   # (addresses are data)
+    b = be.sb.StreamBatch(be.mode, be.table, be.store, S, seeds=rank_seeds(0, S), dm=be.dm)
+    n_ops = F * OPS_PER_FRAME
+    ops = torch.empty((S, n_ops, 6), dtype=torch.uint8, device="cuda")
+    width = native.emit_chunk_range(be.mode, 0, n_ops)[1] + 16
+    dev = [torch.empty((S, width), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    host = [torch.empty((S, width), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+    copy_stream = torch.cuda.Stream()
+    done = [torch.cuda.Event(), torch.cuda.Event()]
+    ready = [torch.cuda.Event(), torch.cuda.Event()]
+    state = {"first_op": 0, "bytes": 0}
+
+    def step(k):
+        _, segs = b.encode_frames(be.fm, be.fa, F, ops)
+        n = sum(s[3] for s in segs)
+        j = k & 1
+        torch.cuda.current_stream().wait_event(done[j])          # the copy that last read dev[j] has finished
+        view = ops.view(-1)[: S * n * 6].view(S, n, 6)            # (streams are packed at the call's own opcode count)
+        _, nb = native.emit_chunk(be.mode, view, state["first_op"], tick_addr, 0xBA72, dev[j])
+        ready[j].record()
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(ready[j])
+            host[j][:, :nb].copy_(dev[j][:, :nb], non_blocking=True)
+            done[j].record()
+        state["first_op"] += n
+        state["bytes"] += nb * S
+
+    for ev in done:
+        ev.record()
+    for k in range(args.warmup):
+        step(k)
+    torch.cuda.synchronize()
+    state["bytes"] = 0
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    b.enc.check()
+    b.close()
+    fps = args.steps * F * S / dt
+    return {"value": fps, "unit": "frames/s", "vs_resident_only": fps / resident_fps,
+            "bytes_to_host": state["bytes"], "d2h_gb_per_s": state["bytes"] / dt / 1e9,
+            "what": "iiv_encode -> iiv_emit_chunk (.a2m framing, tick 34) -> hipMemcpyAsync to pinned host memory, "
+                    "double-buffered; %d steps" % args.steps}
+
+
+def _cpu_baseline(be, seed, args, ops_check):
     """Oracle (single-thread C port of video.py/screen.py) on stream 0's first frames."""
     import numpy as np
     import oracle as O
     import stream_batch
+    fm, fa = be.fm, be.fa
     n = min(args.cpu_frames, fm.shape[1])
     main = fm[0, :n].cpu().numpy()
     aux = fa[0, :n].cpu().numpy() if fa is not None else None
-    _, dm = O.cie2000_matrix(O.PALETTE_RGB[5])
-    tab = O.build_table(mode, dm, symmetric=True)   # untimed, like the GPU's table build
-    v = O.Video(mode, tab, seed_py=seed[0], seed_np=seed[1])
-    segs = stream_batch.MovieClock(dhgr).segments(n)
+    _, dm = O.cie2000_matrix(O.PALETTE_RGB[PALETTE_IDS[args.palette]])
+    tab = O.build_table(be.mode, dm, symmetric=True)   # untimed, like the GPU's table build
+    v = O.Video(be.mode, tab, seed_py=seed[0], seed_np=seed[1])
+    segs = stream_batch.MovieClock(be.dhgr).segments(n)
     t0 = time.perf_counter()
     got = []
-    for (fr, ia, _, k) in segs:
-        v.encode_frame(main[fr], aux[fr] if aux is not None else None, ia)
+    for (fr, ia, restart, k) in segs:
+        if restart:
+            v.encode_frame(main[fr], aux[fr] if aux is not None else None, ia)
         got.append(v.next(k))
     dt = time.perf_counter() - t0
     parity = None
@@ -326,25 +500,26 @@ def _cpu_baseline(mode, dhgr, fm, fa, seed, args, ops_check):
     }
 
 
-def _cpu_baseline_all_cores(mode, dhgr, fm, fa, seeds, args):
+def _cpu_baseline_all_cores(be, seeds, args):
     """One independent stream per host thread (the oracle's C calls release the GIL)."""
     import concurrent.futures
-    import numpy as np
     import oracle as O
     import stream_batch
+    fm, fa = be.fm, be.fa
     threads = min(os.cpu_count() or 1, fm.shape[0])
     n = min(args.cpu_frames_all, fm.shape[1])
     main = fm[:threads, :n].cpu().numpy()
     aux = fa[:threads, :n].cpu().numpy() if fa is not None else None
-    _, dm = O.cie2000_matrix(O.PALETTE_RGB[5])
-    tab = O.build_table(mode, dm, symmetric=True)
-    segs = stream_batch.MovieClock(dhgr).segments(n)
-    vids = [O.Video(mode, tab, seed_py=seeds[i][0], seed_np=seeds[i][1]) for i in range(threads)]
+    _, dm = O.cie2000_matrix(O.PALETTE_RGB[PALETTE_IDS[args.palette]])
+    tab = O.build_table(be.mode, dm, symmetric=True)
+    segs = stream_batch.MovieClock(be.dhgr).segments(n)
+    vids = [O.Video(be.mode, tab, seed_py=seeds[i][0], seed_np=seeds[i][1]) for i in range(threads)]
 
     def work(i):
         v = vids[i]
-        for (fr, ia, _, k) in segs:
-            v.encode_frame(main[i, fr], aux[i, fr] if aux is not None else None, ia)
+        for (fr, ia, restart, k) in segs:
+            if restart:
+                v.encode_frame(main[i, fr], aux[i, fr] if aux is not None else None, ia)
             v.next(k)
 
     t0 = time.perf_counter()

@@ -41,21 +41,34 @@ static size_t stream_size(long n_emit)
     return pos + (2048 - pos % 2048);      // done() pads to the next 2 KiB boundary (a full frame if already on it)
 }
 
-__global__ __launch_bounds__(256) void emit_kernel(int mode, int n_streams, long n_ops, long n_emit,
-                                                   const uint8_t *__restrict__ ops,
-                                                   const uint8_t *__restrict__ ticks,
+// Opcodes [first_op, first_op + n_ops) of every stream -> their bytes, written at
+// out + s * out_stride + (stream position - out_base).  ops / ticks point at opcode first_op of
+// stream 0.  ticks == nullptr: every opcode carries const_tick.  header / finish: also write
+// the 7-byte header (first_op must be 0) / Terminate + zero padding up to `total`.
+// A tick that is not an even number in 4..66 or a page outside 32..63 cannot be an opcode of
+// the player (opcodes.py:11-26): the lookup index is clamped and *err is set.
+__global__ __launch_bounds__(256) void emit_kernel(int mode, long first_op, long n_ops, const uint8_t *__restrict__ ops,
+                                                   size_t ops_stride, const uint8_t *__restrict__ ticks,
+                                                   size_t ticks_stride, uint32_t const_tick,
                                                    const uint16_t *__restrict__ tick_addr, uint32_t ack_addr,
                                                    uint32_t term_addr, uint8_t *__restrict__ out, size_t out_stride,
-                                                   size_t total)
+                                                   size_t out_base, int header, int finish, size_t total,
+                                                   int *__restrict__ err)
 {
     const int s = blockIdx.y;
-    uint8_t *o = out + (size_t)s * out_stride;
+    uint8_t *o = out + (size_t)s * out_stride - out_base;
     const long k = (long)blockIdx.x * 256 + threadIdx.x;
-    if (k < n_emit) {
-        const uint8_t *q = ops + ((size_t)s * n_ops + k) * 6;
-        const uint32_t tick = ticks[(size_t)s * n_ops + k];
-        const uint32_t a = tick_addr[((tick - 4) >> 1) * 32 + (q[0] - 32)];
-        size_t p = tick_offset(k);
+    if (k < n_ops) {
+        const uint8_t *q = ops + (size_t)s * ops_stride + (size_t)k * 6;
+        const uint32_t tick = ticks ? ticks[(size_t)s * ticks_stride + k] : const_tick;
+        uint32_t ti = (tick - 4) >> 1, pi = (uint32_t)q[0] - 32u;
+        if (tick < 4 || tick > 66 || (tick & 1) || pi > 31u) {
+            if (err) *err = 1;
+            ti = ti > 31u ? 0u : ti;
+            pi = pi > 31u ? 0u : pi;
+        }
+        const uint32_t a = tick_addr[ti * 32 + pi];
+        size_t p = tick_offset(first_op + k);
         o[p + 0] = (uint8_t)(a >> 8);  // emit_command (opcodes.py:49-53)
         o[p + 1] = (uint8_t)a;
         o[p + 2] = q[1];               // content, then the 4 offsets (opcodes.py:136-138)
@@ -65,7 +78,7 @@ __global__ __launch_bounds__(256) void emit_kernel(int mode, int n_streams, long
         o[p + 6] = q[5];
         if ((p + 7) % 2048 >= 2044) {
             // ACK: DHGR flips the bank first (movie.py:143-147); ack i carries the bank after i+1 flips
-            const long i = (k - 290) / 292;
+            const long i = (first_op + k - 290) / 292;
             const bool aux = mode == kDHGR && ((i + 1) & 1);
             o[p + 7] = (uint8_t)(ack_addr >> 8);
             o[p + 8] = (uint8_t)ack_addr;
@@ -73,16 +86,19 @@ __global__ __launch_bounds__(256) void emit_kernel(int mode, int n_streams, long
             o[p + 10] = 0xff;
         }
     }
-    if (k == 0) {
+    if (k == 0 && header) {
         for (int i = 0; i < 6; i++) o[i] = 0xff;  // Header (opcodes.py:77-90)
         o[6] = (uint8_t)mode;
-        size_t p = tick_offset(n_emit);
-        o[p] = (uint8_t)(term_addr >> 8);  // Terminate
-        o[p + 1] = (uint8_t)term_addr;
     }
-    // zero padding after Terminate (movie.py:159-161), spread over the grid
-    const size_t pad0 = tick_offset(n_emit) + 2;
-    for (size_t i = pad0 + (size_t)k; i < total; i += (size_t)gridDim.x * 256) o[i] = 0;
+    if (finish) {
+        const size_t pt = tick_offset(first_op + n_ops);
+        if (k == 0) {
+            o[pt] = (uint8_t)(term_addr >> 8);  // Terminate
+            o[pt + 1] = (uint8_t)term_addr;
+        }
+        // zero padding after Terminate (movie.py:159-161), spread over the grid
+        for (size_t i = pt + 2 + (size_t)k; i < total; i += (size_t)gridDim.x * 256) o[i] = 0;
+    }
 }
 
 int emit_stream(int mode, int n_streams, long n_ops, const uint8_t *d_ops, const uint8_t *d_ticks,
@@ -95,17 +111,47 @@ int emit_stream(int mode, int n_streams, long n_ops, const uint8_t *d_ops, const
     if (!d_out) return IIV_OK;  // size query
     if (out_stride < total) return set_error(IIV_ERR_INVALID, "iiv_emit_stream: out_stride %zu < %zu", out_stride, total);
     uint16_t *d_addr = nullptr;
-    IIV_HIP(hipMalloc(&d_addr, 1024 * sizeof(uint16_t)));
+    IIV_HIP(hipMalloc(&d_addr, 1024 * sizeof(uint16_t) + sizeof(int)));
+    int *d_err = reinterpret_cast<int *>(d_addr + 1024);
+    int h_err = 0;
     int rc = hip_check(hipMemcpyAsync(d_addr, tick_addr, 1024 * sizeof(uint16_t), hipMemcpyHostToDevice, st), "copy addr");
+    if (!rc) rc = hip_check(hipMemsetAsync(d_err, 0, sizeof(int), st), "clear flag");
     if (!rc) {
         dim3 grid((unsigned)((n_emit + 255) / 256 > 0 ? (n_emit + 255) / 256 : 1), (unsigned)n_streams);
-        hipLaunchKernelGGL(emit_kernel, grid, dim3(256), 0, st, mode, n_streams, n_ops, n_emit, d_ops, d_ticks, d_addr,
-                           (uint32_t)ack_addr, (uint32_t)term_addr, d_out, out_stride, total);
+        hipLaunchKernelGGL(emit_kernel, grid, dim3(256), 0, st, mode, 0L, n_emit, d_ops, (size_t)n_ops * 6, d_ticks,
+                           (size_t)n_ops, 0u, d_addr, (uint32_t)ack_addr, (uint32_t)term_addr, d_out, out_stride, (size_t)0, 1,
+                           1, total, d_err);
         rc = hip_check(hipGetLastError(), "emit_kernel launch");
     }
+    if (!rc) rc = hip_check(hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, st), "read flag");
     if (!rc) rc = hip_check(hipStreamSynchronize(st), "emit sync");  // tick_addr is caller memory; d_addr freed below
     (void)hipFree(d_addr);
+    if (!rc && h_err)
+        rc = set_error(IIV_ERR_INVALID, "iiv_emit_stream: a tick is not an even number in 4..66, or a page is outside 32..63");
     return rc;
+}
+
+// byte range of opcodes [first_op, first_op + n_ops) in a stream (the header belongs to opcode 0)
+void emit_chunk_range(long first_op, long n_ops, size_t *first_byte, size_t *n_bytes)
+{
+    const size_t b0 = first_op == 0 ? 0 : tick_offset(first_op), b1 = tick_offset(first_op + n_ops);
+    if (first_byte) *first_byte = b0;
+    if (n_bytes) *n_bytes = b1 - b0;
+}
+
+int emit_chunk(int mode, int n_streams, long first_op, long n_ops, const uint8_t *d_ops, size_t ops_stride,
+               const uint8_t *d_ticks, size_t ticks_stride, int const_tick, const uint16_t *d_tick_addr, uint16_t ack_addr,
+               uint8_t *d_out, size_t out_stride, int *d_err, hipStream_t st)
+{
+    size_t b0, nb;
+    emit_chunk_range(first_op, n_ops, &b0, &nb);
+    if (out_stride < nb) return set_error(IIV_ERR_INVALID, "iiv_emit_chunk: out_stride %zu < %zu", out_stride, nb);
+    if (n_ops == 0 && first_op != 0) return IIV_OK;
+    dim3 grid((unsigned)((n_ops + 255) / 256 > 0 ? (n_ops + 255) / 256 : 1), (unsigned)n_streams);
+    hipLaunchKernelGGL(emit_kernel, grid, dim3(256), 0, st, mode, first_op, n_ops, d_ops, ops_stride, d_ticks, ticks_stride,
+                       (uint32_t)const_tick, d_tick_addr, (uint32_t)ack_addr, 0u, d_out, out_stride, b0, first_op == 0 ? 1 : 0,
+                       0, (size_t)0, d_err);
+    return hip_check(hipGetLastError(), "emit_kernel launch");
 }
 
 }  // namespace iiv
@@ -119,4 +165,19 @@ extern "C" int iiv_emit_stream(int mode, int n_streams, long n_ops, const uint8_
         return iiv::set_error(IIV_ERR_INVALID, "iiv_emit_stream: bad argument");
     return iiv::emit_stream(mode, n_streams, n_ops, d_ops, d_ticks, tick_addr, ack_addr, terminate_addr, max_bytes_out,
                             d_out, out_stride, out_len, (hipStream_t)stream);
+}
+
+extern "C" int iiv_emit_chunk(int mode, int n_streams, long first_op, long n_ops, const uint8_t *d_ops, size_t ops_stride,
+                              const uint8_t *d_ticks, size_t ticks_stride, int const_tick, const uint16_t *d_tick_addr,
+                              uint16_t ack_addr, uint8_t *d_out, size_t out_stride, size_t *first_byte, size_t *n_bytes,
+                              int *d_err, void *stream)
+{
+    if ((mode != IIV_HGR && mode != IIV_DHGR) || n_streams <= 0 || n_ops < 0 || first_op < 0)
+        return iiv::set_error(IIV_ERR_INVALID, "iiv_emit_chunk: bad argument");
+    iiv::emit_chunk_range(first_op, n_ops, first_byte, n_bytes);
+    if (!d_out) return IIV_OK;  // size query
+    if (!d_ops || !d_tick_addr || (!d_ticks && (const_tick < 4 || const_tick > 66 || (const_tick & 1))))
+        return iiv::set_error(IIV_ERR_INVALID, "iiv_emit_chunk: bad argument");
+    return iiv::emit_chunk(mode, n_streams, first_op, n_ops, d_ops, ops_stride, d_ticks, ticks_stride, const_tick,
+                           d_tick_addr, ack_addr, d_out, out_stride, d_err, (hipStream_t)stream);
 }

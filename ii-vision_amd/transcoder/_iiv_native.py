@@ -38,7 +38,7 @@ SYMBOLS = [
     "iiv_encoder_set_state_range", "iiv_encode", "iiv_encode_streams",
     "iiv_encoder_check", "iiv_encoder_profile", "iiv_encoder_profile_read",
     "iiv_build_split_store_table", "iiv_split_table_entries",
-    "iiv_emit_stream",
+    "iiv_emit_stream", "iiv_emit_chunk",
 ]
 
 
@@ -109,6 +109,8 @@ def lib():
     L.iiv_encoder_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.iiv_emit_stream.argtypes = [i32, i32, C.c_long, vp, vp, vp, C.c_uint16, C.c_uint16, C.c_long, vp, sz,
                                   C.POINTER(sz), vp]
+    L.iiv_emit_chunk.argtypes = [i32, i32, C.c_long, C.c_long, vp, sz, vp, sz, i32, vp, C.c_uint16, vp, sz,
+                                 C.POINTER(sz), C.POINTER(sz), vp, vp]
     for name in SYMBOLS:
         getattr(L, name)  # AttributeError if the library lacks a declared symbol
     _lib = L
@@ -403,3 +405,25 @@ def emit_stream(mode, ops, ticks, tick_addr, ack_addr, terminate_addr, max_bytes
                                 int(terminate_addr), int(max_bytes_out or 0), dptr(out), length, C.byref(got),
                                 stream_ptr()))
     return out
+
+
+def emit_chunk_range(mode, first_op, n_ops):
+    """(first byte, byte count) of opcodes [first_op, first_op + n_ops) in a stream."""
+    b0, nb = C.c_size_t(0), C.c_size_t(0)
+    check(lib().iiv_emit_chunk(mode, 1, int(first_op), int(n_ops), None, 0, None, 0, 34, None, 0, None, 0,
+                               C.byref(b0), C.byref(nb), None, None))
+    return int(b0.value), int(nb.value)
+
+
+def emit_chunk(mode, ops, first_op, d_tick_addr, ack_addr, out, ticks=None, const_tick=34, d_err=None):
+    """Asynchronous slice emission.  ops: CUDA uint8 (S, n, 6) view (row stride arbitrary) holding opcodes
+    first_op .. first_op + n - 1 of every stream; out: CUDA uint8 (S, >= byte count) -> (first byte, byte count)."""
+    _torch()
+    S, n = int(ops.shape[0]), int(ops.shape[1])
+    assert ops.stride(2) == 1 and ops.stride(1) == 6 and out.stride(1) == 1
+    b0, nb = C.c_size_t(0), C.c_size_t(0)
+    check(lib().iiv_emit_chunk(mode, S, int(first_op), n, dptr(ops), int(ops.stride(0)), dptr(ticks),
+                               int(ticks.stride(0)) if ticks is not None else 0, int(const_tick), dptr(d_tick_addr),
+                               int(ack_addr), dptr(out), int(out.stride(0)), C.byref(b0), C.byref(nb), dptr(d_err),
+                               stream_ptr()))
+    return int(b0.value), int(nb.value)

@@ -236,10 +236,27 @@ int iiv_encoder_profile_read(iiv_encoder *enc, double ms[2], int64_t launches[2]
  *   symbol table (player/iivision.dbg; opcodes.py:168-217) -- host memory.
  * max_bytes_out: Movie.max_bytes_out, 0 = unlimited.
  * *out_len receives the stream length (same for every stream); with d_out == NULL
- * nothing is written (size query).  Synchronises. */
+ * nothing is written (size query).  Synchronises.  IIV_ERR_INVALID if a tick is not an even
+ * number in 4..66 or an opcode's page byte is outside 32..63 (no such player opcode exists). */
 int iiv_emit_stream(int mode, int n_streams, long n_ops, const uint8_t *d_ops, const uint8_t *d_ticks,
                     const uint16_t tick_addr[1024], uint16_t ack_addr, uint16_t terminate_addr,
                     long max_bytes_out, uint8_t *d_out, size_t out_stride, size_t *out_len, void *stream);
+
+/* The same bytes for a slice of the opcode stream, asynchronously (no host round trip, no
+ * synchronisation): opcodes [first_op, first_op + n_ops) of every stream, so that a movie can
+ * be emitted while it is being encoded (iiv_encode -> iiv_emit_chunk -> copy to the host).
+ * d_ops points at opcode first_op of stream 0, streams ops_stride BYTES apart (d_ticks /
+ * ticks_stride likewise, in bytes; d_ticks == NULL: every opcode carries const_tick).
+ * d_tick_addr: the 1024 tick opcode addresses in DEVICE memory.  The slice's bytes are the
+ * stream positions [*first_byte, *first_byte + *n_bytes) -- the 7-byte header belongs to
+ * opcode 0, an ACK to the opcode in front of it -- written at d_out + s * out_stride.
+ * Terminate + padding are not written (iiv_emit_stream, or the caller after the last slice).
+ * d_out == NULL: only the byte range is computed.  d_err (device int, may be NULL) is set to
+ * 1 if a tick is not an even number in 4..66 or a page is outside 32..63. */
+int iiv_emit_chunk(int mode, int n_streams, long first_op, long n_ops, const uint8_t *d_ops, size_t ops_stride,
+                   const uint8_t *d_ticks, size_t ticks_stride, int const_tick, const uint16_t *d_tick_addr,
+                   uint16_t ack_addr, uint8_t *d_out, size_t out_stride, size_t *first_byte, size_t *n_bytes,
+                   int *d_err, void *stream);
 
 #ifdef __cplusplus
 }
