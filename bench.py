@@ -177,7 +177,7 @@ class GpuBackend:
         return self.batch.enc.profile_read()
 
     def uses_wave_kernel(self):
-        return self.args.greedy == "wave" or (self.args.greedy == "auto" and self.S >= 1536)
+        return self.args.greedy != "workgroup"
 
 
 def main(argv=None, backend_cls=GpuBackend):
@@ -418,8 +418,8 @@ def _emit_end_to_end(be, args, resident_fps):
     n_ops = F * OPS_PER_FRAME
     ops = torch.empty((S, n_ops, 6), dtype=torch.uint8, device="cuda")
     width = native.emit_chunk_range(be.mode, 0, n_ops)[1] + 16
-    dev = [torch.empty((S, width), dtype=torch.uint8, device="cuda") for _ in range(2)]
-    host = [torch.empty((S, width), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+    dev = [torch.empty(S * width, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    host = [torch.empty(S * width, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
     copy_stream = torch.cuda.Stream()
     done = [torch.cuda.Event(), torch.cuda.Event()]
     ready = [torch.cuda.Event(), torch.cuda.Event()]
@@ -431,11 +431,13 @@ def _emit_end_to_end(be, args, resident_fps):
         j = k & 1
         torch.cuda.current_stream().wait_event(done[j])          # the copy that last read dev[j] has finished
         view = ops.view(-1)[: S * n * 6].view(S, n, 6)            # (streams are packed at the call's own opcode count)
-        _, nb = native.emit_chunk(be.mode, view, state["first_op"], tick_addr, 0xBA72, dev[j])
+        nb = native.emit_chunk_range(be.mode, state["first_op"], n)[1]
+        out = dev[j][: S * nb].view(S, nb)                        # rows exactly as long as the slice: one contiguous copy
+        native.emit_chunk(be.mode, view, state["first_op"], tick_addr, 0xBA72, out)
         ready[j].record()
         with torch.cuda.stream(copy_stream):
             copy_stream.wait_event(ready[j])
-            host[j][:, :nb].copy_(dev[j][:, :nb], non_blocking=True)
+            host[j][: S * nb].copy_(dev[j][: S * nb], non_blocking=True)
             done[j].record()
         state["first_op"] += n
         state["bytes"] += nb * S

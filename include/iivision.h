@@ -136,9 +136,9 @@ void iiv_encoder_destroy(iiv_encoder *enc);
 #define IIV_DW_TABLE 0         /*   gather from the precomputed table           */
 #define IIV_DW_RECURRENCE 1    /*   run the edit-distance recurrence            */
 #define IIV_OPT_GREEDY_KERNEL 2 /* shape of the greedy-selection kernel         */
-#define IIV_GREEDY_WAVE 0       /*   one 64-lane wave per stream (throughput)    */
-#define IIV_GREEDY_WORKGROUP 1  /*   one 256-thread workgroup per stream (latency) */
-#define IIV_GREEDY_AUTO 2       /*   default: WAVE when n_streams >= 1536 (and dm was given) */
+#define IIV_GREEDY_WAVE 0       /*   one 64-lane wave per stream, split store table */
+#define IIV_GREEDY_WORKGROUP 1  /*   one 256-thread workgroup per stream, dense store table */
+#define IIV_GREEDY_AUTO 2       /*   default: WAVE whenever dm was given at creation */
 #define IIV_OPT_PREFIX_SORT 3    /* 1 (default): when a generator's opcode budget B is known
                                  * (another restart follows in the same iiv_encode call) and
                                  * 3B <= 2048, only that many highest priorities are ordered;
