@@ -74,6 +74,13 @@ int iiv_cie2000_matrix(const uint8_t rgb[48], double out_f[256], int32_t out_i[2
     return iiv::cie2000_matrix(rgb, out_f, out_i, (hipStream_t)stream);
 }
 
+int iiv_delta_e_cie2000(int n, const double *lab1, const double *lab2, double *out, void *stream)
+{
+    if (n < 0 || !lab1 || !lab2 || !out) return iiv::set_error(IIV_ERR_INVALID, "iiv_delta_e_cie2000: bad argument");
+    if (n == 0) return IIV_OK;
+    return iiv::delta_e_pairs(n, lab1, lab2, out, (hipStream_t)stream);
+}
+
 int iiv_pixel_strings(int mode, uint32_t *d_dots, uint8_t *d_pixels, void *stream)
 {
     int rc = iiv::check_mode(mode);

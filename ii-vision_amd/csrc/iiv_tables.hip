@@ -96,6 +96,17 @@ __global__ void cie2000_kernel(const uint8_t *rgb, double *out_f, int32_t *out_i
     out_i[t] = (int32_t)d;  // int(): truncation (make_data_tables.py:68)
 }
 
+// the same delta-E on caller-supplied Lab pairs (published CIEDE2000 test data, tests)
+__global__ void delta_e_kernel(int n, const double *__restrict__ lab1, const double *__restrict__ lab2,
+                               double *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double a[3] = {lab1[3 * i], lab1[3 * i + 1], lab1[3 * i + 2]};
+    const double b[3] = {lab2[3 * i], lab2[3 * i + 1], lab2[3 * i + 2]};
+    out[i] = delta_e_cie2000(a, b);
+}
+
 // ------------------------------------------------------------------ colour strings
 
 template <int MODE>
@@ -422,6 +433,22 @@ int build_split_store_table(int mode, const int32_t dm[256], uint32_t *d_left, u
     if (tmp_r) (void)hipFree(tmp_r);
     if (rc) return rc;
     return hip_check(he, "sync");
+}
+
+int delta_e_pairs(int n, const double *lab1, const double *lab2, double *out, hipStream_t st)
+{
+    double *d = nullptr;
+    IIV_HIP(hipMalloc(&d, (size_t)n * 7 * sizeof(double)));
+    int rc = hip_check(hipMemcpyAsync(d, lab1, (size_t)n * 24, hipMemcpyHostToDevice, st), "copy lab1");
+    if (!rc) rc = hip_check(hipMemcpyAsync(d + 3 * (size_t)n, lab2, (size_t)n * 24, hipMemcpyHostToDevice, st), "copy lab2");
+    if (!rc) {
+        hipLaunchKernelGGL(delta_e_kernel, dim3((n + 63) / 64), dim3(64), 0, st, n, d, d + 3 * (size_t)n, d + 6 * (size_t)n);
+        rc = hip_check(hipGetLastError(), "delta_e_kernel launch");
+    }
+    if (!rc) rc = hip_check(hipMemcpyAsync(out, d + 6 * (size_t)n, (size_t)n * 8, hipMemcpyDeviceToHost, st), "copy out");
+    if (!rc) rc = hip_check(hipStreamSynchronize(st), "sync");
+    (void)hipFree(d);
+    return rc;
 }
 
 int cie2000_matrix(const uint8_t rgb[48], double out_f[256], int32_t out_i[256], hipStream_t st)

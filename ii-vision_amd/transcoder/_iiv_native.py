@@ -31,14 +31,14 @@ SYMBOLS = [
     "iiv_version", "iiv_last_error", "iiv_device_count",
     "iiv_masked_bits", "iiv_masked_dots", "iiv_num_offsets", "iiv_table_entries",
     "iiv_store_table_entries",
-    "iiv_cie2000_matrix", "iiv_pixel_strings", "iiv_build_table", "iiv_build_store_table",
+    "iiv_cie2000_matrix", "iiv_delta_e_cie2000", "iiv_pixel_strings", "iiv_build_table", "iiv_build_store_table",
     "iiv_pack", "iiv_diff_weights", "iiv_compute_delta_pages",
     "iiv_encoder_create", "iiv_encoder_destroy", "iiv_encoder_set_option",
     "iiv_encoder_snapshot", "iiv_encoder_rollback", "iiv_encoder_get_state", "iiv_encoder_set_state",
     "iiv_encoder_set_state_range", "iiv_encode", "iiv_encode_streams",
     "iiv_encoder_check", "iiv_encoder_profile", "iiv_encoder_profile_read",
     "iiv_build_split_store_table", "iiv_split_table_entries",
-    "iiv_emit_stream", "iiv_emit_chunk",
+    "iiv_emit_stream", "iiv_emit_chunk", "iiv_frames_to_memory_maps",
 ]
 
 
@@ -84,6 +84,7 @@ def lib():
         getattr(L, f).restype = sz
         getattr(L, f).argtypes = [i32]
     L.iiv_cie2000_matrix.argtypes = [vp, vp, vp, vp]
+    L.iiv_delta_e_cie2000.argtypes = [i32, vp, vp, vp, vp]
     L.iiv_pixel_strings.argtypes = [i32, vp, vp, vp]
     L.iiv_build_table.argtypes = [i32, vp, vp, i32, vp]
     L.iiv_build_store_table.argtypes = [i32, vp, vp, vp]
@@ -111,6 +112,7 @@ def lib():
                                   C.POINTER(sz), vp]
     L.iiv_emit_chunk.argtypes = [i32, i32, C.c_long, C.c_long, vp, sz, vp, sz, i32, vp, C.c_uint16, vp, sz,
                                  C.POINTER(sz), C.POINTER(sz), vp, vp]
+    L.iiv_frames_to_memory_maps.argtypes = [i32, vp, i32, vp, i32, vp, vp, vp]
     for name in SYMBOLS:
         getattr(L, name)  # AttributeError if the library lacks a declared symbol
     _lib = L
@@ -157,6 +159,16 @@ def cie2000_matrix(rgb):
     i = np.zeros((16, 16), dtype=np.int32)
     check(lib().iiv_cie2000_matrix(hptr(rgb), hptr(f), hptr(i), stream_ptr()))
     return f, i
+
+
+def delta_e_cie2000(lab1, lab2):
+    """Delta-E 2000 of (n, 3) Lab pairs on the device (the table builder's own function)."""
+    _torch()
+    a = np.ascontiguousarray(lab1, dtype=np.float64).reshape(-1, 3)
+    b = np.ascontiguousarray(lab2, dtype=np.float64).reshape(-1, 3)
+    out = np.zeros(len(a), dtype=np.float64)
+    check(lib().iiv_delta_e_cie2000(len(a), hptr(a), hptr(b), hptr(out), stream_ptr()))
+    return out
 
 
 def pixel_strings(mode):
@@ -427,3 +439,17 @@ def emit_chunk(mode, ops, first_op, d_tick_addr, ack_addr, out, ticks=None, cons
                                int(ack_addr), dptr(out), int(out.stride(0)), C.byref(b0), C.byref(nb), dptr(d_err),
                                stream_ptr()))
     return int(b0.value), int(nb.value)
+
+
+# ---- f3: frame ingest ---------------------------------------------------------------
+
+def frames_to_memory_maps(mode, palette_rgb, rgb, dither=0):
+    """rgb: CUDA uint8 (n, 192, 280, 3) -> (main, aux) CUDA uint8 (n, 32, 256); aux is None for HGR."""
+    torch = _torch()
+    assert rgb.dtype == torch.uint8 and tuple(rgb.shape[1:]) == (192, 280, 3) and rgb.is_contiguous()
+    n = int(rgb.shape[0])
+    pal = np.ascontiguousarray(palette_rgb, dtype=np.uint8).reshape(48)
+    main = torch.empty((n, 32, 256), dtype=torch.uint8, device="cuda")
+    aux = torch.empty((n, 32, 256), dtype=torch.uint8, device="cuda") if mode == DHGR else None
+    check(lib().iiv_frames_to_memory_maps(mode, hptr(pal), n, dptr(rgb), int(dither), dptr(main), dptr(aux), stream_ptr()))
+    return main, aux

@@ -54,6 +54,12 @@ size_t iiv_store_table_entries(int mode); /* num_offsets * 2^content_bits * 2^MA
  * Delta-E 2000, out_i = int() of it; either may be NULL.  Synchronises. */
 int iiv_cie2000_matrix(const uint8_t rgb[48], double out_f[256], int32_t out_i[256], void *stream);
 
+/* The delta-E 2000 of iiv_cie2000_matrix on n caller-supplied CIE Lab pairs (host arrays,
+ * n x 3 doubles each; out: n doubles) -- colormath 3.0.0's delta_e_cie2000 with Kl = Kc = Kh = 1
+ * (make_data_tables.py:66-68).  Lets published CIEDE2000 test data be run through the very
+ * device function the tables are built with.  Synchronises. */
+int iiv_delta_e_cie2000(int n, const double *lab1, const double *lab2, double *out, void *stream);
+
 /* to_dots + dots_to_nominal_colour_pixel_values for every masked value
  * (screen.py:743-789, 983-990; colours.py:100-148).
  * d_dots:   [num_offsets][2^bits] u32      (may be NULL)
@@ -241,6 +247,33 @@ int iiv_encoder_profile_read(iiv_encoder *enc, double ms[2], int64_t launches[2]
 int iiv_emit_stream(int mode, int n_streams, long n_ops, const uint8_t *d_ops, const uint8_t *d_ticks,
                     const uint16_t tick_addr[1024], uint16_t ack_addr, uint16_t terminate_addr,
                     long max_bytes_out, uint8_t *d_out, size_t out_stride, size_t *out_len, void *stream);
+
+/* ==== f3: frame ingest =====================================================
+ * RGB frames -> memory maps, the step the reference delegates to the external bmp2dhr tool
+ * (frame_grabber.py:68-115; README.md:217-221 wishes for a "direct image encoding").  That
+ * tool is not part of the reference's source, so there is no reference output to match; the
+ * conversion is SPECIFIED here (integer arithmetic only, so every implementation agrees bit
+ * for bit -- the test suite's CPU restatement and the HIP kernel do):
+ *   - two source pixels (2k, 2k+1 of a 280-pixel row) are averaged, (a + b + 1) / 2 per
+ *     channel, into colour pixel k (140 per row); the ordered-dither offset
+ *     floor((2 * B[y & 3][k & 3] - 15) * dither / 16), B = the 4x4 Bayer matrix
+ *     {0,8,2,10; 12,4,14,6; 3,11,1,9; 15,7,13,5}, is added and the result clamped to 0..255;
+ *   - colour distance = 2 dr^2 + 4 dg^2 + 3 db^2, ties to the lower colour value;
+ *   - DHGR: the nearest of the 16 palette colours; its value IS the pattern of the pixel's
+ *     aligned dot quad (colours.py:100-134: a repeating quad P shows colour value P), dot X of
+ *     the row = bit X & 3 of quad X >> 2; dots are packed 7 per byte, aux / main alternating
+ *     (screen.py:822-826), bit 7 clear (video.py:137);
+ *   - HGR: per screen byte the palette bit (0: black 0, violet 3, green 12, white 15; 1: black,
+ *     blue 6, orange 9, white) whose summed nearest-colour error over the byte's seven dots is
+ *     smaller (ties to 0), then dot X = bit X & 1 of the 2-dot pattern of pixel X >> 1 under that
+ *     palette bit (pattern bit 0 = the even dot column, colours.py:18-44);
+ *   - bytes land at y_to_base_addr (screen.py:16-22); screen holes stay 0.
+ * d_rgb: [n_frames][192][280][3] u8 (frame_grabber.py:75,100 resizes every frame to 280x192);
+ * palette_rgb: 16 x 3 host bytes, row i = colour value i (palette.py:37-78); dither: amplitude
+ * 0..255, 0 = none; d_main / d_aux: [n_frames][32][256] u8 memory maps (d_aux ignored for
+ * HGR).  Synchronises. */
+int iiv_frames_to_memory_maps(int mode, const uint8_t palette_rgb[48], int n_frames, const uint8_t *d_rgb,
+                              int dither, uint8_t *d_main, uint8_t *d_aux, void *stream);
 
 /* The same bytes for a slice of the opcode stream, asynchronously (no host round trip, no
  * synchronisation): opcodes [first_op, first_op + n_ops) of every stream, so that a movie can

@@ -1156,3 +1156,89 @@ size_t orc_emit_stream(int mode, int n_ops, const uint8_t *ops, const uint8_t *t
     for (size_t i = 0; i < pad; i++) out[pos++] = 0;
     return pos;
 }
+
+
+/* ---- frame ingest (f3): see iiv_oracle.h -- this is the definition, not a restatement ---- */
+
+static const int kBayer4[4][4] = {{0, 8, 2, 10}, {12, 4, 14, 6}, {3, 11, 1, 9}, {15, 7, 13, 5}};
+
+/* colour pixel k of row y: mean of source pixels 2k, 2k+1, plus the ordered-dither offset */
+static void ingest_pixel(const uint8_t *rgb, int y, int k, int dither, int out[3])
+{
+    const uint8_t *p = rgb + ((size_t)y * 280 + 2 * k) * 3;
+    const int d = ((2 * kBayer4[y & 3][k & 3] - 15) * dither + 16 * 256) / 16 - 256;  /* floor((2b-15) * dither / 16) */
+    for (int c = 0; c < 3; c++) {
+        int v = ((int)p[c] + (int)p[3 + c] + 1) / 2 + d;
+        out[c] = v < 0 ? 0 : v > 255 ? 255 : v;
+    }
+}
+
+static int ingest_err(const uint8_t *pal, int colour, const int px[3])
+{
+    const int dr = px[0] - pal[3 * colour], dg = px[1] - pal[3 * colour + 1], db = px[2] - pal[3 * colour + 2];
+    return 2 * dr * dr + 4 * dg * dg + 3 * db * db;
+}
+
+/* HGR: the four colours a pixel can take under a palette bit, as (colour value, 2-dot pattern):
+ * pattern bit 0 = the even dot column, bit 1 = the odd one (colours.py:18-44) */
+static const int kHgrColour[2][4] = {{0, 3, 12, 15}, {0, 6, 9, 15}};  /* black, violet|blue, green|orange, white */
+static const int kHgrPattern[4] = {0, 1, 2, 3};
+
+void orc_frame_to_memory_map(int mode, const uint8_t palette_rgb[48], const uint8_t *rgb, int dither,
+                             uint8_t *main_mem, uint8_t *aux_mem)
+{
+    memset(main_mem, 0, 8192);
+    if (mode == ORC_DHGR) memset(aux_mem, 0, 8192);
+    for (int y = 0; y < 192; y++) {
+        const int base = orc_y_to_base_addr(y, 0) - 0x2000;
+        if (mode == ORC_DHGR) {
+            int quad[140];
+            for (int k = 0; k < 140; k++) {
+                int px[3], best = 0, be = 0x7fffffff;
+                ingest_pixel(rgb, y, k, dither, px);
+                for (int c = 0; c < 16; c++) {
+                    const int e = ingest_err(palette_rgb, c, px);
+                    if (e < be) { be = e; best = c; }
+                }
+                quad[k] = best;
+            }
+            for (int j = 0; j < 80; j++) {      /* bytes in dot order: aux, main, aux, main ... (screen.py:822-826) */
+                int v = 0;
+                for (int i = 0; i < 7; i++) {
+                    const int X = 7 * j + i;
+                    v |= ((quad[X >> 2] >> (X & 3)) & 1) << i;
+                }
+                ((j & 1) ? main_mem : aux_mem)[base + (j >> 1)] = (uint8_t)v;
+            }
+        } else {
+            int pat[2][140], err[2][140];
+            for (int k = 0; k < 140; k++) {
+                int px[3];
+                ingest_pixel(rgb, y, k, dither, px);
+                for (int pb = 0; pb < 2; pb++) {
+                    int best = 0, be = 0x7fffffff;
+                    for (int q = 0; q < 4; q++) {
+                        const int e = ingest_err(palette_rgb, kHgrColour[pb][q], px);
+                        if (e < be) { be = e; best = q; }
+                    }
+                    pat[pb][k] = kHgrPattern[best];
+                    err[pb][k] = be;
+                }
+            }
+            for (int b = 0; b < 40; b++) {
+                long e0 = 0, e1 = 0;
+                for (int i = 0; i < 7; i++) {
+                    e0 += err[0][(7 * b + i) >> 1];
+                    e1 += err[1][(7 * b + i) >> 1];
+                }
+                const int pb = e1 < e0 ? 1 : 0;
+                int v = pb << 7;
+                for (int i = 0; i < 7; i++) {
+                    const int X = 7 * b + i;
+                    v |= ((pat[pb][X >> 1] >> (X & 1)) & 1) << i;
+                }
+                main_mem[base + b] = (uint8_t)v;
+            }
+        }
+    }
+}

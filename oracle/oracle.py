@@ -208,6 +208,14 @@ def cie2000_matrix(rgb):
     return f, i
 
 
+def delta_e_cie2000(lab1, lab2):
+    L = lib()
+    L.orc_delta_e_cie2000.restype = C.c_double
+    a = np.ascontiguousarray(lab1, dtype=np.float64).reshape(-1, 3)
+    b = np.ascontiguousarray(lab2, dtype=np.float64).reshape(-1, 3)
+    return np.array([L.orc_delta_e_cie2000(_p(a[i], C.c_double), _p(b[i], C.c_double)) for i in range(len(a))])
+
+
 def substitute_costs(dm):
     dm = np.ascontiguousarray(dm, dtype=np.int32).reshape(256)
     out = np.zeros((16, 16), dtype=np.int32)
@@ -267,6 +275,17 @@ def emit_stream(mode, ops, ticks, tick_addr, ack_addr, terminate_addr, max_bytes
     ln = lib().orc_emit_stream(mode, n, _p(ops, C.c_uint8), _p(ticks, C.c_uint8), _p(ta, C.c_uint16),
                                int(ack_addr), int(terminate_addr), int(max_bytes_out or 0), _p(out, C.c_uint8))
     return out[:ln].copy()
+
+
+def frame_to_memory_map(mode, palette_rgb, rgb, dither=0):
+    """(main, aux) (32,256) u8 memory maps of one 280x192 RGB frame (oracle's DEFINITION of f3)."""
+    pal = np.ascontiguousarray(palette_rgb, dtype=np.uint8).reshape(48)
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8).reshape(192 * 280 * 3)
+    main = np.zeros((32, 256), dtype=np.uint8)
+    aux = np.zeros((32, 256), dtype=np.uint8)
+    lib().orc_frame_to_memory_map(mode, _p(pal, C.c_uint8), _p(rgb, C.c_uint8), int(dither),
+                                  _p(main, C.c_uint8), _p(aux, C.c_uint8))
+    return main, (aux if mode == DHGR else None)
 
 
 class MT(C.Structure):

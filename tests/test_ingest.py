@@ -1,0 +1,119 @@
+"""f3: RGB frame -> memory map.  The reference delegates this to the external
+bmp2dhr tool, so there is no reference output: include/iivision.h specifies the conversion and the oracle restates it
+(orc_frame_to_memory_map).  CPU: the specification is consistent with the colour model that IS pinned
+to the reference (solid colours survive the round trip through pack -> mask -> colour model).
+GPU: the HIP kernel equals the definition bit for bit; the host mirror yields memory maps."""
+
+import numpy as np
+import pytest
+
+
+def _test_frames(n, seed):
+    """gradients, colour bars and noise: (n, 192, 280, 3) u8"""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:192, 0:280]
+    out = np.zeros((n, 192, 280, 3), np.uint8)
+    for i in range(n):
+        kind = i % 4
+        if kind == 0:
+            out[i] = rng.integers(0, 256, (192, 280, 3))
+        elif kind == 1:
+            out[i, ..., 0] = (x * 255 // 279)
+            out[i, ..., 1] = (y * 255 // 191)
+            out[i, ..., 2] = ((x + y + 7 * i) % 256)
+        elif kind == 2:
+            bars = rng.integers(0, 256, (8, 3))
+            out[i] = bars[(x * 8 // 280)]
+        else:
+            out[i] = (rng.integers(0, 256, (24, 35, 3)).repeat(8, axis=0).repeat(8, axis=1))
+    return out
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_solid_colours_round_trip_through_the_colour_model(O, mode):
+    """A frame filled with a palette colour becomes dots whose windows the (reference-pinned) colour
+    model reads back as that colour: the dot patterns and phases of the conversion are right."""
+    pal = O.PALETTE_RGB[0]     # //gs: sixteen distinct colours
+    holes = O.screen_holes()
+    L = O.lib()
+    for c in (range(16) if mode == 1 else (0, 3, 12, 15, 6, 9)):
+        rgb = np.tile(pal[c], (192, 280, 1)).astype(np.uint8)
+        main, aux = O.frame_to_memory_map(mode, pal, rgb, 0)
+        assert (main[holes] == 0).all() and (aux is None or (aux[holes] == 0).all())
+        packed = O.pack(mode, main, aux)
+        for page in (0, 9, 31):
+            for col in (1, 7, 18):          # interior columns of the first 40-byte segment
+                for o in range(O.num_offsets(mode)):
+                    w = L.orc_mask_and_shift(mode, int(packed[page, col]), o)
+                    assert (O.pixel_values(mode, w, o) == c).all(), (mode, c, page, col, o)
+
+
+def test_ingest_definition_properties(O):
+    pal = O.PALETTE_RGB[5]
+    rgb = _test_frames(4, 1)
+    for mode in (0, 1):
+        for f in range(4):
+            main, aux = O.frame_to_memory_map(mode, pal, rgb[f], 0)
+            if mode == 1:
+                assert (main < 128).all() and (aux < 128).all()      # DHGR bytes carry no palette bit (video.py:137)
+            again, _ = O.frame_to_memory_map(mode, pal, rgb[f], 0)
+            assert (again == main).all()
+    # the dither changes flat mid-tone areas, not areas that sit on a palette colour
+    flat = np.full((192, 280, 3), 128, np.uint8)
+    a, _ = O.frame_to_memory_map(1, pal, flat, 0)
+    b, _ = O.frame_to_memory_map(1, pal, flat, 64)
+    assert (a != b).any()
+    white = np.full((192, 280, 3), 255, np.uint8)
+    a, _ = O.frame_to_memory_map(1, pal, white, 0)
+    b, _ = O.frame_to_memory_map(1, pal, white, 16)
+    assert (a == b).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("pal_id", [5, 0])
+def test_ingest_kernel_equals_definition(native, O, mode, pal_id):
+    import torch
+    rgb = _test_frames(9, 2 + mode)
+    for dither in (0, 32, 255):
+        main, aux = native.frames_to_memory_maps(mode, O.PALETTE_RGB[pal_id], torch.from_numpy(rgb).cuda(), dither)
+        main = main.cpu().numpy()
+        aux = aux.cpu().numpy() if aux is not None else None
+        for f in range(len(rgb)):
+            em, ea = O.frame_to_memory_map(mode, O.PALETTE_RGB[pal_id], rgb[f], dither)
+            assert (main[f] == em).all(), (mode, pal_id, dither, f)
+            if mode == 1:
+                assert (aux[f] == ea).all(), (mode, pal_id, dither, f)
+
+
+@pytest.mark.gpu
+def test_frame_grabber_feeds_the_encoder(native, O, oracle_tables, device_tables):
+    """frame_grabber.ArrayFrameGrabber -> memory maps -> StreamBatch: an RGB clip transcodes end to
+    end on the device, and the opcodes equal the oracle's on the oracle-converted frames."""
+    import frame_grabber
+    import palette
+    import stream_batch
+    import video_mode
+    rgb = _test_frames(6, 9)
+    fg = frame_grabber.ArrayFrameGrabber(rgb, video_mode.VideoMode.DHGR, palette.Palette.NTSC, dither=32)
+    assert fg.input_frame_rate == 30 and fg.video_mode == video_mode.VideoMode.DHGR
+    maps = list(fg.frames())
+    assert len(maps) == 6 and maps[0][0].page_offset.shape == (32, 256) and maps[0][1] is not None
+    main, aux = fg.memory_maps()
+    for f in range(6):
+        em, ea = O.frame_to_memory_map(1, O.PALETTE_RGB[5], rgb[f], 32)
+        assert (maps[f][0].page_offset == em).all() and (maps[f][1].page_offset == ea).all()
+    t, s = device_tables.get(1)
+    b = stream_batch.StreamBatch(1, t, s, 1, seeds=[(3, 3)], dm=device_tables.dm[(1, 5)])
+    ops, segs = b.encode_frames(main[None].contiguous(), aux[None].contiguous(), 6)
+    b.enc.check()
+    v = O.Video(1, oracle_tables.get(1), seed_py=3, seed_np=3)
+    exp = []
+    for (f, ia, restart, k) in segs:
+        if restart:
+            v.encode_frame(maps[f][0].page_offset, maps[f][1].page_offset, ia)
+        exp.append(v.next(k))
+    assert (ops.cpu().numpy()[0] == np.concatenate(exp)).all()
+    b.close()
+    with pytest.raises(ValueError):
+        frame_grabber.ArrayFrameGrabber(np.zeros((2, 192, 140, 3), np.uint8), video_mode.VideoMode.HGR)
