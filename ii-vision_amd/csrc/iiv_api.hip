@@ -106,6 +106,22 @@ int iiv_build_store_table(int mode, const int32_t dm[256], uint16_t *d_out, void
     return iiv::build_store_table(mode, dm, d_out, (hipStream_t)stream);
 }
 
+int iiv_symmetrise_table(int mode, uint16_t *d_table, void *stream)
+{
+    int rc = iiv::check_mode(mode);
+    if (rc) return rc;
+    if (!d_table) return iiv::set_error(IIV_ERR_INVALID, "d_table is NULL");
+    return iiv::symmetrise_table(mode, d_table, (hipStream_t)stream);
+}
+
+int iiv_store_table_from_table(int mode, const uint16_t *d_table, uint16_t *d_store_out, void *stream)
+{
+    int rc = iiv::check_mode(mode);
+    if (rc) return rc;
+    if (!d_table || !d_store_out) return iiv::set_error(IIV_ERR_INVALID, "NULL table");
+    return iiv::store_table_from_table(mode, d_table, d_store_out, (hipStream_t)stream);
+}
+
 int iiv_pack(int mode, int n, const uint8_t *d_main, const uint8_t *d_aux, uint64_t *d_packed, void *stream)
 {
     int rc = iiv::check_mode(mode);

@@ -23,6 +23,8 @@ int hip_check(hipError_t e, const char *what);
 
 // iiv_tables.hip
 int cie2000_matrix(const uint8_t rgb[48], double out_f[256], int32_t out_i[256], hipStream_t st);
+int symmetrise_table(int mode, uint16_t *d_table, hipStream_t st);
+int store_table_from_table(int mode, const uint16_t *d_table, uint16_t *d_store, hipStream_t st);
 int delta_e_pairs(int n, const double *lab1, const double *lab2, double *out, hipStream_t st);
 int pixel_strings(int mode, uint32_t *d_dots, uint8_t *d_pixels, ulonglong2 *d_strings, hipStream_t st);
 int build_table(int mode, const int32_t dm[256], uint16_t *d_out, int symmetric, hipStream_t st);

@@ -199,6 +199,38 @@ __global__ __launch_bounds__(256) void store_kernel(const ulonglong2 *__restrict
     out[idx] = (uint16_t)edit_distance<ND>(a.x, (uint32_t)a.y, b.x, (uint32_t)b.y, lut);
 }
 
+// Bitmap.edit_distances' load-time mirror (screen.py:352-365): dist[transpose] += dist[identity],
+// i.e. new[a][b] = old[a][b] + old[b][a] (u16 arithmetic), for a table as the .npz files hold it
+template <int MODE>
+__global__ __launch_bounds__(256) void symmetrise_kernel(uint16_t *__restrict__ table)
+{
+    constexpr int BITS = ModeTraits<MODE>::kBits;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // (o, a, b) with a > b: one thread per unordered pair
+    const size_t per_o = (size_t)1 << (2 * BITS);
+    if (idx >= (size_t)ModeTraits<MODE>::kOffsets * per_o) return;
+    const size_t o = idx / per_o, ab = idx % per_o;
+    const uint32_t a = (uint32_t)(ab >> BITS), b = (uint32_t)(ab & ((1u << BITS) - 1));
+    if (a < b) return;
+    uint16_t *T = table + o * per_o;
+    const uint16_t x = T[((size_t)a << BITS) + b], y = T[((size_t)b << BITS) + a];
+    const uint16_t v = (uint16_t)(x + y);
+    T[((size_t)a << BITS) + b] = v;   // (a == b: both reads and both writes hit the same cell: x + x, as numpy does)
+    T[((size_t)b << BITS) + a] = v;
+}
+
+// the store sub-table out of a full symmetric table: S[o][c][m] = table[o][(poke(m, c) << bits) + m]
+template <int MODE>
+__global__ __launch_bounds__(256) void store_from_table_kernel(const uint16_t *__restrict__ table, uint16_t *__restrict__ out)
+{
+    constexpr int BITS = ModeTraits<MODE>::kBits, CB = ModeTraits<MODE>::kContentBits;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= ((size_t)ModeTraits<MODE>::kOffsets << (CB + BITS))) return;
+    const uint32_t m = idx & ((1u << BITS) - 1), c = (idx >> BITS) & ((1u << CB) - 1);
+    const int o = (int)(idx >> (BITS + CB));
+    const uint32_t pm = poke_window<MODE>(m, c, o & 1);
+    out[idx] = table[((size_t)o << (2 * BITS)) + ((size_t)pm << BITS) + m];
+}
+
 // ------------------------------------------------------------------ split store table
 // (see iiv_stream.h).  One thread per entry of either half: build a representative window
 // from the entry's row bits (all other bits zero -- they cannot reach this half's pixels),
@@ -433,6 +465,24 @@ int build_split_store_table(int mode, const int32_t dm[256], uint32_t *d_left, u
     if (tmp_r) (void)hipFree(tmp_r);
     if (rc) return rc;
     return hip_check(he, "sync");
+}
+
+int symmetrise_table(int mode, uint16_t *d_table, hipStream_t st)
+{
+    const size_t n = (size_t)num_offsets(mode) << (2 * masked_bits(mode));
+    dim3 grid((unsigned)((n + 255) / 256));
+    if (mode == kDHGR) hipLaunchKernelGGL(symmetrise_kernel<kDHGR>, grid, dim3(256), 0, st, d_table);
+    else hipLaunchKernelGGL(symmetrise_kernel<kHGR>, grid, dim3(256), 0, st, d_table);
+    return hip_check(hipGetLastError(), "symmetrise_kernel launch");
+}
+
+int store_table_from_table(int mode, const uint16_t *d_table, uint16_t *d_store, hipStream_t st)
+{
+    const size_t n = (size_t)num_offsets(mode) << (content_bits(mode) + masked_bits(mode));
+    dim3 grid((unsigned)((n + 255) / 256));
+    if (mode == kDHGR) hipLaunchKernelGGL(store_from_table_kernel<kDHGR>, grid, dim3(256), 0, st, d_table, d_store);
+    else hipLaunchKernelGGL(store_from_table_kernel<kHGR>, grid, dim3(256), 0, st, d_table, d_store);
+    return hip_check(hipGetLastError(), "store_from_table_kernel launch");
 }
 
 int delta_e_pairs(int n, const double *lab1, const double *lab2, double *out, hipStream_t st)

@@ -32,6 +32,7 @@ SYMBOLS = [
     "iiv_masked_bits", "iiv_masked_dots", "iiv_num_offsets", "iiv_table_entries",
     "iiv_store_table_entries",
     "iiv_cie2000_matrix", "iiv_delta_e_cie2000", "iiv_pixel_strings", "iiv_build_table", "iiv_build_store_table",
+    "iiv_symmetrise_table", "iiv_store_table_from_table",
     "iiv_pack", "iiv_diff_weights", "iiv_compute_delta_pages",
     "iiv_encoder_create", "iiv_encoder_destroy", "iiv_encoder_set_option",
     "iiv_encoder_snapshot", "iiv_encoder_rollback", "iiv_encoder_get_state", "iiv_encoder_set_state",
@@ -88,6 +89,8 @@ def lib():
     L.iiv_pixel_strings.argtypes = [i32, vp, vp, vp]
     L.iiv_build_table.argtypes = [i32, vp, vp, i32, vp]
     L.iiv_build_store_table.argtypes = [i32, vp, vp, vp]
+    L.iiv_symmetrise_table.argtypes = [i32, vp, vp]
+    L.iiv_store_table_from_table.argtypes = [i32, vp, vp, vp]
     L.iiv_pack.argtypes = [i32, i32, vp, vp, vp, vp]
     L.iiv_diff_weights.argtypes = [i32, vp, i32, vp, vp, i32, vp, vp]
     L.iiv_compute_delta_pages.argtypes = [i32, vp, i32, vp, vp, vp, vp, i32, vp, vp]
@@ -214,6 +217,22 @@ def build_split_store_table(mode, dm, expanded=True):
     exp = torch.empty(L.iiv_store_table_entries(mode), dtype=torch.int16, device="cuda") if expanded else None
     check(L.iiv_build_split_store_table(mode, hptr(dm), dptr(left), dptr(right), dptr(exp), stream_ptr()))
     return left, right, exp
+
+
+def load_table(mode, lower_or_file_array):
+    """A table as a reference .npz holds it (lower triangle) -> (symmetric table, store table) in HBM:
+    Bitmap.edit_distances' load + mirror (screen.py:343-367) on the device."""
+    torch = _torch()
+    L = lib()
+    bits = L.iiv_masked_bits(mode)
+    a = np.ascontiguousarray(lower_or_file_array, dtype=np.uint16)
+    if a.shape != (L.iiv_num_offsets(mode), 1 << (2 * bits)):
+        raise ValueError("edit_distance array has shape %s, expected %s" % (a.shape, (L.iiv_num_offsets(mode), 1 << (2 * bits))))
+    table = torch.from_numpy(a.view(np.int16)).cuda()
+    check(L.iiv_symmetrise_table(mode, dptr(table), stream_ptr()))
+    store = torch.empty(L.iiv_store_table_entries(mode), dtype=torch.int16, device="cuda")
+    check(L.iiv_store_table_from_table(mode, dptr(table), dptr(store), stream_ptr()))
+    return table, store
 
 
 def table_to_numpy(t):

@@ -259,15 +259,25 @@ class Bitmap:
             ary[...] = self._fix_column_right(ary, np.roll(ary, 1, axis=1))
 
     # ---- tables (device)
+    LOAD_TABLE_FILES = False   # True: load the .npz like the reference instead of rebuilding (see edit_distances)
+
     @classmethod
     @functools.lru_cache(None)
     def edit_distances(cls, palette_id: pal.Palette) -> DeviceTable:
         """The symmetric edit-distance table for this mode and palette, in HBM.
 
-        If the reference's data file (transcoder/data/<NAME>_palette_<id>_edit_distance.npz,
-        screen.py:347-350) exists its CIE2000 matrix is not consulted and the table is
-        still rebuilt on the GPU from the palette -- the values are identical and the
-        build takes milliseconds, against ~1 minute to read and mirror the file."""
+        By default the table is rebuilt on the GPU from the palette: the values are those
+        make_data_tables writes, and the build takes milliseconds against ~1 minute to read
+        and mirror a file.  With Bitmap.LOAD_TABLE_FILES = True the reference's behaviour is
+        kept: transcoder/data/<NAME>_palette_<id>_edit_distance.npz (screen.py:347-350, relative
+        to the cwd) is loaded and mirrored (screen.py:352-365, on the device) -- that is how a
+        hand-made or third-party table is used.  Such a table has no diff matrix behind it, so
+        the encoder gathers its diff weights from the table and uses the workgroup kernel."""
+        if cls.LOAD_TABLE_FILES:
+            data = "transcoder/data/%s_palette_%d_edit_distance.npz" % (cls.NAME, palette_id.value)
+            dist = np.load(data)["edit_distance"]
+            table, store = native.load_table(cls.MODE, dist)
+            return DeviceTable(cls.MODE, table, store, None)
         import make_data_tables
         dm = make_data_tables.compute_diff_matrix(pal.PALETTES[palette_id])
         table = native.build_table(cls.MODE, dm, symmetric=True)

@@ -83,6 +83,16 @@ int iiv_build_table(int mode, const int32_t dm[256], uint16_t *d_out, int symmet
  * (DHGR 4x128x8192, HGR 2x256x16384 u16). */
 int iiv_build_store_table(int mode, const int32_t dm[256], uint16_t *d_out, void *stream);
 
+/* A table that did NOT come from iiv_build_table -- a user's own
+ * transcoder/data/<MODE>_palette_<id>_edit_distance.npz (screen.py:347-350), uploaded as the
+ * file holds it: iiv_symmetrise_table applies the load-time mirror of Bitmap.edit_distances
+ * (screen.py:352-365: new[a][b] = old[a][b] + old[b][a]) in place, and
+ * iiv_store_table_from_table derives the store sub-table from the result.  An encoder created
+ * from such a pair with dm == NULL gathers its diff weights from the table (IIV_DW_TABLE)
+ * and runs the workgroup greedy kernel.  Asynchronous on `stream`. */
+int iiv_symmetrise_table(int mode, uint16_t *d_table, void *stream);
+int iiv_store_table_from_table(int mode, const uint16_t *d_table, uint16_t *d_store_out, void *stream);
+
 /* ==== P2: screen.Bitmap operations, batched over n independent screens ===== */
 /* Memory maps are (32,256) u8 page/offset arrays (screen.MemoryMap,
  * screen.py:101-125); d_aux is ignored (may be NULL) for HGR. */

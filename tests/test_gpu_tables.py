@@ -130,3 +130,57 @@ def test_rejects_bad_arguments(native):
         native.build_table(1, np.full(256, 500, np.int32))  # 500*10 > 2047
     with pytest.raises(native.IIVError):
         native.build_table(7, np.zeros(256, np.int32))
+
+
+def test_user_supplied_table_file(native, O, oracle_tables, device_tables, tmp_path, monkeypatch):
+    """A table that does not come from iiv_build_table (VERDICT r1 missing #7): a reference-format
+    .npz is loaded and mirrored on the device as Bitmap.edit_distances does (screen.py:343-367), the
+    store table is derived from it, and an encoder without a diff matrix encodes with it -- here a
+    hand-made table (every distance halved) against the oracle given the same table."""
+    import torch
+    import screen
+    import palette
+    mode = 1
+    full = oracle_tables.get(mode)
+    bits = 13
+    a, b = np.divmod(np.arange(1 << (2 * bits), dtype=np.int64), 1 << bits)
+    lower = np.where(a > b, full, 0).astype(np.uint16)
+    t, s = native.load_table(mode, lower)
+    dt, ds = device_tables.get(mode)
+    assert bool((t == dt).all()) and bool((s == ds).all())
+    # the same through the mirror's file path
+    custom_lower = (lower // 2).astype(np.uint16)
+    custom_full = (full // 2).astype(np.uint16)
+    os_dir = tmp_path / "transcoder" / "data"
+    os_dir.mkdir(parents=True)
+    np.savez(str(os_dir / "DHGR_palette_5_edit_distance.npz"), edit_distance=custom_lower)
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(screen.Bitmap, "LOAD_TABLE_FILES", True)
+    screen.DHGRBitmap.edit_distances.cache_clear()
+    try:
+        tab = screen.DHGRBitmap.edit_distances(palette.Palette.NTSC)
+        assert tab.dm is None
+        assert np.array_equal(native.table_to_numpy(tab.table), custom_full)
+        fr = np.zeros((1, 2, 2, 32, 256), np.uint8)
+        rng = np.random.default_rng(3)
+        fr[:] = rng.integers(0, 128, fr.shape)
+        fr[..., (np.arange(256) & 127) >= 120] = 0
+        enc = native.Encoder(mode, tab.table, tab.store, 1)          # dm = None: table gathers + workgroup kernel
+        enc.set_state(native.STATE_RNG_PY, O.mt_seed_py(5).state_words())
+        enc.set_state(native.STATE_RNG_NP, O.mt_seed_np(6).state_words())
+        fm = torch.from_numpy(np.ascontiguousarray(fr[:, :, 0])).cuda()
+        fa = torch.from_numpy(np.ascontiguousarray(fr[:, :, 1])).cuda()
+        sched = [(0, 0, 1, 291), (0, 1, 1, 198), (1, 1, 1, 94), (1, 0, 1, 292)]
+        got = enc.encode(fm, fa, sched).cpu().numpy()[0]
+        enc.check()
+        with pytest.raises(native.IIVError):
+            enc.set_greedy_kernel(True)                               # the one-wave kernel needs dm
+        v = O.Video(mode, custom_full, seed_py=5, seed_np=6)
+        exp = []
+        for (f, ia, _, k) in sched:
+            v.encode_frame(fr[0, f, 0], fr[0, f, 1], ia)
+            exp.append(v.next(k))
+        assert (got == np.concatenate(exp)).all()
+        enc.close()
+    finally:
+        screen.DHGRBitmap.edit_distances.cache_clear()
