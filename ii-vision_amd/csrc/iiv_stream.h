@@ -186,5 +186,6 @@ struct GreedyArgs {
     int lds_pad;             // extra dynamic LDS per stream (bytes): caps the streams resident per CU
 };
 int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st);
+int launch_greedy_team(int mode, const GreedyArgs &a, hipStream_t st);   // iiv_team.hip
 
 }  // namespace iiv

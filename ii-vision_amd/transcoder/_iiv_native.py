@@ -22,7 +22,7 @@ ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_ASSERT, ERR_OVERFLOW = -1, -2, -3, -4, 
 STATE_MEM_MAIN, STATE_MEM_AUX, STATE_UP_MAIN, STATE_UP_AUX = 0, 1, 2, 3
 STATE_RNG_PY, STATE_RNG_NP, STATE_OUT_OF_WORK, STATE_PACKED, STATE_COUNTERS = 4, 5, 6, 7, 8
 OPT_DIFF_WEIGHTS, DW_TABLE, DW_RECURRENCE = 1, 0, 1
-OPT_GREEDY_KERNEL, GREEDY_WAVE, GREEDY_WORKGROUP, GREEDY_AUTO = 2, 0, 1, 2
+OPT_GREEDY_KERNEL, GREEDY_WAVE, GREEDY_WORKGROUP, GREEDY_AUTO, GREEDY_TEAM = 2, 0, 1, 2, 3
 OPT_PREFIX_SORT = 3
 OPT_GREEDY_LDS_PAD = 5
 
@@ -303,8 +303,10 @@ class Encoder:
         self._h = h
 
     def set_greedy_kernel(self, wave_per_stream):
-        """True: one wave per stream; False: one 256-thread workgroup; None: automatic."""
-        v = GREEDY_AUTO if wave_per_stream is None else (GREEDY_WAVE if wave_per_stream else GREEDY_WORKGROUP)
+        """True: one wave per stream; False: one 256-thread workgroup; "team": eight waves per stream;
+        None: automatic."""
+        v = GREEDY_AUTO if wave_per_stream is None else GREEDY_TEAM if wave_per_stream == "team" else (
+            GREEDY_WAVE if wave_per_stream else GREEDY_WORKGROUP)
         check(lib().iiv_encoder_set_option(self._h, OPT_GREEDY_KERNEL, v))
 
     def set_prefix_sort(self, enable):

@@ -154,7 +154,9 @@ void iiv_encoder_destroy(iiv_encoder *enc);
 #define IIV_OPT_GREEDY_KERNEL 2 /* shape of the greedy-selection kernel         */
 #define IIV_GREEDY_WAVE 0       /*   one 64-lane wave per stream, split store table */
 #define IIV_GREEDY_WORKGROUP 1  /*   one 256-thread workgroup per stream, dense store table */
-#define IIV_GREEDY_AUTO 2       /*   default: WAVE whenever dm was given at creation */
+#define IIV_GREEDY_AUTO 2       /*   default: TEAM up to 768 streams, WAVE beyond (dm given at creation) */
+#define IIV_GREEDY_TEAM 3       /*   eight waves per stream score the next list entries concurrently and
+                                 *   commit in order: the lowest latency for one or a few clips */
 #define IIV_OPT_PREFIX_SORT 3    /* 1 (default): when a generator's opcode budget B is known
                                  * (another restart follows in the same iiv_encode call) and
                                  * 3B <= 2048, only that many highest priorities are ordered;

@@ -46,7 +46,7 @@ for rnd in range(rounds):
             f = int(rng.integers(0, nf))
             ia = int(rng.integers(0, 2)) if mode == 1 else 0
         sched.append((f, ia, restart, k))
-    wave = bool(rng.random() < 0.75)
+    wave = (True, True, "team", "team", False)[int(rng.integers(0, 5))]
     recurrence = bool(rng.random() < 0.8)
     prefix = bool(rng.random() < 0.7)
     enc = native.Encoder(mode, dtab[key][0], dtab[key][1], n, dm=dms[pal])
@@ -77,6 +77,6 @@ for rnd in range(rounds):
         assert (int(cnt[0]), int(cnt[1])) == v.draws(), ("draws", rnd, i)
         total_ops += exp.shape[0]
     enc.close()
-    print("round %2d ok: mode=%s pal=%d %s wave=%d rec=%d prefix=%d segs=%s" % (
+    print("round %2d ok: mode=%s pal=%d %s wave=%s rec=%d prefix=%d segs=%s" % (
         rnd, "DHGR" if mode else "HGR", pal, kind, wave, recurrence, prefix, [s[3] for s in sched]), flush=True)
 print("fuzz parity: %d rounds, %d opcodes compared, all equal (%.0f s)" % (rounds, total_ops, time.time() - t_start))

@@ -28,7 +28,8 @@ def _frames(mode, n_streams, n_frames, seed, kinds):
     return out
 
 
-def _run_and_compare(native, O, oracle_tables, device_tables, mode, pal, frames, seeds, step_frames, every_n=1):
+def _run_and_compare(native, O, oracle_tables, device_tables, mode, pal, frames, seeds, step_frames, every_n=1,
+                     kernel=True):
     import torch
     n, nf = frames.shape[:2]
     t, s = device_tables.get(mode, pal)
@@ -36,7 +37,7 @@ def _run_and_compare(native, O, oracle_tables, device_tables, mode, pal, frames,
     fa = torch.from_numpy(np.ascontiguousarray(frames[:, :, 1])).cuda() if mode == 1 else None
     b = stream_batch.StreamBatch(mode, t, s, n, seeds=seeds, dm=device_tables.dm[(mode, pal)],
                                  every_n_video_frames=every_n)
-    b.enc.set_greedy_kernel(True)
+    b.enc.set_greedy_kernel(kernel)
     got, all_segs = [], []
     while b.clock.frame_number < nf:
         ops, segs = b.encode_frames(fm, fa, min(step_frames, nf - b.clock.frame_number))
@@ -67,11 +68,14 @@ def _run_and_compare(native, O, oracle_tables, device_tables, mode, pal, frames,
 
 
 @pytest.mark.parametrize("mode", [1, 0])
-def test_long_movie_paced_clips(native, O, oracle_tables, device_tables, mode):
+@pytest.mark.parametrize("kernel", [True, "team"])
+def test_long_movie_paced_clips(native, O, oracle_tables, device_tables, mode, kernel):
     """Configs 3 / 4: 210 frames (102 900 opcodes per stream, ~560 generators in DHGR) of an iid, a
-    coherent and an image-like clip in one batch, 50 frames per iiv_encode call."""
+    coherent and an image-like clip in one batch, 50 frames per iiv_encode call -- through the
+    one-wave kernel and through the eight-waves-per-stream kernel a single clip gets."""
     frames = _frames(mode, 3, 210, 4000 + mode, ("iid", "coh", "img"))
-    _run_and_compare(native, O, oracle_tables, device_tables, mode, 5, frames, [(21, 22), (23, 24), (25, 26)], 50)
+    _run_and_compare(native, O, oracle_tables, device_tables, mode, 5, frames, [(21, 22), (23, 24), (25, 26)], 50,
+                     kernel=kernel)
 
 
 def test_main_py_defaults_long_clip(native, O, oracle_tables, device_tables):

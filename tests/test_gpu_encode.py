@@ -51,12 +51,13 @@ def _next_draws(O, words, n, high):
     return [f(C.byref(m)) for _ in range(n)]
 
 
-@pytest.mark.parametrize("recurrence,wave", [(True, True), (False, True), (True, False), (False, False)])
+@pytest.mark.parametrize("recurrence,wave", [(True, True), (False, True), (True, False), (False, False), (True, "team")])
 def test_golden_runs(native, O, golden, device_tables, recurrence, wave):
     """recurrence=True: diff weights recomputed in the prologue; False: gathered from
     the HBM table.  wave=True: one wave per stream reading the split store table; False: one
-    256-thread workgroup per stream reading the dense u16 store table.  Every combination must
-    reproduce the reference bit for bit."""
+    256-thread workgroup per stream reading the dense u16 store table; "team": eight waves per
+    stream scoring the next list entries concurrently.  Every combination must reproduce the
+    reference bit for bit."""
     g3 = golden.g3_encode_runs
     for tag in _tags(g3):
         mode, pal, sp, sn = (int(x) for x in g3[tag + "/meta"])
@@ -109,7 +110,7 @@ def _oracle_run(O, oracle_tables, mode, pal, frames, sched, sp, sn):
 
 
 @pytest.mark.parametrize("mode,wave,prefix", [(1, True, True), (0, True, True), (1, False, True), (1, True, False),
-                                              (0, False, False)])
+                                              (0, False, False), (1, "team", True), (0, "team", False)])
 def test_batch_of_independent_streams(native, O, oracle_tables, device_tables, mode, wave, prefix):
     """12 streams with different data / seeds / coherence in ONE launch sequence,
     ragged segment lengths incl. bank flips; every stream equals its own oracle run."""
@@ -193,7 +194,7 @@ def test_reference_asserts_are_reported(native, device_tables):
     enc.close()
 
 
-@pytest.mark.parametrize("mode,wave", [(1, True), (1, False), (0, True)])
+@pytest.mark.parametrize("mode,wave", [(1, True), (1, False), (0, True), (1, "team"), (0, "team")])
 def test_image_like_streams(native, O, oracle_tables, device_tables, mode, wave):
     """S-img input (dithered moving bars): large coherent areas, many identical
     windows, so the two best deltas tie far more often than on random data -- the wave
@@ -224,7 +225,7 @@ def test_image_like_streams(native, O, oracle_tables, device_tables, mode, wave)
     enc.close()
 
 
-@pytest.mark.parametrize("mode,wave", [(1, True), (0, True), (1, False)])
+@pytest.mark.parametrize("mode,wave", [(1, True), (0, True), (1, False), (1, "team"), (0, "team")])
 def test_per_stream_schedules(native, O, oracle_tables, device_tables, mode, wave):
     """iiv_encode_streams: every stream has its own movie clock (movie.py:16-54) -- different
     clip lengths, every_n_video_frames and frame rates in ONE batch, over two calls so that

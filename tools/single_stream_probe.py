@@ -8,7 +8,7 @@ for mode in (native.DHGR, native.HGR):
     dhgr = mode == native.DHGR
     for n in (1, 8):
         fm, fa = stream_batch.synth_frames_torch(n, 60, dhgr, seed=99)
-        for wave in (False, True):
+        for wave in (False, True, "team"):
             b = stream_batch.StreamBatch(mode, table, store, n, seeds=[(i+1,i+1) for i in range(n)], dm=dm)
             b.enc.set_greedy_kernel(wave)
             b.enc.profile(True)
