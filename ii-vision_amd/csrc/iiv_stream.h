@@ -148,7 +148,7 @@ __device__ static inline void wave_lds_sync()
 }
 
 // next MT19937 block, one wave, fully unrolled (constant LDS offsets, no loop counters)
-__device__ static inline void mt_twist_wave(const uint32_t *src, uint32_t *dst, int lane)
+__device__ static inline void mt_twist_wave(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int lane)
 {
 #pragma unroll
     for (int k = 0; k < 4; k++) {

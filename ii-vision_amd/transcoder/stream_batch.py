@@ -54,17 +54,17 @@ class MovieClock:
         cur = None
         end_frame = None if n_video_frames is None else self.frame_number + int(n_video_frames)
         end_ticks = None if max_ticks is None else self.ticks + int(max_ticks)
+        tpf = self.ticks_per_frame
         while True:
             if end_ticks is not None and self.ticks >= end_ticks:
                 break
             # would the next tick start frame `end_frame`?  then stop before it
             nxt = self.ticks + 1
-            if end_frame is not None and nxt >= self.ticks_per_frame * self.frame_number \
-                    and self.frame_number >= end_frame:
+            if end_frame is not None and nxt >= tpf * self.frame_number and self.frame_number >= end_frame:
                 break
             self.ticks = nxt
             restart = False
-            if self.ticks >= self.ticks_per_frame * self.frame_number:   # Video.tick
+            if self.ticks >= tpf * self.frame_number:                    # Video.tick
                 self.frame_number += 1
                 if (self.frame_number - 1) % self.every_n == 0:
                     self._target = self.frame_number - 1
@@ -89,6 +89,19 @@ class MovieClock:
                 if self.dhgr:
                     self.aux_bank = not self.aux_bank
                 self.stream_pos += ACK_BYTES
+                continue
+            # ---- the ticks after this one up to the next event are all alike (same generator, one opcode
+            # each): take them in one step.  Events: the tick that starts the next frame, the tick whose
+            # opcode fills the socket frame (it is handled by the code above), the end of the call.
+            m = int(-(-(tpf * self.frame_number) // 1)) - 1 - self.ticks      # ticks before the next frame's first
+            r = self.stream_pos % SOCKET_FRAME
+            m = min(m, (SOCKET_FRAME - ACK_BYTES - 1 - r) // TICK_OPCODE_BYTES)   # opcodes that still end below 2044
+            if end_ticks is not None:
+                m = min(m, end_ticks - self.ticks)
+            if m > 0:
+                self.ticks += m
+                cur[3] += m
+                self.stream_pos += TICK_OPCODE_BYTES * m
         return [tuple(s) for s in segs]
 
 
