@@ -10,7 +10,7 @@ import _iiv_native as native, stream_batch, palette
 for mode in (native.DHGR, native.HGR):
     _, dm = native.cie2000_matrix(palette.NTSCPalette.rgb_array())
     table = native.build_table(mode, dm, True); store = native.build_store_table(mode, dm)
-    for n in (1, 64, 512):
+    for n in [int(x) for x in (sys.argv[1:] or ("1", "64", "512"))]:
         fm, fa = stream_batch.synth_frames_torch(n, 260, mode == native.DHGR, seed=99)
         for kern in (True, "team"):
             b = stream_batch.StreamBatch(mode, table, store, n, seeds=[(i + 1, i + 1) for i in range(n)], dm=dm)
