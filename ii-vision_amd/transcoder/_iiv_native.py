@@ -36,7 +36,8 @@ SYMBOLS = [
     "iiv_pack", "iiv_diff_weights", "iiv_compute_delta_pages",
     "iiv_encoder_create", "iiv_encoder_destroy", "iiv_encoder_set_option",
     "iiv_encoder_snapshot", "iiv_encoder_rollback", "iiv_encoder_get_state", "iiv_encoder_set_state",
-    "iiv_encoder_set_state_range", "iiv_encode", "iiv_encode_streams",
+    "iiv_encoder_set_state_range", "iiv_encoder_get_video_state", "iiv_encoder_set_video_state",
+    "iiv_encode", "iiv_encode_streams",
     "iiv_encoder_check", "iiv_encoder_profile", "iiv_encoder_profile_read",
     "iiv_build_split_store_table", "iiv_split_table_entries",
     "iiv_emit_stream", "iiv_emit_chunk", "iiv_frames_to_memory_maps",
@@ -45,6 +46,17 @@ SYMBOLS = [
 
 class Segment(C.Structure):
     _fields_ = [("frame", C.c_int32), ("is_aux", C.c_int32), ("restart", C.c_int32), ("n_ops", C.c_int32)]
+
+
+class VideoState(C.Structure):
+    """include/iivision.h: iiv_video_state"""
+    _fields_ = [("mem_main", C.c_uint8 * 8192), ("mem_aux", C.c_uint8 * 8192),
+                ("up_main", C.c_int32 * 8192), ("up_aux", C.c_int32 * 8192),
+                ("rng_py", C.c_uint32 * 625), ("rng_np", C.c_uint32 * 625),
+                ("out_of_work", C.c_int32 * 2), ("packed", C.c_uint64 * 4096)]
+
+    def array(self, name, dtype, shape):
+        return np.frombuffer(getattr(self, name), dtype=dtype).reshape(shape)
 
 
 class IIVError(RuntimeError):
@@ -103,6 +115,8 @@ def lib():
     L.iiv_encoder_get_state.argtypes = [vp, i32, i32, vp, sz]
     L.iiv_encoder_set_state.argtypes = [vp, i32, i32, vp, sz]
     L.iiv_encoder_set_state_range.argtypes = [vp, i32, i32, i32, vp, sz]
+    L.iiv_encoder_get_video_state.argtypes = [vp, i32, C.POINTER(VideoState)]
+    L.iiv_encoder_set_video_state.argtypes = [vp, i32, C.POINTER(VideoState)]
     L.iiv_encode.argtypes = [vp, vp, vp, i32, C.POINTER(Segment), i32, vp, vp]
     L.iiv_encode_streams.argtypes = [vp, vp, vp, i32, C.POINTER(Segment), C.POINTER(C.c_int32), vp, sz, vp]
     L.iiv_build_split_store_table.argtypes = [i32, vp, vp, vp, vp, vp]
@@ -350,6 +364,14 @@ class Encoder:
         shape, dt = self._ITEMS[what]
         a = np.ascontiguousarray(value, dtype=dt).reshape(shape)
         check(lib().iiv_encoder_set_state(self._h, int(stream), what, hptr(a), a.nbytes))
+
+    def get_video_state(self, stream=0, out=None):
+        out = out if out is not None else VideoState()
+        check(lib().iiv_encoder_get_video_state(self._h, int(stream), C.byref(out)))
+        return out
+
+    def set_video_state(self, state, stream=0):
+        check(lib().iiv_encoder_set_video_state(self._h, int(stream), C.byref(state)))
 
     def set_state_all(self, what, values, first=0):
         """values: (n, ...) array, item `what` of streams first .. first + n - 1 in one upload."""

@@ -101,6 +101,8 @@ class Video:
         self._mode_id = native.DHGR if mode == VideoMode.DHGR else native.HGR
         self._enc = native.Encoder(self._mode_id, tables.table, tables.store, n_streams=1, dm=tables.dm)
         self._live = None  # the generator whose state the device currently holds
+        self._vs = native.VideoState()   # one staging buffer for every state round trip
+        self._dev_main = self._dev_aux = None   # the live generator's target on the device
 
     # ---- the reference's public attributes; reading one settles any speculation first
     def _settled(name):  # noqa: N805
@@ -148,37 +150,40 @@ class Video:
     # ------------------------------------------------------------------ device sync
 
     def _upload(self):
-        e = self._enc
-        e.set_state(native.STATE_MEM_MAIN, self._memory_map.page_offset)
-        e.set_state(native.STATE_UP_MAIN, self._update_priority)
-        if self.mode == VideoMode.DHGR:
-            e.set_state(native.STATE_MEM_AUX, self._aux_memory_map.page_offset)
-            e.set_state(native.STATE_UP_AUX, self._aux_update_priority)
-        e.set_state(native.STATE_RNG_PY, np.array(random.getstate()[1], dtype=np.uint32))
-        st = np.random.get_state()
-        e.set_state(native.STATE_RNG_NP,
-                    np.concatenate([np.asarray(st[1], dtype=np.uint32), np.array([st[2]], dtype=np.uint32)]))
+        """Host state -> device, one call (iiv_encoder_set_video_state)."""
+        st = self._vs
+        dhgr = self.mode == VideoMode.DHGR
+        st.array("mem_main", np.uint8, (32, 256))[...] = self._memory_map.page_offset
+        st.array("up_main", np.int32, (32, 256))[...] = self._update_priority
+        if dhgr:
+            st.array("mem_aux", np.uint8, (32, 256))[...] = self._aux_memory_map.page_offset
+            st.array("up_aux", np.int32, (32, 256))[...] = self._aux_update_priority
+        st.array("rng_py", np.uint32, (625,))[...] = random.getstate()[1]
+        nps = np.random.get_state()
+        rn = st.array("rng_np", np.uint32, (625,))
+        rn[:624] = nps[1]
+        rn[624] = nps[2]
         # movie.py:96 resets the flags at every frame
-        e.set_state(native.STATE_OUT_OF_WORK,
-                    np.array([int(bool(self._out_of_work[False])), int(bool(self._out_of_work[True]))], dtype=np.int32))
+        st.out_of_work[0] = int(bool(self._out_of_work[False]))
+        st.out_of_work[1] = int(bool(self._out_of_work[True]))
+        self._enc.set_video_state(st)
         self._touched = False
 
     def _download(self):
-        e = self._enc
-        # in place: callers (and self.pixelmap) hold references to these arrays
-        self._memory_map.page_offset[...] = e.get_state(native.STATE_MEM_MAIN)
-        self._update_priority[...] = e.get_state(native.STATE_UP_MAIN)
+        """Device state -> host, one call; in place: callers (and self.pixelmap) hold references to the arrays."""
+        st = self._enc.get_video_state(out=self._vs)
+        self._memory_map.page_offset[...] = st.array("mem_main", np.uint8, (32, 256))
+        self._update_priority[...] = st.array("up_main", np.int32, (32, 256))
         if self.mode == VideoMode.DHGR:
-            self._aux_memory_map.page_offset[...] = e.get_state(native.STATE_MEM_AUX)
-            self._aux_update_priority[...] = e.get_state(native.STATE_UP_AUX)
-        self._pixelmap.packed[...] = e.get_state(native.STATE_PACKED)
-        random.setstate((3, tuple(int(x) for x in e.get_state(native.STATE_RNG_PY)), None))
-        npw = e.get_state(native.STATE_RNG_NP)
-        st = np.random.get_state()
-        np.random.set_state((st[0], npw[:624].copy(), int(npw[624]), st[3], st[4]))
-        oow = e.get_state(native.STATE_OUT_OF_WORK)
-        self._out_of_work[False] = bool(oow[0])  # video.py:189
-        self._out_of_work[True] = bool(oow[1])
+            self._aux_memory_map.page_offset[...] = st.array("mem_aux", np.uint8, (32, 256))
+            self._aux_update_priority[...] = st.array("up_aux", np.int32, (32, 256))
+        self._pixelmap.packed[...] = st.array("packed", np.uint64, (32, 128))
+        random.setstate((3, tuple(st.rng_py), None))
+        npw = st.array("rng_np", np.uint32, (625,))
+        nps = np.random.get_state()
+        np.random.set_state((nps[0], npw[:624].copy(), int(npw[624]), nps[3], nps[4]))
+        self._out_of_work[False] = bool(st.out_of_work[0])  # video.py:189
+        self._out_of_work[True] = bool(st.out_of_work[1])
         self._host_current = True
 
     def _launch(self, token, restart, n_ops):
@@ -235,13 +240,16 @@ class Video:
 
         token = _Token()
         token.is_aux = bool(is_aux)
-        # the target stays on the device for the generator's life
-        main = np.ascontiguousarray(target_pixelmap.main_memory.page_offset, dtype=np.uint8)
-        token.fm = torch.from_numpy(main[None, None].copy()).cuda()
-        token.fa = None
+        # the target lives in ONE pair of device buffers per Video (only the latest generator can run,
+        # see below); this generator's copy goes there when it starts, after the previous one is settled
+        token.main = np.ascontiguousarray(target_pixelmap.main_memory.page_offset, dtype=np.uint8).reshape(1, 1, 32, 256).copy()
+        token.aux = None
         if self.mode == VideoMode.DHGR:
-            aux = np.ascontiguousarray(target_pixelmap.aux_memory.page_offset, dtype=np.uint8)
-            token.fa = torch.from_numpy(aux[None, None].copy()).cuda()
+            token.aux = np.ascontiguousarray(target_pixelmap.aux_memory.page_offset, dtype=np.uint8).reshape(1, 1, 32, 256).copy()
+        if self._dev_main is None:
+            self._dev_main = torch.empty((1, 1, 32, 256), dtype=torch.uint8, device="cuda")
+            self._dev_aux = torch.empty((1, 1, 32, 256), dtype=torch.uint8, device="cuda") if token.aux is not None else None
+        token.fm, token.fa = self._dev_main, self._dev_aux
         chunk = int(budget) if budget else 1 if self.STRICT_SYNC else max(1, int(self.SPECULATE))
         speculative = not budget and chunk > 1
         while True:
@@ -255,6 +263,10 @@ class Video:
             if restart or self._touched or self.STRICT_SYNC:
                 self._settle()
                 self._upload()
+            if restart:
+                self._dev_main.copy_(torch.from_numpy(token.main))
+                if token.aux is not None:
+                    self._dev_aux.copy_(torch.from_numpy(token.aux))
             if speculative:
                 self._enc.snapshot()
                 try:

@@ -184,6 +184,18 @@ int iiv_encoder_set_state(iiv_encoder *enc, int stream_index, int what, const vo
 int iiv_encoder_set_state_range(iiv_encoder *enc, int first_stream, int n_streams, int what, const void *host_buf,
                                 size_t bytes_per_stream);
 
+/* Everything a video.Video object exposes, in one round trip (one synchronisation, four copies)
+ * instead of one call per item: what the drop-in Video needs whenever somebody looks at it. */
+typedef struct {
+    uint8_t mem_main[32 * 256], mem_aux[32 * 256];   /* memory_map / aux_memory_map .page_offset     */
+    int32_t up_main[32 * 256], up_aux[32 * 256];     /* update_priority / aux_update_priority        */
+    uint32_t rng_py[625], rng_np[625];               /* as IIV_STATE_RNG_PY / IIV_STATE_RNG_NP       */
+    int32_t out_of_work[2];                          /* out_of_work {False, True}                    */
+    uint64_t packed[32 * 128];                       /* pixelmap.packed (filled by get, ignored by set) */
+} iiv_video_state;
+int iiv_encoder_get_video_state(iiv_encoder *enc, int stream_index, iiv_video_state *host_out);
+int iiv_encoder_set_video_state(iiv_encoder *enc, int stream_index, const iiv_video_state *host_in);
+
 /* Copy / restore the complete state of every stream (screen, priorities, live
  * generator, both RNG streams) on the device.  A caller that must not run ahead of
  * its consumer (a lazy generator, video.py:72-93) can snapshot, produce N opcodes in
