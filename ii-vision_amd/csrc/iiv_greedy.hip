@@ -365,6 +365,19 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
     };
 
     int guard = n_ops + 8192 + 2 * kPushedCap + 64;
+#ifdef IIV_STAMPS
+    // diagnostic build: shader clocks of this wave per pipeline stage, and its start / end time
+    unsigned long long ph[4] = {0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memtime();
+    const unsigned long long wave_t0 = ph_t;
+#define IIV_PHASE(i)                                                  \
+    do {                                                              \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        ph[i] += now_ - ph_t;                                         \
+        ph_t = now_;                                                  \
+    } while (0)
+#else
+#define IIV_PHASE(i) do { } while (0)
+#endif
 
     // ---- phase A: the sorted initial list (video.py:121-131), pipelined.
     // The list is read 64 entries at a time (the next window's words are requested one window
@@ -445,9 +458,12 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
             int hD = hC;
             const uint32_t eD = (active && eC) ? take(hD) : 0u;
             row = row_of(eD);
+            IIV_PHASE(0);   // wait for the row, issue eight table loads, take an entry, request its row
             if (!active) return false;
             twist_now();  // (the MT19937 block generation hides behind the loads)
+            IIV_PHASE(1);   // MT19937 block generation
             (void)step(eA, cur);
+            IIV_PHASE(2);   // wait for the table words, score, apply
             head = hA;
             eA = eB;
             hA = hB;
@@ -533,8 +549,15 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         S.ops += (unsigned long long)done;
         S.pad_ops += pad_ops;
         if (err && S.error == 0) S.error = err;
+#ifdef IIV_STAMPS
+        for (int i = 0; i < 4; i++) S.stamps[16 + i] = ph[i];
+        S.stamps[24] = wave_t0;
+        S.stamps[25] = __builtin_amdgcn_s_memtime();
+        S.stamps[26] = (unsigned long long)done;
+#endif
     }
 }
+#undef IIV_PHASE
 
 int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st)
 {
