@@ -451,6 +451,10 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         // compiler's wait for the row from covering the stores of the latest step -- but
         // nothing is scored.
         auto half = [&](const Loaded &cur, Loaded &nxt, uint4 &row, bool active) -> bool {
+#ifdef IIV_STAMPS
+            asm volatile("" : "+v"(row.x), "+v"(row.y), "+v"(row.z), "+v"(row.w));   // (the row's arrival, timed on its own)
+            IIV_PHASE(3);
+#endif
             gather8(row, eB >> 16 & 0xffu, nxt);
             // every use of the old row is scheduled before the new one is requested, so that the
             // load can land in the same registers (otherwise: a copy, and a wait in front of it)

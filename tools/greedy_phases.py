@@ -23,8 +23,8 @@ print("S=%d: wave lifetimes mean %.0f  min %.0f  max %.0f clocks; launch span %.
     S, life.mean(), life.min(), life.max(), span, life.mean() / span))
 print("        starts: first %.0f, median %.0f, last %.0f clocks after the first wave" % (
     0, np.median(t0 - t0.min()), (t0 - t0.min()).max()))
-names = ["row wait + 8 loads + take + row request", "MT19937 generation", "table-word wait + score + apply", "-"]
+names = ["8 loads + take + row request", "MT19937 generation", "table-word wait + score + apply", "waiting for the row (requested two entries earlier)"]
 tot = rows.sum(axis=1).mean()
 print("        clocks per opcode %.0f:" % (tot / ops.mean()))
-for n, v in zip(names[:3], rows.mean(axis=0)[:3]):
+for n, v in zip(names, rows.mean(axis=0)):
     print("          %-44s %7.0f  (%4.1f %%)" % (n, v / ops.mean(), 100 * v / tot))
