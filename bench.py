@@ -87,8 +87,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip make_data_tables / single-stream (profiling runs)")
     ap.add_argument("--cpu-frames", type=int, default=600, help="frames of stream 0 the CPU baseline encodes")
     ap.add_argument("--cpu-frames-all", type=int, default=60, help="frames per stream of the all-cores CPU baseline")
-    ap.add_argument("--dw-table", action="store_true",
-                    help="gather diff weights from the HBM table instead of recomputing them (same values)")
+    ap.add_argument("--dw", choices=["split", "recurrence", "table"], default="recurrence",
+                    help="how the prologue obtains the diff weights (same values): the recurrence in the kernel, two "
+                         "gathers from the split table, or one gather from the full table in HBM")
+    ap.add_argument("--dw-table", action="store_true", help="same as --dw table")
     ap.add_argument("--greedy", choices=["auto", "wave", "workgroup"], default="auto",
                     help="greedy kernel shape: one wave per stream, one 256-thread workgroup per stream, or auto")
     ap.add_argument("--full-sort", action="store_true", help="disable the prologue's prefix sort")
@@ -145,8 +147,7 @@ class GpuBackend:
     def make_batch(self, S, seeds):
         a = self.args
         b = self.sb.StreamBatch(self.mode, self.table, self.store, S, seeds=seeds, dm=self.dm)
-        if a.dw_table:
-            b.enc.set_diff_weights_mode(False)
+        b.enc.set_diff_weights_mode("table" if a.dw_table else a.dw)
         b.enc.set_greedy_kernel(None if a.greedy == "auto" else a.greedy == "wave")
         if a.full_sort:
             b.enc.set_prefix_sort(False)
@@ -272,7 +273,7 @@ def main(argv=None, backend_cls=GpuBackend):
             "parallelism": "%d GPU x %d independent streams, no collective" % (n_gpus, S),
         },
         "opcodes_per_s": fps * OPS_PER_FRAME,
-        "diff_weights": "table-gather" if args.dw_table else "recurrence",
+        "diff_weights": "table-gather" if args.dw_table or args.dw == "table" else args.dw,
         "table_build_s": t_tab,
     }
 

@@ -129,6 +129,17 @@ template <int MODE> __host__ __device__ constexpr size_t split_right_entries()
 {
     return (size_t)ModeTraits<MODE>::kOffsets << (SplitTraits<MODE>::kRightCBits + SplitTraits<MODE>::kRightRowBits);
 }
+// The same cut applied to the diff weights (Bitmap.diff_weights, screen.py:400-449: distance between
+// the current and the target window of a byte): both windows are arbitrary, so a half is indexed
+// by the row parts of both -- DWL[o][row_left(cur)][row_left(tgt)], DWR[o][row_right(cur)][row_right(tgt)].
+template <int MODE> __host__ __device__ constexpr size_t split_dw_left_entries()
+{
+    return (size_t)ModeTraits<MODE>::kOffsets << (2 * SplitTraits<MODE>::kLeftRowBits);
+}
+template <int MODE> __host__ __device__ constexpr size_t split_dw_right_entries()
+{
+    return (size_t)ModeTraits<MODE>::kOffsets << (2 * SplitTraits<MODE>::kRightRowBits);
+}
 constexpr uint32_t kSplitInf = 0x3fffu;  // "no path": finite sums stay below it, and INF + INF fits 16 bits
 
 // S from the two packed halves (lo 16 bits = component 0, hi = component 1)

@@ -300,6 +300,55 @@ __global__ __launch_bounds__(256) void split_kernel(const ulonglong2 *__restrict
     }
 }
 
+// The halves of the diff-weight table (iiv_stream.h): the same recurrence between two arbitrary
+// windows, each built from its row part alone.
+template <int MODE>
+__global__ __launch_bounds__(256) void split_dw_kernel(const ulonglong2 *__restrict__ strings,
+                                                       const uint16_t *__restrict__ sub, uint32_t *__restrict__ left,
+                                                       uint32_t *__restrict__ right)
+{
+    using T = SplitTraits<MODE>;
+    constexpr int BITS = ModeTraits<MODE>::kBits, ND = ModeTraits<MODE>::kDots;
+    __shared__ uint16_t lut[256];
+    load_cost_lut(lut, sub, threadIdx.x);
+    __syncthreads();
+    const size_t nl = split_dw_left_entries<MODE>(), nr = split_dw_right_entries<MODE>();
+    size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool is_left = idx < nl;
+    if (!is_left) idx -= nl;
+    if (!is_left && idx >= nr) return;
+    const int rb = is_left ? T::kLeftRowBits : T::kRightRowBits;
+    const uint32_t row_t = idx & ((1u << rb) - 1), row_s = (idx >> rb) & ((1u << rb) - 1);
+    const int o = (int)(idx >> (2 * rb));
+    const uint32_t mask = is_left ? split_mask_left<MODE>(o) : split_mask_right<MODE>(o);
+    const ulonglong2 a = strings[((size_t)o << BITS) + pdep32(row_s, mask)],
+                     b = strings[((size_t)o << BITS) + pdep32(row_t, mask)];
+    auto step = [&](int k, uint32_t &e1, uint32_t &e2) {
+        const uint32_t ak = string_pixel(a, k), bk = string_pixel(b, k);
+        uint32_t e = e1 + lut[ak * 16 + bk];
+        if (k >= 1) {
+            const uint32_t ap = string_pixel(a, k - 1), bp = string_pixel(b, k - 1);
+            if (ap == bk && ak == bp && e2 + 1 < e) e = e2 + 1;
+        }
+        e = e < kSplitInf ? e : kSplitInf;
+        e2 = e1;
+        e1 = e;
+    };
+    if (is_left) {
+        uint32_t e1 = 0, e2 = kSplitInf;
+        for (int k = 0; k < T::kCut; k++) step(k, e1, e2);
+        left[idx] = e2 | (e1 << 16);
+    } else {
+        uint32_t r[2];
+        for (int j = 0; j < 2; j++) {
+            uint32_t e2 = j == 0 ? 0u : kSplitInf, e1 = j == 0 ? kSplitInf : 0u;
+            for (int k = T::kCut; k < ND; k++) step(k, e1, e2);
+            r[j] = e1;
+        }
+        right[idx] = r[0] | (r[1] << 16);
+    }
+}
+
 // the dense store table rebuilt from the two halves with the index arithmetic the encoder
 // kernels use (tests compare it with store_kernel's output, entry for entry)
 template <int MODE>
@@ -429,6 +478,74 @@ int build_split_tables(int mode, const ulonglong2 *d_strings, const uint16_t *d_
     else
         hipLaunchKernelGGL(split_kernel<kHGR>, grid, dim3(256), 0, st, d_strings, d_sub, d_left, d_right);
     return hip_check(hipGetLastError(), "split_kernel launch");
+}
+
+size_t split_dw_entries(int mode, int right)
+{
+    if (mode == kDHGR) return right ? split_dw_right_entries<kDHGR>() : split_dw_left_entries<kDHGR>();
+    return right ? split_dw_right_entries<kHGR>() : split_dw_left_entries<kHGR>();
+}
+
+int build_split_dw_tables(int mode, const ulonglong2 *d_strings, const uint16_t *d_sub, uint32_t *d_left, uint32_t *d_right,
+                          hipStream_t st)
+{
+    const size_t n = split_dw_entries(mode, 0) + split_dw_entries(mode, 1);
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (mode == kDHGR)
+        hipLaunchKernelGGL(split_dw_kernel<kDHGR>, grid, dim3(256), 0, st, d_strings, d_sub, d_left, d_right);
+    else
+        hipLaunchKernelGGL(split_dw_kernel<kHGR>, grid, dim3(256), 0, st, d_strings, d_sub, d_left, d_right);
+    return hip_check(hipGetLastError(), "split_dw_kernel launch");
+}
+
+// every entry of the full symmetric table against the combination of the two halves
+template <int MODE>
+__global__ __launch_bounds__(256) void split_dw_check_kernel(const uint32_t *__restrict__ left,
+                                                             const uint32_t *__restrict__ right,
+                                                             const uint16_t *__restrict__ table,
+                                                             unsigned long long *__restrict__ mismatches)
+{
+    using T = SplitTraits<MODE>;
+    constexpr int BITS = ModeTraits<MODE>::kBits;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // ((o << BITS) + source) << BITS) + target
+    if (idx >= ((size_t)ModeTraits<MODE>::kOffsets << (2 * BITS))) return;
+    const uint32_t t = idx & ((1u << BITS) - 1), s = (idx >> BITS) & ((1u << BITS) - 1);
+    const int o = (int)(idx >> (2 * BITS)), odd = o & 1;
+    const uint32_t l = left[(((size_t)o << T::kLeftRowBits) + split_row_left<MODE>(s, odd) << T::kLeftRowBits) +
+                            split_row_left<MODE>(t, odd)];
+    const uint32_t r = right[(((size_t)o << T::kRightRowBits) + split_row_right<MODE>(s, odd) << T::kRightRowBits) +
+                             split_row_right<MODE>(t, odd)];
+    if (split_combine(l, r) != table[idx]) atomicAdd(mismatches, 1ull);
+}
+
+int check_split_dw_table(int mode, const int32_t dm[256], const uint16_t *d_table, unsigned long long *mismatches,
+                         hipStream_t st)
+{
+    TableScratch sc;
+    int rc = prepare_scratch(mode, dm, sc, st);
+    if (rc) return rc;
+    uint32_t *d_l = nullptr, *d_r = nullptr;
+    unsigned long long *d_cnt = nullptr;
+    do {
+        if ((rc = hip_check(hipMalloc(&d_l, split_dw_entries(mode, 0) * 4), "hipMalloc(dw left)"))) break;
+        if ((rc = hip_check(hipMalloc(&d_r, split_dw_entries(mode, 1) * 4), "hipMalloc(dw right)"))) break;
+        if ((rc = hip_check(hipMalloc(&d_cnt, 8), "hipMalloc(count)"))) break;
+        if ((rc = hip_check(hipMemsetAsync(d_cnt, 0, 8, st), "memset"))) break;
+        if ((rc = build_split_dw_tables(mode, sc.strings, sc.sub, d_l, d_r, st))) break;
+        const size_t n = (size_t)num_offsets(mode) << (2 * masked_bits(mode));
+        const dim3 grid((unsigned)((n + 255) / 256));
+        if (mode == kDHGR)
+            hipLaunchKernelGGL(split_dw_check_kernel<kDHGR>, grid, dim3(256), 0, st, d_l, d_r, d_table, d_cnt);
+        else
+            hipLaunchKernelGGL(split_dw_check_kernel<kHGR>, grid, dim3(256), 0, st, d_l, d_r, d_table, d_cnt);
+        if ((rc = hip_check(hipGetLastError(), "split_dw_check_kernel launch"))) break;
+        if ((rc = hip_check(hipMemcpyAsync(mismatches, d_cnt, 8, hipMemcpyDeviceToHost, st), "copy count"))) break;
+        rc = hip_check(hipStreamSynchronize(st), "sync");
+    } while (0);
+    if (d_l) (void)hipFree(d_l);
+    if (d_r) (void)hipFree(d_r);
+    if (d_cnt) (void)hipFree(d_cnt);
+    return rc;
 }
 
 size_t split_entries(int mode, int right)

@@ -21,7 +21,7 @@ ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_ASSERT, ERR_OVERFLOW = -1, -2, -3, -4, 
 
 STATE_MEM_MAIN, STATE_MEM_AUX, STATE_UP_MAIN, STATE_UP_AUX = 0, 1, 2, 3
 STATE_RNG_PY, STATE_RNG_NP, STATE_OUT_OF_WORK, STATE_PACKED, STATE_COUNTERS = 4, 5, 6, 7, 8
-OPT_DIFF_WEIGHTS, DW_TABLE, DW_RECURRENCE = 1, 0, 1
+OPT_DIFF_WEIGHTS, DW_TABLE, DW_RECURRENCE, DW_SPLIT = 1, 0, 1, 2
 OPT_GREEDY_KERNEL, GREEDY_WAVE, GREEDY_WORKGROUP, GREEDY_AUTO, GREEDY_TEAM = 2, 0, 1, 2, 3
 OPT_PREFIX_SORT = 3
 OPT_GREEDY_LDS_PAD = 5
@@ -39,7 +39,7 @@ SYMBOLS = [
     "iiv_encoder_set_state_range", "iiv_encoder_get_video_state", "iiv_encoder_set_video_state",
     "iiv_encode", "iiv_encode_streams",
     "iiv_encoder_check", "iiv_encoder_profile", "iiv_encoder_profile_read",
-    "iiv_build_split_store_table", "iiv_split_table_entries",
+    "iiv_build_split_store_table", "iiv_split_table_entries", "iiv_check_split_diff_table",
     "iiv_emit_stream", "iiv_emit_chunk", "iiv_frames_to_memory_maps",
 ]
 
@@ -121,6 +121,7 @@ def lib():
     L.iiv_encode_streams.argtypes = [vp, vp, vp, i32, C.POINTER(Segment), C.POINTER(C.c_int32), vp, sz, vp]
     L.iiv_build_split_store_table.argtypes = [i32, vp, vp, vp, vp, vp]
     L.iiv_split_table_entries.restype = sz
+    L.iiv_check_split_diff_table.argtypes = [i32, vp, vp, vp, vp]
     L.iiv_split_table_entries.argtypes = [i32, i32]
     L.iiv_encoder_check.argtypes = [vp, C.POINTER(i32), vp]
     L.iiv_encoder_profile.argtypes = [vp, i32]
@@ -218,6 +219,16 @@ def build_store_table(mode, dm):
     out = torch.empty(L.iiv_store_table_entries(mode), dtype=torch.int16, device="cuda")
     check(L.iiv_build_store_table(mode, hptr(dm), dptr(out), stream_ptr()))
     return out
+
+
+def check_split_diff_table(mode, dm, table):
+    """Number of entries of the full symmetric table that differ from the combination of the
+    two halves of the split diff-weight table built from dm (0 = exact everywhere)."""
+    _torch()
+    dm = np.ascontiguousarray(dm, dtype=np.int32).reshape(256)
+    n = C.c_ulonglong(0)
+    check(lib().iiv_check_split_diff_table(mode, hptr(dm), dptr(table), C.byref(n), stream_ptr()))
+    return int(n.value)
 
 
 def build_split_store_table(mode, dm, expanded=True):
@@ -329,8 +340,13 @@ class Encoder:
     def set_greedy_lds_pad(self, n_bytes):
         check(lib().iiv_encoder_set_option(self._h, OPT_GREEDY_LDS_PAD, int(n_bytes)))
 
-    def set_diff_weights_mode(self, recurrence):
-        check(lib().iiv_encoder_set_option(self._h, OPT_DIFF_WEIGHTS, DW_RECURRENCE if recurrence else DW_TABLE))
+    def set_diff_weights_mode(self, mode):
+        """True / "recurrence" (default with dm): the edit-distance recurrence in the kernel;
+        "split": two gathers from the split diff-weight table; False / "table": one gather from
+        the full table."""
+        v = {"split": DW_SPLIT, "recurrence": DW_RECURRENCE, "table": DW_TABLE, True: DW_RECURRENCE,
+             False: DW_TABLE}[mode]
+        check(lib().iiv_encoder_set_option(self._h, OPT_DIFF_WEIGHTS, v))
 
     def close(self):
         if getattr(self, "_h", None):

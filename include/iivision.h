@@ -129,13 +129,25 @@ int iiv_build_split_store_table(int mode, const int32_t dm[256], uint32_t *d_lef
                                 uint16_t *d_expanded, void *stream);
 size_t iiv_split_table_entries(int mode, int right_half);
 
+/* Bitmap.diff_weights' table (screen.py:343-367, 436-443) cut the same way: a diff weight is
+ * min(l0 + r0, l1 + r1) of DWL[o][left row of source][left row of target] and
+ * DWR[o][right row of source][right row of target] (5 MiB DHGR / 4 MiB HGR instead of
+ * 512 MiB / 1 GiB).  iiv_check_split_diff_table builds the halves from dm and compares their
+ * combination with EVERY entry of d_table (iiv_build_table(..., symmetric = 1)); *mismatches
+ * receives the number of differing entries. */
+int iiv_check_split_diff_table(int mode, const int32_t dm[256], const uint16_t *d_table,
+                               unsigned long long *mismatches, void *stream);
+
 /* One encoder = n_streams independent Video objects of one (mode, palette),
  * all state resident in HBM.  d_table = full symmetric table (iiv_build_table),
  * d_store_table = iiv_build_store_table output; both must outlive the encoder.
  * dm = the 16x16 int CIE2000 matrix the tables were built from, or NULL.
  *   dm != NULL (default mode IIV_DW_RECURRENCE): Bitmap.diff_weights values are
- *     recomputed on the fly with the same recurrence that built the table
- *     (bit-identical, no HBM table traffic); d_table may then be NULL.  The split
+ *     recomputed on the fly with the same recurrence that built the table, or
+ *     (IIV_DW_SPLIT) combined from the two halves of a split diff-weight table built
+ *     from dm (two gathers per byte from 2.5-4 MiB: measured slower, 1.03 against
+ *     0.62 ms per 12288 streams, kept as a third independent way to the same values)
+ *     -- both bit-identical, no HBM table traffic; d_table may then be NULL.  The split
  *     store table of the one-wave greedy kernel is built from dm as well.
  *   dm == NULL (IIV_DW_TABLE): they are gathered from d_table (screen.py:436-443);
  *     only the workgroup greedy kernel (which reads d_store_table) is available.
@@ -151,6 +163,7 @@ void iiv_encoder_destroy(iiv_encoder *enc);
 #define IIV_OPT_DIFF_WEIGHTS 1 /* how the prologue obtains Bitmap.diff_weights */
 #define IIV_DW_TABLE 0         /*   gather from the precomputed table           */
 #define IIV_DW_RECURRENCE 1    /*   run the edit-distance recurrence            */
+#define IIV_DW_SPLIT 2         /*   combine the two halves of the split table   */
 #define IIV_OPT_GREEDY_KERNEL 2 /* shape of the greedy-selection kernel         */
 #define IIV_GREEDY_WAVE 0       /*   one 64-lane wave per stream, split store table */
 #define IIV_GREEDY_WORKGROUP 1  /*   one 256-thread workgroup per stream, dense store table */

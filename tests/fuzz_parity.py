@@ -47,7 +47,7 @@ for rnd in range(rounds):
             ia = int(rng.integers(0, 2)) if mode == 1 else 0
         sched.append((f, ia, restart, k))
     wave = (True, True, "team", "team", False)[int(rng.integers(0, 5))]
-    recurrence = bool(rng.random() < 0.8)
+    recurrence = ("split", "split", True, True, False)[int(rng.integers(0, 5))]
     prefix = bool(rng.random() < 0.7)
     enc = native.Encoder(mode, dtab[key][0], dtab[key][1], n, dm=dms[pal])
     enc.set_diff_weights_mode(recurrence)

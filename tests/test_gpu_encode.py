@@ -51,10 +51,11 @@ def _next_draws(O, words, n, high):
     return [f(C.byref(m)) for _ in range(n)]
 
 
-@pytest.mark.parametrize("recurrence,wave", [(True, True), (False, True), (True, False), (False, False), (True, "team")])
+@pytest.mark.parametrize("recurrence,wave", [(True, True), (False, True), (True, False), (False, False), (True, "team"),
+                                             ("split", True), ("split", "team"), ("split", False)])
 def test_golden_runs(native, O, golden, device_tables, recurrence, wave):
     """recurrence=True: diff weights recomputed in the prologue; False: gathered from
-    the HBM table.  wave=True: one wave per stream reading the split store table; False: one
+    the HBM table; "split": combined from the two halves of the split diff-weight table.  wave=True: one wave per stream reading the split store table; False: one
     256-thread workgroup per stream reading the dense u16 store table; "team": eight waves per
     stream scoring the next list entries concurrently.  Every combination must reproduce the
     reference bit for bit."""

@@ -107,6 +107,20 @@ def test_split_store_table_is_exact(native, device_tables, dms, mode, pal):
     assert set(np.unique(r & 0xffff)) - set(range(2048)) <= {0x3fff}
 
 
+@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("pal", [5, 0])
+def test_split_diff_weight_table_is_exact(native, device_tables, dms, mode, pal):
+    """The split diff-weight table of the prologue's IIV_DW_SPLIT mode (csrc/iiv_stream.h): the same
+    cut applied to Bitmap.diff_weights' table.  Combined with the prologue's own index
+    arithmetic it must equal the full symmetric table for EVERY (offset, source window,
+    target window): 2.7e8 (DHGR) / 5.4e8 (HGR) entries, compared on the device."""
+    table, _ = device_tables.get(mode, pal)
+    assert native.check_split_diff_table(mode, dms[pal], table) == 0
+    # and the check can fail: against another palette's table many entries differ
+    other, _ = device_tables.get(mode, 0 if pal == 5 else 5)
+    assert native.check_split_diff_table(mode, dms[pal], other) > 0
+
+
 def test_encoder_rejects_values_beyond_its_key_fields(native, device_tables):
     """diff weights and store values are packed into 11-bit fields; a diff matrix
     or a table that exceeds them must be refused at creation instead of reordering opcodes."""
