@@ -91,6 +91,9 @@ def parse_args(argv=None):
                     help="how the prologue obtains the diff weights (same values): the recurrence in the kernel, two "
                          "gathers from the split table, or one gather from the full table in HBM")
     ap.add_argument("--dw-table", action="store_true", help="same as --dw table")
+    ap.add_argument("--joint", action="store_true",
+                    help="SURVEY 8(f4): choose every step's content byte jointly with its extra offsets "
+                         "(IIV_CONTENT_JOINT; NOT the reference's output -- not the BASELINE workload)")
     ap.add_argument("--greedy", choices=["auto", "wave", "workgroup"], default="auto",
                     help="greedy kernel shape: one wave per stream, one 256-thread workgroup per stream, or auto")
     ap.add_argument("--full-sort", action="store_true", help="disable the prologue's prefix sort")
@@ -146,7 +149,7 @@ class GpuBackend:
 
     def make_batch(self, S, seeds):
         a = self.args
-        b = self.sb.StreamBatch(self.mode, self.table, self.store, S, seeds=seeds, dm=self.dm)
+        b = self.sb.StreamBatch(self.mode, self.table, self.store, S, seeds=seeds, dm=self.dm, joint_content=a.joint)
         b.enc.set_diff_weights_mode("table" if a.dw_table else a.dw)
         b.enc.set_greedy_kernel(None if a.greedy == "auto" else a.greedy == "wave")
         if a.full_sort:
@@ -178,7 +181,7 @@ class GpuBackend:
         return self.batch.enc.profile_read()
 
     def uses_wave_kernel(self):
-        return self.args.greedy != "workgroup"
+        return self.args.greedy != "workgroup" and not self.args.joint
 
 
 def main(argv=None, backend_cls=GpuBackend):
@@ -262,10 +265,11 @@ def main(argv=None, backend_cls=GpuBackend):
         "data": "synthetic",
         "config": {
             "workload": "%s %s palette %dx192 S-%s synthetic clips, %d frames each, %d independent clips per GPU, "
-                        "Movie.encode control flow (490 opcodes/frame%s)" % (
+                        "Movie.encode control flow (490 opcodes/frame%s)%s" % (
                             args.mode, "//gs RGB (IIGS)" if args.palette == "IIGS" else "NTSC", 560 if dhgr else 280,
                             "img" if args.img else "coh" if args.coherent else "iid",
-                            args.steps * F, S, ", bank flip per 2 KiB" if dhgr else ""),
+                            args.steps * F, S, ", bank flip per 2 KiB" if dhgr else "",
+                            "; JOINT content choice (f4, not the reference's output)" if args.joint else ""),
             "palette": args.palette,
             "streams_per_gpu": S,
             "frames_per_step": F,
@@ -365,7 +369,7 @@ def _single_stream(be, args):
     """One clip alone (a video is a sequential chain: latency-bound)."""
     import torch
     fm, fa = be.sb.synth_frames_torch(1, 60, be.dhgr, seed=99, coherent=args.coherent)
-    b = be.sb.StreamBatch(be.mode, be.table, be.store, 1, seeds=[(1, 1)], dm=be.dm)
+    b = be.sb.StreamBatch(be.mode, be.table, be.store, 1, seeds=[(1, 1)], dm=be.dm, joint_content=args.joint)
     b.enc.set_greedy_kernel(None if args.greedy == "auto" else args.greedy == "wave")
     b.encode_frames(fm, fa, 10)
     torch.cuda.synchronize()
@@ -475,6 +479,7 @@ def _cpu_baseline(be, seed, args, ops_check):
     _, dm = O.cie2000_matrix(O.PALETTE_RGB[PALETTE_IDS[args.palette]])
     tab = O.build_table(be.mode, dm, symmetric=True)   # untimed, like the GPU's table build
     v = O.Video(be.mode, tab, seed_py=seed[0], seed_np=seed[1])
+    v.set_joint(args.joint)
     segs = stream_batch.MovieClock(be.dhgr).segments(n)
     t0 = time.perf_counter()
     got = []
@@ -517,6 +522,8 @@ def _cpu_baseline_all_cores(be, seeds, args):
     tab = O.build_table(be.mode, dm, symmetric=True)
     segs = stream_batch.MovieClock(be.dhgr).segments(n)
     vids = [O.Video(be.mode, tab, seed_py=seeds[i][0], seed_np=seeds[i][1]) for i in range(threads)]
+    for v in vids:
+        v.set_joint(args.joint)
 
     def work(i):
         v = vids[i]

@@ -33,6 +33,8 @@ int build_strings(int mode, const int32_t dm[256], ulonglong2 **d_strings, uint1
 size_t split_entries(int mode, int right);
 int build_split_tables(int mode, const ulonglong2 *d_strings, const uint16_t *d_sub, uint32_t *d_left, uint32_t *d_right,
                        hipStream_t st);
+int transpose_split_tables(int mode, const uint32_t *d_left, const uint32_t *d_right, uint32_t *d_left_t,
+                           uint32_t *d_right_t, hipStream_t st);
 size_t split_dw_entries(int mode, int right);
 int build_split_dw_tables(int mode, const ulonglong2 *d_strings, const uint16_t *d_sub, uint32_t *d_left, uint32_t *d_right,
                           hipStream_t st);

@@ -300,6 +300,39 @@ __global__ __launch_bounds__(256) void split_kernel(const ulonglong2 *__restrict
     }
 }
 
+// The halves with content innermost -- T[o][row][content part] -- for the joint content choice
+// (iiv_encode.hip, greedy_kernel<MODE, true>): one row's values for every byte value are one or
+// two cache lines.
+template <int MODE>
+__global__ __launch_bounds__(256) void split_transpose_kernel(const uint32_t *__restrict__ left,
+                                                              const uint32_t *__restrict__ right,
+                                                              uint32_t *__restrict__ left_t, uint32_t *__restrict__ right_t)
+{
+    using T = SplitTraits<MODE>;
+    const size_t nl = split_left_entries<MODE>(), nr = split_right_entries<MODE>();
+    size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool is_left = idx < nl;
+    if (!is_left) idx -= nl;
+    if (!is_left && idx >= nr) return;
+    const int rb = is_left ? T::kLeftRowBits : T::kRightRowBits, cb = is_left ? T::kLeftCBits : T::kRightCBits;
+    const uint32_t row = idx & ((1u << rb) - 1), cpart = (idx >> rb) & ((1u << cb) - 1);
+    const size_t o = idx >> (rb + cb);
+    (is_left ? left_t : right_t)[(((o << rb) + row) << cb) + cpart] = (is_left ? left : right)[idx];
+}
+
+int transpose_split_tables(int mode, const uint32_t *d_left, const uint32_t *d_right, uint32_t *d_left_t,
+                           uint32_t *d_right_t, hipStream_t st)
+{
+    const size_t n = mode == kDHGR ? split_left_entries<kDHGR>() + split_right_entries<kDHGR>()
+                                   : split_left_entries<kHGR>() + split_right_entries<kHGR>();
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (mode == kDHGR)
+        hipLaunchKernelGGL(split_transpose_kernel<kDHGR>, grid, dim3(256), 0, st, d_left, d_right, d_left_t, d_right_t);
+    else
+        hipLaunchKernelGGL(split_transpose_kernel<kHGR>, grid, dim3(256), 0, st, d_left, d_right, d_left_t, d_right_t);
+    return hip_check(hipGetLastError(), "split_transpose_kernel launch");
+}
+
 // The halves of the diff-weight table (iiv_stream.h): the same recurrence between two arbitrary
 // windows, each built from its row part alone.
 template <int MODE>

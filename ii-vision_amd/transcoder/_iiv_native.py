@@ -25,6 +25,7 @@ OPT_DIFF_WEIGHTS, DW_TABLE, DW_RECURRENCE, DW_SPLIT = 1, 0, 1, 2
 OPT_GREEDY_KERNEL, GREEDY_WAVE, GREEDY_WORKGROUP, GREEDY_AUTO, GREEDY_TEAM = 2, 0, 1, 2, 3
 OPT_PREFIX_SORT = 3
 OPT_GREEDY_LDS_PAD = 5
+OPT_CONTENT_CHOICE, CONTENT_TARGET, CONTENT_JOINT = 6, 0, 1
 
 # every symbol include/iivision.h declares
 SYMBOLS = [
@@ -339,6 +340,12 @@ class Encoder:
 
     def set_greedy_lds_pad(self, n_bytes):
         check(lib().iiv_encoder_set_option(self._h, OPT_GREEDY_LDS_PAD, int(n_bytes)))
+
+    def set_content_choice(self, joint):
+        """False (default): the reference's greedy step.  True: the content byte of every step is
+        chosen jointly with its extra offsets (include/iivision.h: IIV_CONTENT_JOINT) -- the
+        reference README's "global optimization" idea, NOT the reference's output."""
+        check(lib().iiv_encoder_set_option(self._h, OPT_CONTENT_CHOICE, CONTENT_JOINT if joint else CONTENT_TARGET))
 
     def set_diff_weights_mode(self, mode):
         """True / "recurrence" (default with dm): the edit-distance recurrence in the kernel;

@@ -187,10 +187,15 @@ def synth_frames_img(n_streams, n_frames, dhgr, seed, device="cuda"):
 class StreamBatch:
     """S independent video.Video encoders advanced in lock step on one GPU."""
 
-    def __init__(self, mode, table, store_table, n_streams, seeds=None, dm=None, **clock_kw):
+    def __init__(self, mode, table, store_table, n_streams, seeds=None, dm=None, joint_content=False, **clock_kw):
+        """joint_content=True: the content byte of every step is chosen jointly with its extra
+        offsets (reference README.md:212-215, include/iivision.h IIV_CONTENT_JOINT) -- better
+        pictures per opcode, NOT the reference's opcode stream."""
         self.mode = mode
         self.n_streams = int(n_streams)
         self.enc = native.Encoder(mode, table, store_table, self.n_streams, dm=dm)
+        if joint_content:
+            self.enc.set_content_choice(True)
         self.clock = MovieClock(mode == native.DHGR, **clock_kw)
         if seeds is not None:
             self.seed(seeds)

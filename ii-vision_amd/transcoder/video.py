@@ -64,8 +64,13 @@ class Video:
             frame_grabber,
             ticks_per_second: float,
             mode: VideoMode = VideoMode.HGR,
-            palette: Palette = Palette.NTSC
+            palette: Palette = Palette.NTSC,
+            joint_content: bool = False
     ):
+        """joint_content (not in the reference's signature, default off): choose every opcode's
+        content byte jointly with its extra offsets -- the "global optimization" of the reference's
+        README.md:212-215 (include/iivision.h: IIV_CONTENT_JOINT).  Less error per opcode, NOT the
+        reference's opcode stream."""
         self.mode = mode  # type: VideoMode
         self.frame_grabber = frame_grabber
         self.ticks_per_second = float(ticks_per_second)  # type: float
@@ -100,6 +105,8 @@ class Video:
         tables = self._pixelmap.edit_distances(palette)
         self._mode_id = native.DHGR if mode == VideoMode.DHGR else native.HGR
         self._enc = native.Encoder(self._mode_id, tables.table, tables.store, n_streams=1, dm=tables.dm)
+        if joint_content:
+            self._enc.set_content_choice(True)
         self._live = None  # the generator whose state the device currently holds
         self._vs = native.VideoState()   # one staging buffer for every state round trip
         self._dev_main = self._dev_aux = None   # the live generator's target on the device

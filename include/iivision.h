@@ -178,6 +178,19 @@ void iiv_encoder_destroy(iiv_encoder *enc);
                                   * (default 0), which caps how many streams are resident per CU:
                                   * a batch whose size is a whole multiple of the resident streams
                                   * finishes its launches without a half-empty last round */
+#define IIV_OPT_CONTENT_CHOICE 6 /* which byte value a greedy step stores */
+#define IIV_CONTENT_TARGET 0     /*   default, the reference: the primary location's target byte (video.py:134) */
+#define IIV_CONTENT_JOINT 1      /*   NOT reference behaviour -- the "global optimization" the reference's
+                                  *   README.md:212-215 leaves as future work: the value c maximising
+                                  *     R(c) = (dw[primary] - nd_c[primary]) - (d1 + d2),
+                                  *   nd_c[y] = error of byte y of the page once it holds c, d1/d2 = the two
+                                  *   smallest negative nd_c[y] - dw[y] over the page's other bytes with non-zero
+                                  *   priority (what _compute_error would hand out); ties: the target byte, then
+                                  *   the smallest c.  update_priority[primary] becomes nd_c[primary] instead of 0
+                                  *   (video.py:140); everything else is the reference's step applied to c.
+                                  *   R(target byte) is what the reference's step removes, so a joint step never
+                                  *   removes less.  128 / 256 times the lookups of a reference step; runs in the
+                                  *   workgroup greedy kernel whatever IIV_OPT_GREEDY_KERNEL says. */
 int iiv_encoder_set_option(iiv_encoder *enc, int option, int value);
 
 /* state items, per stream */

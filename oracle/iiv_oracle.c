@@ -12,6 +12,7 @@
 #include "iiv_oracle.h"
 
 #include <math.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -696,6 +697,7 @@ struct orc_video {
     int out_of_work[2];      /* video.py:62 */
     orc_mt rng_py, rng_np;
     uint64_t draws_py, draws_np;
+    int joint;               /* f4: joint choice of the content byte (not the reference's behaviour) */
     /* generator */
     int gen_active, gen_started, gen_is_aux, gen_exhausted, gen_form;
     uint8_t tgt[2][8192];
@@ -736,6 +738,7 @@ void orc_video_destroy(orc_video *v)
     free(v);
 }
 
+void orc_video_set_joint(orc_video *v, int joint) { v->joint = joint ? 1 : 0; }
 orc_mt *orc_video_rng_py(orc_video *v) { return &v->rng_py; }
 orc_mt *orc_video_rng_np(orc_video *v) { return &v->rng_np; }
 uint8_t *orc_video_memory(orc_video *v, int is_aux) { return v->mem[is_aux ? 1 : 0]; }
@@ -907,6 +910,65 @@ static void emit_pad(orc_video *v, uint8_t *out)
     out[2] = out[3] = out[4] = out[5] = 0;
 }
 
+/* f4 -- README.md:212-215 ("Global optimization": "the best value to store to minimize the total
+ * error of 4 offsets may not even be any one of those target content bytes").  NOT reference
+ * behaviour: the reference has no such mode, so this is the definition the kernels are tested
+ * against, not a restatement.  With the flag set a step differs from video.py:121-187 in two
+ * places only:
+ *   :134  content = the byte value c that maximises
+ *             R(c) = (dw[primary] - nd_c[primary]) - (d1 + d2),
+ *         nd_c[y] = error of byte y after storing c (compute_delta_page's new_diff),
+ *         d1, d2 = the two smallest negative deltas nd_c[y] - dw[y] over the other bytes of the page
+ *         whose priority is non-zero (exactly the offsets _compute_error would hand out; 0 if absent);
+ *         ties: the primary's target byte first, then the smallest c.  R(target byte) is what
+ *         the reference's step removes, so a joint step never removes less.
+ *   :140  update_priority[page, offset] = nd_c[primary], the error the chosen byte leaves
+ *         (0 when c is the target byte); it is not re-queued -- the next generator sees it.
+ * Everything else (candidate order, nonce draws, re-queueing of the extra offsets) is the
+ * reference's, applied to the chosen byte. */
+static uint8_t choose_content_joint(orc_video *v, int page, int offset, int ia, int32_t *residual)
+{
+    const int bits = orc_masked_bits(v->mode);
+    const int32_t *up = v->up[ia];
+    const int ncontent = v->mode == ORC_DHGR ? 128 : 256;
+    const uint8_t tc = v->tgt[ia][page * 256 + offset];
+    const uint64_t *row = v->tgt_packed + page * 128;
+    int64_t best_key = INT64_MIN;
+    int best_c = tc;
+    int32_t best_res = 0;
+    for (int c = 0; c < ncontent; c++) {
+        int32_t m1 = 0, m2 = 0, nd_primary = 0; /* m1 <= m2 <= 0: the two smallest negative deltas */
+        for (int y = 0; y < 256; y++) {
+            int bo = orc_byte_offset(v->mode, y, ia);
+            uint64_t t = orc_mask_and_shift(v->mode, row[y / 2], bo);
+            uint64_t s = orc_mask_and_shift(v->mode, orc_masked_update(v->mode, bo, row[y / 2], (uint8_t)c), bo);
+            int32_t nd = v->table[((size_t)bo << (2 * bits)) + ((s << bits) + t)];
+            if (y == offset) {
+                nd_primary = nd;
+                continue;
+            }
+            int32_t d = nd - v->dw[page * 256 + y];
+            if (d >= 0 || up[page * 256 + y] == 0)
+                continue;
+            if (d < m1) {
+                m2 = m1;
+                m1 = d;
+            } else if (d < m2) {
+                m2 = d;
+            }
+        }
+        int64_t r = (int64_t)v->dw[page * 256 + offset] - nd_primary - m1 - m2;
+        int64_t key = r * 512 + (c == tc ? 256 : 0) + (255 - c);
+        if (key > best_key) {
+            best_key = key;
+            best_c = c;
+            best_res = nd_primary;
+        }
+    }
+    *residual = best_res;
+    return (uint8_t)best_c;
+}
+
 /* One greedy step, heap form: follows video.py:121-187 and :275-301 literally. */
 static int step_heap(orc_video *v, uint8_t *out)
 {
@@ -926,8 +988,11 @@ static int step_heap(orc_video *v, uint8_t *out)
         uint8_t content = target[page * 256 + offset]; /* :134 */
         if (v->mode == ORC_DHGR && content >= 0x80)
             return -4; /* :137 */
-        up[page * 256 + offset] = 0;    /* :140 */
-        v->dw[page * 256 + offset] = 0; /* :141 */
+        int32_t residual = 0;
+        if (v->joint)
+            content = choose_content_joint(v, page, offset, ia, &residual);
+        up[page * 256 + offset] = residual; /* :140 (0 unless joint) */
+        v->dw[page * 256 + offset] = 0;     /* :141 */
         orc_apply(v->mode, v->packed, v->mem[0], v->mem[1], page, offset, ia, content); /* :144 */
 
         /* _compute_error (:275-301) */
@@ -1023,7 +1088,10 @@ static int step_struct(orc_video *v, uint8_t *out)
         uint8_t content = target[page * 256 + offset];
         if (v->mode == ORC_DHGR && content >= 0x80)
             return -4;
-        up[page * 256 + offset] = 0;
+        int32_t residual = 0;
+        if (v->joint)
+            content = choose_content_joint(v, page, offset, ia, &residual);
+        up[page * 256 + offset] = residual;
         v->dw[page * 256 + offset] = 0;
         orc_apply(v->mode, v->packed, v->mem[0], v->mem[1], page, offset, ia, content);
 
