@@ -77,6 +77,6 @@ for rnd in range(rounds):
         assert (int(cnt[0]), int(cnt[1])) == v.draws(), ("draws", rnd, i)
         total_ops += exp.shape[0]
     enc.close()
-    print("round %2d ok: mode=%s pal=%d %s wave=%s rec=%d prefix=%d segs=%s" % (
+    print("round %2d ok: mode=%s pal=%d %s wave=%s rec=%s prefix=%d segs=%s" % (
         rnd, "DHGR" if mode else "HGR", pal, kind, wave, recurrence, prefix, [s[3] for s in sched]), flush=True)
 print("fuzz parity: %d rounds, %d opcodes compared, all equal (%.0f s)" % (rounds, total_ops, time.time() - t_start))
