@@ -38,6 +38,7 @@ SYMBOLS = [
     "iiv_encoder_create", "iiv_encoder_destroy", "iiv_encoder_set_option",
     "iiv_encoder_snapshot", "iiv_encoder_rollback", "iiv_encoder_get_state", "iiv_encoder_set_state",
     "iiv_encoder_set_state_range", "iiv_encoder_get_video_state", "iiv_encoder_set_video_state",
+    "iiv_encoder_get_video_brief",
     "iiv_encode", "iiv_encode_streams",
     "iiv_encoder_check", "iiv_encoder_profile", "iiv_encoder_profile_read",
     "iiv_build_split_store_table", "iiv_split_table_entries", "iiv_check_split_diff_table",
@@ -58,6 +59,12 @@ class VideoState(C.Structure):
 
     def array(self, name, dtype, shape):
         return np.frombuffer(getattr(self, name), dtype=dtype).reshape(shape)
+
+
+class VideoBrief(C.Structure):
+    """include/iivision.h: iiv_video_brief"""
+    _fields_ = [("priority_sum", C.c_int64 * 2), ("hole_bytes", C.c_int32 * 2), ("out_of_work", C.c_int32 * 2),
+                ("rng_py", C.c_uint32 * 625), ("rng_np", C.c_uint32 * 625)]
 
 
 class IIVError(RuntimeError):
@@ -117,6 +124,7 @@ def lib():
     L.iiv_encoder_set_state.argtypes = [vp, i32, i32, vp, sz]
     L.iiv_encoder_set_state_range.argtypes = [vp, i32, i32, i32, vp, sz]
     L.iiv_encoder_get_video_state.argtypes = [vp, i32, C.POINTER(VideoState)]
+    L.iiv_encoder_get_video_brief.argtypes = [vp, i32, C.POINTER(VideoBrief)]
     L.iiv_encoder_set_video_state.argtypes = [vp, i32, C.POINTER(VideoState)]
     L.iiv_encode.argtypes = [vp, vp, vp, i32, C.POINTER(Segment), i32, vp, vp]
     L.iiv_encode_streams.argtypes = [vp, vp, vp, i32, C.POINTER(Segment), C.POINTER(C.c_int32), vp, sz, vp]
@@ -147,16 +155,27 @@ def check(rc):
     raise IIVError(rc, msg)
 
 
+_torch_mod = None
+
+
 def _torch():
+    global _torch_mod
+    if _torch_mod is not None:   # (availability was established once; the check costs microseconds per call)
+        return _torch_mod
     import torch
     if not torch.cuda.is_available():
         raise RuntimeError("libiivision needs an AMD GPU (torch.cuda.is_available() is False); "
                            "there is no CPU fallback")
+    _torch_mod = torch
     return torch
 
 
 def stream_ptr():
+    """torch's current stream on the current device, as a raw hipStream_t"""
     torch = _torch()
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is not None:   # the same value as current_stream().cuda_stream without building a Stream object
+        return C.c_void_p(raw(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -391,6 +410,11 @@ class Encoder:
     def get_video_state(self, stream=0, out=None):
         out = out if out is not None else VideoState()
         check(lib().iiv_encoder_get_video_state(self._h, int(stream), C.byref(out)))
+        return out
+
+    def get_video_brief(self, stream=0, out=None):
+        out = out if out is not None else VideoBrief()
+        check(lib().iiv_encoder_get_video_brief(self._h, int(stream), C.byref(out)))
         return out
 
     def set_video_state(self, state, stream=0):

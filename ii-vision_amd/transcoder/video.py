@@ -11,9 +11,11 @@ of csrc/iiv_encode.hip through iiv_encode() (include/iivision.h).
 State model: the device holds the live state while a generator runs; the host numpy
 arrays (memory maps, update priorities, pixelmap.packed, out_of_work) and Python's /
 NumPy's global RNG states are brought up to date *when somebody looks*: reading any of
-the state attributes, starting another generator (its prologue uploads the host state,
-so code that pokes `video.memory_map.page_offset` or reseeds `random` between frames
-keeps working) -- the same points at which the reference's caller (movie.py) looks.
+the state attributes brings everything; starting another generator brings the RNG positions
+and out_of_work (5 KB), and carries to the device whatever the caller changed in between --
+arrays it was handed, a reseeded or advanced `random` / `np.random` -- so code that pokes
+`video.memory_map.page_offset` or reseeds `random` between frames keeps working: the same
+points at which the reference's caller (movie.py) looks.
 `Video.STRICT_SYNC = True` restores the literal behaviour (every next() round-trips the
 whole state, global RNG states included), at about 1.5 k opcodes per second.
 
@@ -21,7 +23,7 @@ Budget: a generator may be abandoned after any next() (movie.py:94-109 does so a
 every frame and bank flip), and its side effects must then be exactly those of
 the opcodes consumed.  Without a hint every next() is therefore one device step.
 `encode_frame(target, is_aux, budget=K)` promises that K opcodes will be pulled;
-they are then computed by one launch.  `Video.SPECULATE = N` (default 64; 0 = one device
+they are then computed by one launch.  `Video.SPECULATE = N` (default 256; 0 = one device
 step per next()) gets batched launches without a promise: N opcodes are produced from a
 device-side snapshot and rolled back + replayed if fewer were consumed.  Batched, many-stream encoding
 (what bench.py measures) goes through stream_batch.StreamBatch instead.
@@ -51,12 +53,14 @@ class Video:
     #: opcodes.  Nothing observable depends on it (an assertion of the reference that would
     #: fire inside the unconsumed part of a chunk makes the generator fall back to exact
     #: stepping), only the speed does.
-    SPECULATE = 64
+    SPECULATE = 256
 
     #: True: after every next() the host arrays and the *global* random / np.random states
     #: are those of the reference at that point (one full state round trip per opcode).
-    #: False (default): they are synchronised whenever a state attribute is read or another
-    #: generator starts.
+    #: False (default): the arrays are synchronised whenever a state attribute is read, the global
+    #: RNG positions and out_of_work also whenever another generator starts (a 5 KB round trip:
+    #: iiv_encoder_get_video_brief); draws from / reseeds of random or np.random between two
+    #: generators are noticed and carried to the device.
     STRICT_SYNC = False
 
     def __init__(
@@ -109,6 +113,9 @@ class Video:
             self._enc.set_content_choice(True)
         self._live = None  # the generator whose state the device currently holds
         self._vs = native.VideoState()   # one staging buffer for every state round trip
+        self._vb = native.VideoBrief()
+        self._rng_seen = None  # the global (random, np.random) states as this object last left or read them
+        self._brief_fresh = False  # self._vb describes the device state as it stands
         self._dev_main = self._dev_aux = None   # the live generator's target on the device
 
     # ---- the reference's public attributes; reading one settles any speculation first
@@ -127,7 +134,21 @@ class Video:
     memory_map = _settled("_memory_map")
     pixelmap = _settled("_pixelmap")
     update_priority = _settled("_update_priority")
-    out_of_work = _settled("_out_of_work")
+
+    @property
+    def out_of_work(self):
+        self._settle()
+        self._touched = True
+        return self._out_of_work
+
+    @out_of_work.setter
+    def out_of_work(self, value):
+        # movie.py:96 assigns a fresh dict at every frame: only the two flags travel, not the whole state
+        self._settle(download=False)
+        self._out_of_work = value
+        if not self._touched:  # the device's copy is the one the next launch reads
+            self._enc.set_state(native.STATE_OUT_OF_WORK, np.array([int(bool(value[False])), int(bool(value[True]))], np.int32))
+            self._brief_fresh = False
 
     @property
     def aux_memory_map(self):
@@ -165,16 +186,19 @@ class Video:
         if dhgr:
             st.array("mem_aux", np.uint8, (32, 256))[...] = self._aux_memory_map.page_offset
             st.array("up_aux", np.int32, (32, 256))[...] = self._aux_update_priority
-        st.array("rng_py", np.uint32, (625,))[...] = random.getstate()[1]
+        py = random.getstate()[1]
+        st.array("rng_py", np.uint32, (625,))[...] = py
         nps = np.random.get_state()
         rn = st.array("rng_np", np.uint32, (625,))
         rn[:624] = nps[1]
         rn[624] = nps[2]
+        self._rng_seen = (py, nps[1].tobytes(), int(nps[2]))
         # movie.py:96 resets the flags at every frame
         st.out_of_work[0] = int(bool(self._out_of_work[False]))
         st.out_of_work[1] = int(bool(self._out_of_work[True]))
         self._enc.set_video_state(st)
         self._touched = False
+        self._brief_fresh = False
 
     def _download(self):
         """Device state -> host, one call; in place: callers (and self.pixelmap) hold references to the arrays."""
@@ -185,23 +209,65 @@ class Video:
             self._aux_memory_map.page_offset[...] = st.array("mem_aux", np.uint8, (32, 256))
             self._aux_update_priority[...] = st.array("up_aux", np.int32, (32, 256))
         self._pixelmap.packed[...] = st.array("packed", np.uint64, (32, 128))
-        random.setstate((3, tuple(st.rng_py), None))
-        npw = st.array("rng_np", np.uint32, (625,))
-        nps = np.random.get_state()
-        np.random.set_state((nps[0], npw[:624].copy(), int(npw[624]), nps[3], nps[4]))
+        self._set_global_rng(st)
         self._out_of_work[False] = bool(st.out_of_work[0])  # video.py:189
         self._out_of_work[True] = bool(st.out_of_work[1])
         self._host_current = True
 
+    def _set_global_rng(self, st):
+        """the device's random / np.random positions (st.rng_py, st.rng_np) become the process's"""
+        py = tuple(st.rng_py)
+        random.setstate((3, py, None))
+        npw = np.frombuffer(st.rng_np, dtype=np.uint32)
+        nps = np.random.get_state()
+        key = npw[:624].copy()
+        np.random.set_state((nps[0], key, int(npw[624]), nps[3], nps[4]))
+        self._rng_seen = (py, key.tobytes(), int(npw[624]))
+
+    def _global_rng_moved(self):
+        """did anyone draw from / reseed random or np.random since this object last synchronised them?"""
+        if self._rng_seen is None:
+            return True
+        nps = np.random.get_state()
+        return (random.getstate()[1], nps[1].tobytes(), int(nps[2])) != self._rng_seen
+
+    def _upload_rng(self):
+        py = np.array(random.getstate()[1], dtype=np.uint32)
+        nps = np.random.get_state()
+        rn = np.empty(625, dtype=np.uint32)
+        rn[:624] = nps[1]
+        rn[624] = nps[2]
+        self._enc.set_state(native.STATE_RNG_PY, py)
+        self._enc.set_state(native.STATE_RNG_NP, rn)
+        self._brief_fresh = False
+        self._rng_seen = (tuple(int(x) for x in py), nps[1].tobytes(), int(nps[2]))
+
+    def _sync_brief(self):
+        """Settle the device state and bring home the small things: global RNG positions, out_of_work
+        (and the numbers encode_frame prints / asserts).  The arrays stay on the device."""
+        self._settle(download=False)
+        if self._host_current:
+            return None  # nothing on the device is newer than what the host holds
+        if self._brief_fresh:
+            return self._vb
+        b = self._enc.get_video_brief(out=self._vb)
+        if not self._global_rng_moved():  # (else the caller's draws / reseed win: uploaded at the next launch)
+            self._set_global_rng(b)
+        self._out_of_work[False] = bool(b.out_of_work[0])
+        self._out_of_work[True] = bool(b.out_of_work[1])
+        self._brief_fresh = True
+        return b
+
     def _launch(self, token, restart, n_ops):
         """[prologue +] n_ops greedy steps on the device state as it stands."""
+        self._brief_fresh = False
         ops = self._enc.encode(token.fm, token.fa, [(0, int(bool(token.is_aux)), int(restart), int(n_ops))])
         self._enc.check()
         self._host_current = False
         return ops[0].cpu().numpy()
 
-    def _settle(self):
-        """Make host state reflect exactly the opcodes consumed so far."""
+    def _settle(self, download=True):
+        """Make the device state -- and, with download, the host's -- reflect exactly the opcodes consumed so far."""
         p = self._pending
         self._pending = None
         if p is not None and p["consumed"] < p["produced"]:
@@ -213,7 +279,7 @@ class Video:
             elif p["restart"]:
                 self._live = p["prev_live"]  # the prologue never happened
                 p["token"].started = False
-        if not self._host_current:
+        if download and not self._host_current:
             self._download()
 
     # ------------------------------------------------------------------ encode
@@ -229,13 +295,23 @@ class Video:
         Lazy generator, as in the reference (video.py:72-93): nothing happens until
         the first next(); it never terminates (pads forever once out of work).
         """
-        memory_map = self.aux_memory_map if is_aux else self.memory_map
-        update_priority = self.aux_update_priority if is_aux else self.update_priority
+        if is_aux and self._aux_memory_map is None:
+            raise AttributeError("aux_memory_map")  # as the reference's HGR Video (video.py:79-80)
+        self._settle(download=False)
+        if self._host_current:
+            memory_map = self._aux_memory_map if is_aux else self._memory_map
+            update_priority = self._aux_update_priority if is_aux else self._update_priority
+            # Make sure nothing is leaking into screen holes (video.py:87)
+            assert np.count_nonzero(memory_map.page_offset[screen.SCREEN_HOLES]) == 0
+            similarity = update_priority.mean()
+        else:
+            # the state lives on the device: fetch what these lines look at (and what the caller could
+            # observe between two generators: the global RNG positions, out_of_work) -- 5 KB, not 300
+            b = self._sync_brief()
+            assert b.hole_bytes[1 if is_aux else 0] == 0
+            similarity = b.priority_sum[1 if is_aux else 0] / 8192.0  # == update_priority.mean(), exactly
 
-        # Make sure nothing is leaking into screen holes (video.py:87)
-        assert np.count_nonzero(memory_map.page_offset[screen.SCREEN_HOLES]) == 0
-
-        print("Similarity %f" % (update_priority.mean()))
+        print("Similarity %f" % similarity)
 
         yield from self._index_changes(target, is_aux, budget)
 
@@ -259,51 +335,66 @@ class Video:
         token.fm, token.fa = self._dev_main, self._dev_aux
         chunk = int(budget) if budget else 1 if self.STRICT_SYNC else max(1, int(self.SPECULATE))
         speculative = not budget and chunk > 1
-        while True:
-            restart = 0 if self._live is token else 1
-            if restart and token.started:
-                raise RuntimeError("this encode_frame() generator cannot be resumed: another generator "
-                                   "has run on this Video since (the reference's heap is not kept)")
-            prev_live = self._live
-            if restart or self._pending is not None:
-                self._settle()  # the previous generator's speculation ends here
-            if restart or self._touched or self.STRICT_SYNC:
-                self._settle()
-                self._upload()
-            if restart:
-                self._dev_main.copy_(torch.from_numpy(token.main))
-                if token.aux is not None:
-                    self._dev_aux.copy_(torch.from_numpy(token.aux))
-            if speculative:
-                self._enc.snapshot()
-                try:
+        try:
+            while True:
+                restart = 0 if self._live is token else 1
+                if restart and token.started:
+                    raise RuntimeError("this encode_frame() generator cannot be resumed: another generator "
+                                       "has run on this Video since (the reference's heap is not kept)")
+                prev_live = self._live
+                if restart or self._pending is not None:
+                    self._settle(download=False)  # the previous generator's speculation ends here
+                if self._touched or self.STRICT_SYNC:
+                    self._settle()
+                    self._upload()
+                elif restart and self._global_rng_moved():
+                    self._upload_rng()  # someone drew from / reseeded random or np.random in between
+                if restart:
+                    self._dev_main.copy_(torch.from_numpy(token.main))
+                    if token.aux is not None:
+                        self._dev_aux.copy_(torch.from_numpy(token.aux))
+                if speculative:
+                    self._enc.snapshot()
+                    try:
+                        ops = self._launch(token, restart, chunk)
+                    except native.IIVAssertionError:
+                        # one of the reference's asserts fires somewhere in this chunk -- maybe past
+                        # what the caller will pull: step exactly from here on, so that it is raised
+                        # by the next() that would raise it in the reference
+                        self._enc.rollback()
+                        self._host_current = False
+                        speculative, chunk = False, 1
+                        continue
+                else:
                     ops = self._launch(token, restart, chunk)
-                except native.IIVAssertionError:
-                    # one of the reference's asserts fires somewhere in this chunk -- maybe past
-                    # what the caller will pull: step exactly from here on, so that it is raised
-                    # by the next() that would raise it in the reference
-                    self._enc.rollback()
-                    self._host_current = False
-                    speculative, chunk = False, 1
-                    continue
-            else:
-                ops = self._launch(token, restart, chunk)
-            self._live = token
-            token.started = True
-            if self.STRICT_SYNC:
-                self._download()
-            rec = None
-            if speculative:
-                rec = dict(token=token, restart=restart, consumed=0, produced=len(ops), prev_live=prev_live)
-                self._pending = rec
-            for k in range(len(ops)):
-                if rec is not None:
-                    rec["consumed"] = k + 1
-                yield int(ops[k, 0]), int(ops[k, 1]), [int(o) for o in ops[k, 2:6]]
-                if rec is not None and self._pending is not rec:
-                    break  # settled underneath us: the rest of this chunk was rolled back
-            else:
-                if rec is not None and self._pending is rec:
-                    self._pending = None
-            if not speculative:
-                chunk = 1
+                self._live = token
+                token.started = True
+                if self.STRICT_SYNC:
+                    self._download()
+                rec = None
+                if speculative:
+                    rec = dict(token=token, restart=restart, consumed=0, produced=len(ops), prev_live=prev_live)
+                    self._pending = rec
+                rows = ops.tolist()  # plain ints, converted once per chunk
+                for k in range(len(rows)):
+                    if rec is not None:
+                        rec["consumed"] = k + 1
+                    row = rows[k]
+                    yield row[0], row[1], row[2:6]
+                    if rec is not None and self._pending is not rec:
+                        break  # settled underneath us: the rest of this chunk was rolled back
+                else:
+                    if rec is not None and self._pending is rec:
+                        self._pending = None
+                if not speculative:
+                    chunk = 1
+        except GeneratorExit:
+            # abandoned (movie.py:94-101 rebinds op_seq: CPython finalises the old generator right there):
+            # undo what was speculated beyond the consumed opcodes and bring the global RNG positions
+            # home now, so that draws made before the next generator starts continue the right stream
+            if self._live is token:
+                try:
+                    self._sync_brief()
+                except Exception:
+                    pass  # (interpreter shutdown, closed encoder: nothing left to keep consistent)
+            raise

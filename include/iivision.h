@@ -222,6 +222,18 @@ typedef struct {
 int iiv_encoder_get_video_state(iiv_encoder *enc, int stream_index, iiv_video_state *host_out);
 int iiv_encoder_set_video_state(iiv_encoder *enc, int stream_index, const iiv_video_state *host_in);
 
+/* What video.py looks at when a generator starts (video.py:86-91: the screen-hole assert, the
+ * "Similarity" print = update_priority.mean()) plus what the caller can observe between two
+ * generators without touching the Video (the global random / np.random states, out_of_work): 5 KB
+ * in one round trip instead of the 300 KB of iiv_encoder_get_video_state. */
+typedef struct iiv_video_brief {
+    int64_t priority_sum[2];   /* sum of update_priority, aux_update_priority            */
+    int32_t hole_bytes[2];     /* non-zero bytes inside the screen holes, main / aux map */
+    int32_t out_of_work[2];
+    uint32_t rng_py[625], rng_np[625];
+} iiv_video_brief;
+int iiv_encoder_get_video_brief(iiv_encoder *enc, int stream_index, iiv_video_brief *host_out);
+
 /* Copy / restore the complete state of every stream (screen, priorities, live
  * generator, both RNG streams) on the device.  A caller that must not run ahead of
  * its consumer (a lazy generator, video.py:72-93) can snapshot, produce N opcodes in

@@ -250,3 +250,47 @@ def test_speculation_raises_where_the_reference_would():
     assert raised and 0 < len(exact) < 8000
     spec, raised_spec = run(64)
     assert raised_spec and spec == exact
+
+
+def test_reseeding_between_generators_is_carried_to_the_device(O, oracle_tables):
+    """Between two generators the caller may reseed (or draw from) the global random / np.random
+    without touching the Video: the next generator must start from THOSE positions, as the
+    reference's would (it reads the globals, video.py:178,265,291) -- and when nobody moved them,
+    from where the previous generator left them.  (A draw made while the previous generator object
+    is still alive and unsettled reads a stale position: movie.py:94-101 rebinds `op_seq`, which
+    finalises it -- the `gen = None` below.)"""
+    import palette
+    import screen
+    import video
+    import video_mode
+    from test_gpu_encode import _synth
+    frames = _synth(1, 3, 31337)
+    sched = [(0, 0, 50), (1, 1, 40), (2, 0, 30)]
+    random.seed(5)
+    np.random.seed(6)
+    v = video.Video(_FG(), ticks_per_second=14700., mode=video_mode.VideoMode.DHGR, palette=palette.Palette.NTSC)
+    ov = O.Video(1, oracle_tables.get(1, 5), seed_py=5, seed_np=6)
+    got, want = [], []
+    with contextlib.redirect_stdout(io.StringIO()):
+        for i, (fi, ia, n) in enumerate(sched):
+            if i == 1:    # reseed both, read nothing
+                random.seed(77)
+                np.random.seed(78)
+                O.lib().orc_mt_seed_py(O.lib().orc_video_rng_py(ov._h), 77)
+                O.lib().orc_mt_seed_np(O.lib().orc_video_rng_np(ov._h), 78)
+            if i == 2:    # draw from both, read nothing
+                a, b = random.getrandbits(8), int(np.random.randint(0, 256))
+                import ctypes as C
+                assert a == O.lib().orc_py_getrandbits8(C.byref(ov.rng_py()))
+                assert b == O.lib().orc_np_randint256(C.byref(ov.rng_np()))
+            tgt = screen.DHGRBitmap(main_memory=screen.MemoryMap(1, frames[fi, 0].copy()),
+                                    aux_memory=screen.MemoryMap(1, frames[fi, 1].copy()), palette=palette.Palette.NTSC)
+            gen = v.encode_frame(tgt, is_aux=bool(ia))
+            for _ in range(n):
+                page, content, offsets = next(gen)
+                got.append([page, content] + list(offsets))
+            gen = None
+            ov.encode_frame(frames[fi, 0], frames[fi, 1], ia)
+            want.append(ov.next(n))
+    assert (np.array(got, dtype=np.uint8) == np.concatenate(want)).all()
+    assert (v.update_priority == ov.update_priority(0)).all() and (v.aux_update_priority == ov.update_priority(1)).all()
