@@ -137,7 +137,7 @@ __device__ inline uint32_t edit_distance_bytes(const uint32_t (&src)[G], const u
 #pragma unroll
     for (int g = 0; g < G; g++) {
         xs[g] = (src[g] << 4) | tgt[g];
-        ys[g] = ((xs[g] & 0x0f0f0f0fu) << 4) | ((xs[g] >> 4) & 0x0f0f0f0fu);
+        ys[g] = (tgt[g] << 4) | src[g];  // xs with the nibbles of every byte swapped (one v_lshl_or each)
     }
     uint32_t e1 = 0, e2 = 0;
     EditStepBytes<0, N>::run(xs, ys, lut, e1, e2);
