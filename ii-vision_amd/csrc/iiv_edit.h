@@ -144,6 +144,39 @@ __device__ inline uint32_t edit_distance_bytes(const uint32_t (&src)[G], const u
     return e1;
 }
 
+// HGR colour strings from three small lookups: pixels 0..5, 6..11 and 12..17 of a window's string
+// depend on only 7, 6 and 7 of its 14 bits (found by brute force over all 2 x 2^14 windows: flip a
+// bit, see which pixels can change -- the palette bit of the byte itself reaches every pixel of
+// its group, a neighbour's only the pixels next to it):
+//     even byte:  bits 0..5 and 10 | bits 4..8 and 10 | bits 7..13
+//     odd byte:   bits 0..6        | bits 3 and 5..9  | bits 3 and 8..13
+// hgr_group_index compresses a window to the index of group g; hgr_group_window is its inverse
+// with every other bit zero (a representative window for building the table).
+constexpr int kHgrGroupEntries = 320;  // 128 + 64 + 128 per parity
+__host__ __device__ constexpr int hgr_group_base(int g) { return g == 0 ? 0 : g == 1 ? 128 : 192; }
+__host__ __device__ inline uint32_t hgr_group_index(uint32_t m, int g, int odd)
+{
+    if (!odd) {
+        if (g == 0) return (m & 0x3fu) | ((m >> 4) & 0x40u);
+        if (g == 1) return ((m >> 4) & 0x1fu) | ((m >> 5) & 0x20u);
+        return m >> 7;
+    }
+    if (g == 0) return m & 0x7fu;
+    if (g == 1) return ((m >> 3) & 1u) | ((m >> 4) & 0x3eu);
+    return ((m >> 3) & 1u) | ((m >> 7) & 0x7eu);
+}
+__host__ __device__ inline uint32_t hgr_group_window(uint32_t idx, int g, int odd)
+{
+    if (!odd) {
+        if (g == 0) return (idx & 0x3fu) | ((idx & 0x40u) << 4);
+        if (g == 1) return ((idx & 0x1fu) << 4) | ((idx & 0x20u) << 5);
+        return idx << 7;
+    }
+    if (g == 0) return idx;
+    if (g == 1) return ((idx & 1u) << 3) | ((idx & 0x3eu) << 4);
+    return ((idx & 1u) << 3) | ((idx & 0x7eu) << 7);
+}
+
 template <int N>
 __device__ inline uint32_t edit_distance(uint64_t alo, uint32_t ahi, uint64_t blo, uint32_t bhi, const uint16_t *lut)
 {

@@ -430,6 +430,36 @@ int pixel_strings(int mode, uint32_t *d_dots, uint8_t *d_pixels, ulonglong2 *d_s
                          : pixel_strings_impl<kHGR>(d_dots, d_pixels, d_strings, st);
 }
 
+// The table behind hgr_group_index (iiv_edit.h): entry (parity, group g, index) = the six pixels
+// 6g .. 6g + 5 of a representative window's string, one pixel per byte, already in the byte slots
+// they have among the five words of an 18-pixel string (group 0: words 0, 1; group 1: words 1, 2;
+// group 2: words 3, 4), so a string is three entries OR-ed together.
+__global__ __launch_bounds__(64) void hgr_string_lut_kernel(uint2 *__restrict__ out)
+{
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= 2 * kHgrGroupEntries) return;
+    const int odd = t / kHgrGroupEntries, e = t % kHgrGroupEntries;
+    const int g = e < 128 ? 0 : e < 192 ? 1 : 2;
+    const uint32_t m = hgr_group_window((uint32_t)(e - hgr_group_base(g)), g, odd);
+    uint64_t lo;
+    uint32_t hi;
+    colour_string<kHGR>(m, odd, lo, hi);
+    uint32_t w[5] = {0, 0, 0, 0, 0};
+    for (int p = 6 * g; p < 6 * g + 6; p++) {
+        const uint32_t px = p < 16 ? (uint32_t)(lo >> (4 * p)) & 0xfu : (hi >> (4 * (p - 16))) & 0xfu;
+        w[p >> 2] |= px << (8 * (p & 3));
+    }
+    const int first = g == 0 ? 0 : g == 1 ? 1 : 3;
+    out[t] = make_uint2(w[first], w[first + 1]);
+}
+
+int build_hgr_string_lut(uint2 **d_out, hipStream_t st)
+{
+    IIV_HIP(hipMalloc(d_out, 2 * kHgrGroupEntries * sizeof(uint2)));
+    hipLaunchKernelGGL(hgr_string_lut_kernel, dim3((2 * kHgrGroupEntries + 63) / 64), dim3(64), 0, st, *d_out);
+    return hip_check(hipGetLastError(), "hgr_string_lut_kernel launch");
+}
+
 struct TableScratch {
     ulonglong2 *strings = nullptr;
     uint16_t *sub = nullptr;

@@ -6,16 +6,16 @@ sys.path.insert(0, os.path.join(os.getcwd(), 'ii-vision_amd', 'transcoder'))
 import numpy as np, torch
 import _iiv_native as native, stream_batch, palette
 _, dm = native.cie2000_matrix(palette.NTSCPalette.rgb_array())
-mode = native.DHGR
+mode = native.HGR if len(sys.argv) > 1 and sys.argv[1] == "HGR" else native.DHGR
 table = native.build_table(mode, dm, True); store = native.build_store_table(mode, dm)
 for S in (1, 512, 4096):
-    fm, fa = stream_batch.synth_frames_torch(S, 4, True, seed=5)
+    fm, fa = stream_batch.synth_frames_torch(S, 4, mode == native.DHGR, seed=5)
     b = stream_batch.StreamBatch(mode, table, store, S, seeds=[(i+1,i+1) for i in range(S)], dm=dm)
     b.encode_frames(fm, fa, 3)
     ops, segs = b.encode_frames(fm, fa, 1)
     b.enc.check()
     full = np.stack([b.enc.get_state(100, i) for i in range(0, S, max(1, S//16))]).astype(np.int64)
-    b.enc.encode(fm, fa, [(3, 0, 1, 292), (3, 1, 1, 0)])   # closed generator -> prefix sort
+    b.enc.encode(fm, fa, [(3, 0, 1, 292), (3, 1 if mode == native.DHGR else 0, 1, 0)])   # closed generator -> prefix sort
     b.enc.check()
     rows = np.stack([b.enc.get_state(100, i) for i in range(0, S, max(1, S//16))]).astype(np.int64)
     sub = rows[:, [5, 8, 9, 6]]
