@@ -58,9 +58,9 @@ def data_seed(rank):
     return 7 + 1000 * rank
 
 
-def max_over_ranks(elapsed, device, world):
+def max_over_ranks(elapsed, device, world, use_dist=None):
     """The only data that crosses ranks: MAX of the timed region."""
-    if world <= 1:
+    if not (world > 1 if use_dist is None else use_dist):
         return elapsed
     import torch
     import torch.distributed as dist
@@ -192,8 +192,15 @@ def main(argv=None, backend_cls=GpuBackend):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     be = backend_cls(args, local_rank, world)
-    if world > 1:
+    # the process group exists for N > 1 only; IIV_BENCH_FORCE_DIST=1 creates it for one rank too, so that
+    # the RCCL initialisation, the barrier and the two scalar reductions can be exercised on a 1-GPU box
+    # (python -m torch.distributed.run --nproc-per-node 1 ... bench.py)
+    use_dist = world > 1 or os.environ.get("IIV_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(be.dist_backend, **be.dist_kwargs())
     n_gpus = max(world, 1)
     dhgr = args.mode == "DHGR"
@@ -204,7 +211,7 @@ def main(argv=None, backend_cls=GpuBackend):
     if S <= 0:
         per_clip = n_frames * 8192 * (2 if dhgr else 1) + 260 * 1024 + F * OPS_PER_FRAME * 6   # frames + stream state + opcodes
         S = next((c for c in (12288, 6144, 3072, 1536) if c * per_clip + (3 << 30) <= 0.85 * be.free_bytes()), 1536)
-        if world > 1:   # every rank runs the same number of clips
+        if use_dist:   # every rank runs the same number of clips
             import torch
             t = torch.tensor([S], dtype=torch.int64, device=be.device)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -217,7 +224,7 @@ def main(argv=None, backend_cls=GpuBackend):
     be.make_batch(S, seeds)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     first_ops = None   # stream 0's opcodes of the first F frames, checked against the oracle below
@@ -245,7 +252,7 @@ def main(argv=None, backend_cls=GpuBackend):
     prof = be.profile_read()
     be.profile(False)
 
-    elapsed = max_over_ranks(elapsed, be.device, world)
+    elapsed = max_over_ranks(elapsed, be.device, world, use_dist)
 
     frames_done = args.steps * F * S * n_gpus
     fps = frames_done / elapsed
@@ -326,7 +333,7 @@ def main(argv=None, backend_cls=GpuBackend):
             out["vs_reference_python"] = _vs_reference(args.mode, fps, out["cpu_baseline"]["value"])
 
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     return out
 
