@@ -1,0 +1,256 @@
+// Microbenchmark: the memory-side floor of the greedy step's access pattern, with none of its
+// arithmetic.  One wave per "stream" (28 resident per CU, like greedy_wave_kernel), per "opcode":
+// one coalesced 1 KiB row (streamed from HBM, like the wd row), then eight 4-byte gathers whose
+// lane addresses are row-dependent indices into the four (offset, content) slices of a table with
+// the split store table's shape (DHGR: left 4 x 32 x 256, right 4 x 64 x 512 u32 = 640 KiB), the
+// content changing every opcode.  Reports lookups per second and per CU-cycle; the greedy kernel's
+// own rate (512 lookups per opcode) is to be read against this.
+//   hipcc --offload-arch=gfx950 -O3 -o tools/gather_ceiling tools/gather_ceiling.hip && tools/gather_ceiling
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+__global__ __launch_bounds__(64) void pattern_kernel(const uint32_t *__restrict__ left, const uint32_t *__restrict__ right,
+                                                     const uint4 *__restrict__ rows, int n_ops, int gathers,
+                                                     uint32_t *__restrict__ sink)
+{
+    extern __shared__ uint32_t pad[];  // occupancy: the greedy kernel's 5.7 KiB per wave
+    const int lane = threadIdx.x;
+    const uint4 *my = rows + (size_t)blockIdx.x * n_ops * 64 + lane;
+    uint32_t acc = 0, h = blockIdx.x * 2654435761u + 977u;
+    uint4 next = my[0];
+    for (int op = 0; op < n_ops; op++) {
+        const uint4 row = next;
+        if (op + 1 < n_ops) next = my[(size_t)(op + 1) * 64];
+        h = h * 1664525u + 1013904223u;
+        const uint32_t c = (h >> 16) & 127u;  // wave-uniform content byte
+        const uint32_t *le = left + (((0u << 5) | (c & 31u)) << 8), *lo = left + (((2u << 5) | (c & 31u)) << 8);
+        const uint32_t *re = right + (((0u << 6) | ((c >> 1) & 63u)) << 9), *ro = right + (((2u << 6) | ((c >> 1) & 63u)) << 9);
+        if (gathers) {
+            const uint32_t a0 = le[row.x & 0xffu], b0 = re[(row.x >> 8) & 0x1ffu];
+            const uint32_t a1 = lo[row.y & 0xffu], b1 = ro[(row.y >> 8) & 0x1ffu];
+            const uint32_t a2 = le[row.z & 0xffu], b2 = re[(row.z >> 8) & 0x1ffu];
+            const uint32_t a3 = lo[row.w & 0xffu], b3 = ro[(row.w >> 8) & 0x1ffu];
+            acc += (a0 + b0) ^ (a1 + b1) ^ (a2 + b2) ^ (a3 + b3);
+        } else {
+            acc += row.x ^ row.y ^ row.z ^ row.w;
+        }
+    }
+    if (acc == 0x12345678u) pad[lane] = acc;
+    sink[blockIdx.x * 64 + lane] = acc;
+}
+
+// Variant A: the same eight gathers from a table of half the entry size (u16): half the slice bytes.
+__global__ __launch_bounds__(64) void pattern_u16_kernel(const uint16_t *__restrict__ left, const uint16_t *__restrict__ right,
+                                                         const uint4 *__restrict__ rows, int n_ops, uint32_t *__restrict__ sink)
+{
+    extern __shared__ uint32_t pad[];
+    const int lane = threadIdx.x;
+    const uint4 *my = rows + (size_t)blockIdx.x * n_ops * 64 + lane;
+    uint32_t acc = 0, h = blockIdx.x * 2654435761u + 977u;
+    uint4 next = my[0];
+    for (int op = 0; op < n_ops; op++) {
+        const uint4 row = next;
+        if (op + 1 < n_ops) next = my[(size_t)(op + 1) * 64];
+        h = h * 1664525u + 1013904223u;
+        const uint32_t c = (h >> 16) & 127u;
+        const uint16_t *le = left + (((0u << 5) | (c & 31u)) << 8), *lo = left + (((2u << 5) | (c & 31u)) << 8);
+        const uint16_t *re = right + (((0u << 6) | ((c >> 1) & 63u)) << 9), *ro = right + (((2u << 6) | ((c >> 1) & 63u)) << 9);
+        const uint32_t a0 = le[row.x & 0xffu], b0 = re[(row.x >> 8) & 0x1ffu];
+        const uint32_t a1 = lo[row.y & 0xffu], b1 = ro[(row.y >> 8) & 0x1ffu];
+        const uint32_t a2 = le[row.z & 0xffu], b2 = re[(row.z >> 8) & 0x1ffu];
+        const uint32_t a3 = lo[row.w & 0xffu], b3 = ro[(row.w >> 8) & 0x1ffu];
+        acc += (a0 + b0) ^ (a1 + b1) ^ (a2 + b2) ^ (a3 + b3);
+    }
+    if (acc == 0x12345678u) pad[lane] = acc;
+    sink[blockIdx.x * 64 + lane] = acc;
+}
+
+// Variant D: A plus, for one byte in 64 (the bytes whose colour strings can be transposed across the
+// cut), a 2-byte gather from the 8 MiB dense table under an execution mask.
+__global__ __launch_bounds__(64) void pattern_u16_rare_kernel(const uint16_t *__restrict__ left, const uint16_t *__restrict__ right,
+                                                              const uint16_t *__restrict__ dense, const uint4 *__restrict__ rows,
+                                                              int n_ops, uint32_t *__restrict__ sink)
+{
+    extern __shared__ uint32_t pad[];
+    const int lane = threadIdx.x;
+    const uint4 *my = rows + (size_t)blockIdx.x * n_ops * 64 + lane;
+    uint32_t acc = 0, h = blockIdx.x * 2654435761u + 977u;
+    uint4 next = my[0];
+    for (int op = 0; op < n_ops; op++) {
+        const uint4 row = next;
+        if (op + 1 < n_ops) next = my[(size_t)(op + 1) * 64];
+        h = h * 1664525u + 1013904223u;
+        const uint32_t c = (h >> 16) & 127u;
+        const uint16_t *le = left + (((0u << 5) | (c & 31u)) << 8), *lo = left + (((2u << 5) | (c & 31u)) << 8);
+        const uint16_t *re = right + (((0u << 6) | ((c >> 1) & 63u)) << 9), *ro = right + (((2u << 6) | ((c >> 1) & 63u)) << 9);
+        const uint16_t *de = dense + ((size_t)c << 13), *dd = dense + ((size_t)(256 + c) << 13);
+        uint32_t a0 = le[row.x & 0xffu], b0 = re[(row.x >> 8) & 0x1ffu];
+        uint32_t a1 = lo[row.y & 0xffu], b1 = ro[(row.y >> 8) & 0x1ffu];
+        uint32_t a2 = le[row.z & 0xffu], b2 = re[(row.z >> 8) & 0x1ffu];
+        uint32_t a3 = lo[row.w & 0xffu], b3 = ro[(row.w >> 8) & 0x1ffu];
+        if (((row.x >> 20) & 63u) == 0) a0 = de[row.x & 0x1fffu];
+        if (((row.y >> 20) & 63u) == 0) a1 = dd[row.y & 0x1fffu];
+        if (((row.z >> 20) & 63u) == 0) a2 = de[row.z & 0x1fffu];
+        if (((row.w >> 20) & 63u) == 0) a3 = dd[row.w & 0x1fffu];
+        acc += (a0 + b0) ^ (a1 + b1) ^ (a2 + b2) ^ (a3 + b3);
+    }
+    if (acc == 0x12345678u) pad[lane] = acc;
+    sink[blockIdx.x * 64 + lane] = acc;
+}
+
+// Variant B: four 8-byte gathers (as if both halves of a byte's value sat side by side in one
+// 6 KiB slice per opcode): what a layout that serves a byte with ONE load would buy.
+__global__ __launch_bounds__(64) void pattern_x2_kernel(const uint2 *__restrict__ both, const uint4 *__restrict__ rows,
+                                                        int n_ops, uint32_t *__restrict__ sink)
+{
+    extern __shared__ uint32_t pad[];
+    const int lane = threadIdx.x;
+    const uint4 *my = rows + (size_t)blockIdx.x * n_ops * 64 + lane;
+    uint32_t acc = 0, h = blockIdx.x * 2654435761u + 977u;
+    uint4 next = my[0];
+    for (int op = 0; op < n_ops; op++) {
+        const uint4 row = next;
+        if (op + 1 < n_ops) next = my[(size_t)(op + 1) * 64];
+        h = h * 1664525u + 1013904223u;
+        const uint32_t c = (h >> 16) & 127u;
+        const uint2 *e = both + ((0u << 7 | c) * 384u), *o = both + ((1u << 7 | c) * 384u);   // 384 rows x 8 B = 3 KiB per parity
+        const uint2 v0 = e[(row.x & 0x1ffu) % 384u], v1 = o[(row.y & 0x1ffu) % 384u], v2 = e[(row.z & 0x1ffu) % 384u],
+                    v3 = o[(row.w & 0x1ffu) % 384u];
+        acc += (v0.x + v0.y) ^ (v1.x + v1.y) ^ (v2.x + v2.y) ^ (v3.x + v3.y);
+    }
+    if (acc == 0x12345678u) pad[lane] = acc;
+    sink[blockIdx.x * 64 + lane] = acc;
+}
+
+// Variant C: the opcode's four slices (6 KiB) copied into LDS with coalesced 16-byte loads, the
+// eight gathers served by LDS; LDS per wave 5.7 + 6 KiB, i.e. 13 waves per CU.
+__global__ __launch_bounds__(64) void pattern_lds_kernel(const uint32_t *__restrict__ left, const uint32_t *__restrict__ right,
+                                                         const uint4 *__restrict__ rows, int n_ops, uint32_t *__restrict__ sink)
+{
+    extern __shared__ uint32_t lds[];   // [0, 1536): the slices; the rest: padding
+    const int lane = threadIdx.x;
+    const uint4 *my = rows + (size_t)blockIdx.x * n_ops * 64 + lane;
+    uint32_t acc = 0, h = blockIdx.x * 2654435761u + 977u;
+    uint4 next = my[0];
+    uint4 *l4 = reinterpret_cast<uint4 *>(lds);
+    for (int op = 0; op < n_ops; op++) {
+        const uint4 row = next;
+        if (op + 1 < n_ops) next = my[(size_t)(op + 1) * 64];
+        h = h * 1664525u + 1013904223u;
+        const uint32_t c = (h >> 16) & 127u;
+        const uint4 *le = reinterpret_cast<const uint4 *>(left + (((0u << 5) | (c & 31u)) << 8));
+        const uint4 *lo = reinterpret_cast<const uint4 *>(left + (((2u << 5) | (c & 31u)) << 8));
+        const uint4 *re = reinterpret_cast<const uint4 *>(right + (((0u << 6) | ((c >> 1) & 63u)) << 9));
+        const uint4 *ro = reinterpret_cast<const uint4 *>(right + (((2u << 6) | ((c >> 1) & 63u)) << 9));
+        const uint4 s0 = le[lane], s1 = lo[lane], s2 = re[lane], s3 = re[64 + lane], s4 = ro[lane], s5 = ro[64 + lane];
+        l4[lane] = s0; l4[64 + lane] = s1; l4[128 + lane] = s2; l4[192 + lane] = s3; l4[256 + lane] = s4; l4[320 + lane] = s5;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t a0 = lds[row.x & 0xffu], b0 = lds[512 + ((row.x >> 8) & 0x1ffu)];
+        const uint32_t a1 = lds[256 + (row.y & 0xffu)], b1 = lds[1024 + ((row.y >> 8) & 0x1ffu)];
+        const uint32_t a2 = lds[row.z & 0xffu], b2 = lds[512 + ((row.z >> 8) & 0x1ffu)];
+        const uint32_t a3 = lds[256 + (row.w & 0xffu)], b3 = lds[1024 + ((row.w >> 8) & 0x1ffu)];
+        acc += (a0 + b0) ^ (a1 + b1) ^ (a2 + b2) ^ (a3 + b3);
+        __builtin_amdgcn_wave_barrier();
+    }
+    sink[blockIdx.x * 64 + lane] = acc;
+}
+
+int main(int argc, char **argv)
+{
+    const int n_ops = 183;
+    const size_t nl = 4 * 32 * 256, nr = 4 * 64 * 512;
+    uint32_t *left, *right, *sink;
+    uint4 *rows;
+    for (int waves : {7168, 12288}) {
+        const size_t n_rows = (size_t)waves * n_ops * 64;
+        (void)hipMalloc(&left, nl * 4);
+        (void)hipMalloc(&right, nr * 4);
+        (void)hipMalloc(&rows, n_rows * sizeof(uint4));
+        (void)hipMalloc(&sink, (size_t)waves * 64 * 4);
+        (void)hipMemset(left, 1, nl * 4);
+        (void)hipMemset(right, 1, nr * 4);
+        {   // random rows (the gathers' addresses)
+            const size_t chunk = 1 << 24;
+            uint32_t *h = (uint32_t *)malloc(chunk * 4);
+            uint32_t s = 12345;
+            for (size_t o = 0; o < n_rows * 4; o += chunk) {
+                const size_t n = n_rows * 4 - o < chunk ? n_rows * 4 - o : chunk;
+                for (size_t i = 0; i < n; i++) { s = s * 1664525u + 1013904223u; h[i] = s >> 7; }
+                (void)hipMemcpy((uint32_t *)rows + o, h, n * 4, hipMemcpyHostToDevice);
+            }
+            free(h);
+        }
+        for (int lds : {5824, 5120}) {
+            for (int gathers : {1, 0}) {
+                hipEvent_t a, b;
+                (void)hipEventCreate(&a);
+                (void)hipEventCreate(&b);
+                hipLaunchKernelGGL(pattern_kernel, dim3(waves), dim3(64), lds, 0, left, right, rows, n_ops, gathers, sink);
+                (void)hipDeviceSynchronize();
+                (void)hipEventRecord(a);
+                const int reps = 5;
+                for (int r = 0; r < reps; r++)
+                    hipLaunchKernelGGL(pattern_kernel, dim3(waves), dim3(64), lds, 0, left, right, rows, n_ops, gathers, sink);
+                (void)hipEventRecord(b);
+                (void)hipEventSynchronize(b);
+                float ms;
+                (void)hipEventElapsedTime(&ms, a, b);
+                ms /= reps;
+                const double lookups = (double)waves * n_ops * 512;
+                printf("waves %5d  LDS/wave %4d B  %-28s %7.3f ms per launch", waves, lds,
+                       gathers ? "row + 8 gathers per opcode:" : "row only (HBM stream):", ms);
+                if (gathers)
+                    printf("  %7.1f G lookups/s  (%.2f per CU-cycle @2.4 GHz)\n", lookups / ms * 1e-6, lookups / (ms * 1e-3) / 256 / 2.4e9);
+                else
+                    printf("  %7.1f GB/s\n", (double)waves * n_ops * 1024 / ms * 1e-6);
+            }
+        }
+        {
+            auto time = [&](const char *name, auto launch) {
+                hipEvent_t a, b;
+                (void)hipEventCreate(&a);
+                (void)hipEventCreate(&b);
+                launch();
+                (void)hipDeviceSynchronize();
+                (void)hipEventRecord(a);
+                for (int r = 0; r < 5; r++) launch();
+                (void)hipEventRecord(b);
+                (void)hipEventSynchronize(b);
+                float ms;
+                (void)hipEventElapsedTime(&ms, a, b);
+                ms /= 5;
+                const double lookups = (double)waves * n_ops * 512;
+                printf("waves %5d  %-58s %7.3f ms per launch  %7.1f G lookups/s  err=%d\n", waves, name, ms, lookups / ms * 1e-6,
+                       (int)hipGetLastError());
+            };
+            uint2 *both;
+            (void)hipMalloc(&both, (size_t)2 * 128 * 384 * 8);
+            (void)hipMemset(both, 1, (size_t)2 * 128 * 384 * 8);
+            time("A: eight 2-byte gathers (half-size slices)", [&] {
+                hipLaunchKernelGGL(pattern_u16_kernel, dim3(waves), dim3(64), 5824, 0, (const uint16_t *)left, (const uint16_t *)right,
+                                   rows, n_ops, sink);
+            });
+            uint16_t *dense;
+            (void)hipMalloc(&dense, (size_t)8 << 20);
+            (void)hipMemset(dense, 1, (size_t)8 << 20);
+            time("D: A + a dense-table gather for 1 byte in 64", [&] {
+                hipLaunchKernelGGL(pattern_u16_rare_kernel, dim3(waves), dim3(64), 5824, 0, (const uint16_t *)left,
+                                   (const uint16_t *)right, dense, rows, n_ops, sink);
+            });
+            (void)hipFree(dense);
+            time("B: four 8-byte gathers (one load per byte, 6 KiB slices)", [&] {
+                hipLaunchKernelGGL(pattern_x2_kernel, dim3(waves), dim3(64), 5824, 0, both, rows, n_ops, sink);
+            });
+            time("C: slices copied to LDS, gathers from LDS (13 waves per CU)", [&] {
+                hipLaunchKernelGGL(pattern_lds_kernel, dim3(waves), dim3(64), 5824 + 6144, 0, left, right, rows, n_ops, sink);
+            });
+            (void)hipFree(both);
+        }
+        (void)hipFree(left); (void)hipFree(right); (void)hipFree(rows); (void)hipFree(sink);
+    }
+    return 0;
+}
