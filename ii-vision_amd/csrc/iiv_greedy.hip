@@ -31,6 +31,7 @@
 // (2.7 % of the opcodes of the bench workload) it re-scores the entry with every nonce
 // materialised in reference order.  Exact either way.
 #include "iiv_host.h"
+#include <type_traits>
 #include "iiv_stream.h"
 #include "iiv_wave.h"
 
@@ -45,8 +46,7 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
                                                                    const uint8_t *__restrict__ frames_main,
                                                                    const uint8_t *__restrict__ frames_aux, int n_frames,
                                                                    const LaunchSeg *__restrict__ segs, int seg_stride,
-                                                                   const uint32_t *__restrict__ left,
-                                                                   const uint32_t *__restrict__ right,
+                                                                   const NarrowTables nt,
                                                                    uint8_t *__restrict__ ops_out, size_t ops_stride)
 {
     using T = SplitTraits<MODE>;
@@ -140,12 +140,24 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
     unsigned long long pad_ops = 0;
     const uint32_t pad_content = (uint32_t)IIV_SGPR(S.pad_content);
 
-    // table slices of the even / odd page bytes of this bank
+    // table slices of the even / odd page bytes of this bank (narrow form, iiv_stream.h): byte
+    // offsets, inside the one allocation, of L1[o], R1[o] and dense[o]
+    constexpr int BITS = ModeTraits<MODE>::kBits, CB = ModeTraits<MODE>::kContentBits;
     const int o_e = byte_offset<MODE>(0, is_aux), o_d = byte_offset<MODE>(1, is_aux);
-    const uint32_t *left_e = left + ((size_t)o_e << (T::kLeftCBits + T::kLeftRowBits));
-    const uint32_t *left_d = left + ((size_t)o_d << (T::kLeftCBits + T::kLeftRowBits));
-    const uint32_t *right_e = right + ((size_t)o_e << (T::kRightCBits + T::kRightRowBits));
-    const uint32_t *right_d = right + ((size_t)o_d << (T::kRightCBits + T::kRightRowBits));
+    const uint32_t l1_e = (uint32_t)o_e << (T::kLeftCBits + T::kLeftRowBits + 1), l1_d = (uint32_t)o_d << (T::kLeftCBits + T::kLeftRowBits + 1);
+    const uint32_t r1_e = nt.right_off + ((uint32_t)o_e << (T::kRightCBits + T::kRightRowBits + 1));
+    const uint32_t r1_d = nt.right_off + ((uint32_t)o_d << (T::kRightCBits + T::kRightRowBits + 1));
+    const uint32_t ds_e = nt.dense_off + ((uint32_t)o_e << (CB + BITS + 1)), ds_d = nt.dense_off + ((uint32_t)o_d << (CB + BITS + 1));
+    // the exception masks of both parities: lane i holds the word of content part i
+    typedef typename std::conditional<MODE == kDHGR, uint32_t, unsigned long long>::type xmask_t;
+    const xmask_t xm_e = reinterpret_cast<const xmask_t *>(nt.xmask)[(o_e << 6) + lane];
+    const xmask_t xm_d = reinterpret_cast<const xmask_t *>(nt.xmask)[(o_d << 6) + lane];
+    auto xmask_of = [&](xmask_t v, uint32_t part) -> xmask_t {
+        if (MODE == kDHGR) return (xmask_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)part);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)part);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)v >> 32), (int)part);
+        return (xmask_t)(((unsigned long long)hi << 32) | lo);
+    };
     const uint8_t *tgt_frames = (MODE == kDHGR && is_aux ? frames_aux : frames_main) +
                                 ((size_t)blockIdx.x * n_frames + frame) * 8192;
     const uint4 *wd_rows = reinterpret_cast<const uint4 *>(S.wd);
@@ -166,21 +178,30 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
     // offsets, 1, 3 odd ones; both lookups of a slice back to back (the second finds the
     // slice's lines in L1)
     auto gather8 = [&](const uint4 &w, uint32_t c, Loaded &L) {
-        const char *le = reinterpret_cast<const char *>(left_e + (split_content_left<MODE>(c, 0) << T::kLeftRowBits));
-        const char *ld = reinterpret_cast<const char *>(left_d + (split_content_left<MODE>(c, 1) << T::kLeftRowBits));
-        const char *re = reinterpret_cast<const char *>(right_e + (split_content_right<MODE>(c, 0) << T::kRightRowBits));
-        const char *rd = reinterpret_cast<const char *>(right_d + (split_content_right<MODE>(c, 1) << T::kRightRowBits));
-        constexpr uint32_t LM = kWdRowMask << kWdLeftShift;   // byte offset of the left row's word
-        constexpr int RS = kWdRightShift - 2;                 // brings the right row to bit 2
+        // slice bases of this content byte, and where an excepted byte's loads go instead
+        const uint32_t sl_e = l1_e + (split_content_left<MODE>(c, 0) << (T::kLeftRowBits + 1));
+        const uint32_t sl_d = l1_d + (split_content_left<MODE>(c, 1) << (T::kLeftRowBits + 1));
+        const uint32_t sr_e = r1_e + (split_content_right<MODE>(c, 0) << (T::kRightRowBits + 1));
+        const uint32_t sr_d = r1_d + (split_content_right<MODE>(c, 1) << (T::kRightRowBits + 1));
+        const uint8_t *le = nt.base + sl_e, *ld = nt.base + sl_d, *re = nt.base + sr_e, *rd = nt.base + sr_d;
+        const uint32_t zr_e = nt.zero_off - sl_e, zr_d = nt.zero_off - sl_d;
+        const uint32_t cd = (c & ((1u << CB) - 1)) << (BITS + 1);   // (a DHGR byte with bit 7 set is an error elsewhere)
+        const uint32_t dr_e = ds_e + cd - sr_e, dr_d = ds_d + cd - sr_d;
+        const xmask_t me = xmask_of(xm_e, narrow_mask_content<MODE>(c, 0)), md = xmask_of(xm_d, narrow_mask_content<MODE>(c, 1));
         const uint32_t wr[4] = {w.x, w.y, w.z, w.w};
-        L.gl[0] = *reinterpret_cast<const uint32_t *>(le + (wr[0] & LM));
-        L.gl[2] = *reinterpret_cast<const uint32_t *>(le + (wr[2] & LM));
-        L.gl[1] = *reinterpret_cast<const uint32_t *>(ld + (wr[1] & LM));
-        L.gl[3] = *reinterpret_cast<const uint32_t *>(ld + (wr[3] & LM));
-        L.gr[0] = *reinterpret_cast<const uint32_t *>(re + ((wr[0] >> RS) & LM));
-        L.gr[2] = *reinterpret_cast<const uint32_t *>(re + ((wr[2] >> RS) & LM));
-        L.gr[1] = *reinterpret_cast<const uint32_t *>(rd + ((wr[1] >> RS) & LM));
-        L.gr[3] = *reinterpret_cast<const uint32_t *>(rd + ((wr[3] >> RS) & LM));
+        uint32_t ol[4], orr[4];
+        narrow_offsets<MODE, 0>(wr[0], me, zr_e, dr_e, ol[0], orr[0]);
+        narrow_offsets<MODE, 0>(wr[2], me, zr_e, dr_e, ol[2], orr[2]);
+        narrow_offsets<MODE, 1>(wr[1], md, zr_d, dr_d, ol[1], orr[1]);
+        narrow_offsets<MODE, 1>(wr[3], md, zr_d, dr_d, ol[3], orr[3]);
+        L.gl[0] = *reinterpret_cast<const uint16_t *>(le + ol[0]);
+        L.gl[2] = *reinterpret_cast<const uint16_t *>(le + ol[2]);
+        L.gl[1] = *reinterpret_cast<const uint16_t *>(ld + ol[1]);
+        L.gl[3] = *reinterpret_cast<const uint16_t *>(ld + ol[3]);
+        L.gr[0] = *reinterpret_cast<const uint16_t *>(re + orr[0]);
+        L.gr[2] = *reinterpret_cast<const uint16_t *>(re + orr[2]);
+        L.gr[1] = *reinterpret_cast<const uint16_t *>(rd + orr[1]);
+        L.gr[3] = *reinterpret_cast<const uint16_t *>(rd + orr[3]);
         // (the empty asm keeps the compiler from sinking these four ANDs to the scoring two
         // half-iterations later, which would keep the whole row alive until then)
 #pragma unroll
@@ -277,7 +298,7 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         unsigned long long cand[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            nd[r] = combine(L.gl[r], L.gr[r]);
+            nd[r] = L.gl[r] + L.gr[r];   // l1 + r1, or 0 + the dense value (iiv_stream.h: narrow form)
             const int d = (int)((nd[r] << kWdDwShift) | (y0 + r)) - (int)L.dwm[r];
             const int gone = __builtin_amdgcn_sbfe((int)pdw, sh0 + r, 1);
             const int live = __builtin_amdgcn_sbfe((int)nzw, sh0 + r, 1);
@@ -567,10 +588,10 @@ int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st)
 {
     if (mode == kDHGR)
         hipLaunchKernelGGL(greedy_wave_kernel<kDHGR>, dim3(a.n_streams), dim3(64), (size_t)a.lds_pad, st, a.states, a.frames_main,
-                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.left, a.right, a.ops_out, a.ops_stride);
+                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride);
     else
         hipLaunchKernelGGL(greedy_wave_kernel<kHGR>, dim3(a.n_streams), dim3(64), (size_t)a.lds_pad, st, a.states, a.frames_main,
-                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.left, a.right, a.ops_out, a.ops_stride);
+                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride);
     return hip_check(hipGetLastError(), "greedy_wave_kernel launch");
 }
 

@@ -12,15 +12,18 @@ constexpr int kPushedCap = 16384;  // >= 2 pushes x 7680 non-hole bytes
 
 // ---- wd[]: one word per byte of the live generator's bank, written once by the prologue
 // and immutable while the generator lives:
-//   bits  2..10  row index into the LEFT  half of the split store table  (split_row_left),
-//                i.e. bits 0..10 are the byte offset of the row's u32 inside a slice
-//   bits 11..19  row index into the RIGHT half                           (split_row_right)
+//   bits  0..8   row index into the RIGHT half of the split store table  (split_row_right);
+//                its low 5 / 6 bits are also the index into the "exception" masks below, which
+//                is why it sits at bit 0: a shift instruction takes them as they are
+//   bits 10..18  row index into the LEFT half                            (split_row_left);
+//                with bit 9 (always 0) the 10-bit field at bit 9 is the byte offset of the
+//                row's u16 inside a slice
 //   bits 20..30  diff weight of the byte (Bitmap.diff_weights, screen.py:400-449), <= 2047
 // Keys of the greedy step are `value << 20 | offset`, so `key - (wd & kWdDwMask)` is
 // `delta << 20 | offset` with delta = store value - diff weight (screen.py:547) in [-2047, 2047].
 constexpr int kWdDwShift = 20;
 constexpr uint32_t kWdDwMask = 0xffffffffu << kWdDwShift;
-constexpr int kWdLeftShift = 2, kWdRightShift = 11;
+constexpr int kWdLeftShift = 10, kWdRightShift = 0;
 constexpr uint32_t kWdRowMask = 0x1ffu;
 __host__ __device__ inline uint32_t wd_word(uint32_t row_left, uint32_t row_right, uint32_t dw)
 {
@@ -149,6 +152,80 @@ __host__ __device__ inline uint32_t split_combine(uint32_t l, uint32_t r)
     return a < b ? a : b;
 }
 
+// ---- the narrow form the greedy kernels read -------------------------------------------------
+// A greedy step is bound by the L1's rate for divergent loads, and that rate follows the bytes
+// its slices occupy (tools/gather_ceiling.hip: the access pattern alone, no arithmetic, takes
+// 1.42 ms per 12288-stream launch with 4-byte entries and 0.92 ms with 2-byte ones).  Of the two
+// paths of S = min(l0 + r0, l1 + r1), path 0 -- a transposition of the two pixels across the
+// cut -- exists only when the source's pixels (M, M+1) are the target's swapped, 1.6 % of all
+// (content, window) pairs.  So the kernels read
+//     L1[o][content part][row] = l1,   R1[o][content part][row] = r1      (u16 each)
+// and S = l1 + r1, except where an *exception mask* says the pair may differ from that: there
+// the value comes from the dense store table S[o][content][window] itself (one more table, read
+// by one lane in 64).  The mask is indexed by the few bits the swap condition can depend on:
+//     X[o][content part][index],  index = low 5 (DHGR) / 6 (HGR) bits of the right row
+//                                         (HGR odd bytes: bits 3..8 of the left row)
+// and is *built by comparison*: a bit is set iff some (content, window) it covers has
+// l1 + r1 != S (iiv_tables.hip: narrow_mask_kernel), so the scheme is exact by construction
+// whatever the bits chosen; choosing them well only keeps the exceptions rare.
+// To keep every load of a step unconditional (the software pipeline of iiv_greedy.hip depends on
+// that), an excepted byte does not branch: its RIGHT load is redirected to the dense entry and
+// its LEFT load to a zero word -- L1 | zero | R1 | dense copy live in ONE allocation, so a
+// redirection is a different 32-bit offset from the same slice base.
+struct NarrowTables {
+    const uint8_t *base;                         // the allocation (its first bytes are L1)
+    uint32_t zero_off, right_off, dense_off;     // byte offsets of the zero word, R1, the dense copy
+    const void *xmask;                           // DHGR: u32 [4][64]; HGR: u64 [2][64]
+};
+template <int MODE> __host__ __device__ constexpr uint32_t narrow_zero_off() { return (uint32_t)split_left_entries<MODE>() * 2; }
+template <int MODE> __host__ __device__ constexpr uint32_t narrow_right_off() { return narrow_zero_off<MODE>() + 256; }
+template <int MODE> __host__ __device__ constexpr uint32_t narrow_dense_off()
+{
+    return narrow_right_off<MODE>() + (uint32_t)split_right_entries<MODE>() * 2;
+}
+template <int MODE> __host__ __device__ constexpr size_t narrow_total_bytes()
+{
+    return narrow_dense_off<MODE>() + (((size_t)ModeTraits<MODE>::kOffsets << (ModeTraits<MODE>::kContentBits + ModeTraits<MODE>::kBits)) * 2);
+}
+// which mask word / bit a (content, rows) pair falls under
+template <int MODE> __host__ __device__ inline uint32_t narrow_mask_content(uint32_t c, int odd)
+{
+    if (MODE == kDHGR) return split_content_right<MODE>(c, odd);
+    return odd ? split_content_left<MODE>(c, 1) : split_content_right<MODE>(c, 0);
+}
+template <int MODE> __host__ __device__ inline uint32_t narrow_mask_index(uint32_t row_left, uint32_t row_right, int odd)
+{
+    if (MODE == kDHGR) return row_right & 31u;
+    return odd ? (row_left >> 3) & 63u : row_right & 63u;
+}
+// the window back from its two rows
+template <int MODE> __host__ __device__ inline uint32_t split_window_from_rows(uint32_t row_left, uint32_t row_right, int odd)
+{
+    if (MODE == kDHGR) return (row_right << 4) | (row_left & 15u);
+    return odd ? ((row_right >> 1) << 6) | (row_left & 63u) : (row_right << 5) | (row_left & 31u);
+}
+// byte offsets, relative to the (offset, content) slice bases of L1 and R1, of the two u16 a
+// byte's value is the sum of.  xm = the byte's mask word (u32 DHGR / u64 HGR, wave-uniform per
+// parity), zrel = zero word - L1 slice base, drel = dense[o][content][0] - R1 slice base.
+template <int MODE, int ODD, typename M>
+__device__ static inline void narrow_offsets(uint32_t wd, M xm, uint32_t zrel, uint32_t drel, uint32_t &off_l, uint32_t &off_r)
+{
+    const uint32_t rr = wd & kWdRowMask;
+    const uint32_t lr2 = (wd >> (kWdLeftShift - 1)) & 0x3feu;   // one v_bfe_u32: bit 9 of wd is 0
+    uint32_t t;
+    if (MODE == kDHGR) t = (uint32_t)xm >> (wd & 31u);                              // (the shift takes wd's low bits as they are)
+    else if (!ODD) t = (uint32_t)(xm >> (wd & 63u));
+    else t = (uint32_t)(xm >> ((wd >> (kWdLeftShift + 3)) & 63u));
+    const uint32_t m = 0u - (t & 1u);
+    const uint32_t lrow = wd >> kWdLeftShift;
+    uint32_t win;
+    if (MODE == kDHGR) win = (rr << 4) | (lrow & 15u);
+    else if (!ODD) win = (rr << 5) | (lrow & 31u);
+    else win = ((rr >> 1) << 6) | (lrow & 63u);
+    off_l = (lr2 & ~m) | (zrel & m);
+    off_r = ((rr << 1) & ~m) | (((win << 1) + drel) & m);
+}
+
 // LDS accesses of one wave execute in order: making one lane's LDS writes visible to the
 // other lanes of the same wave needs no s_barrier, only that the compiler keeps the order.
 __device__ static inline void wave_lds_sync()
@@ -191,7 +268,8 @@ struct GreedyArgs {
     int n_frames, n_streams;
     const LaunchSeg *segs;   // device
     int seg_stride;          // 0: one descriptor for every stream; 1: descriptor per stream
-    const uint32_t *left, *right;  // split store table
+    const uint32_t *left, *right;  // split store table (u32 pairs: the joint choice, the builders)
+    NarrowTables nt;               // its narrow form (the one-wave and the team kernel)
     uint8_t *ops_out;
     size_t ops_stride;       // bytes between the outputs of consecutive streams
     int lds_pad;             // extra dynamic LDS per stream (bytes): caps the streams resident per CU

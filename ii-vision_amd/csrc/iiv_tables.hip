@@ -300,6 +300,149 @@ __global__ __launch_bounds__(256) void split_kernel(const ulonglong2 *__restrict
     }
 }
 
+// ------------------------------------------------------------------ narrow form (iiv_stream.h)
+
+// L1 / R1: component 1 of every entry of the two halves, as u16
+template <int MODE>
+__global__ __launch_bounds__(256) void narrow_fill_kernel(const uint32_t *__restrict__ left, const uint32_t *__restrict__ right,
+                                                          uint8_t *__restrict__ buf)
+{
+    const size_t nl = split_left_entries<MODE>(), nr = split_right_entries<MODE>();
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx < nl)
+        reinterpret_cast<uint16_t *>(buf)[idx] = (uint16_t)(left[idx] >> 16);
+    else if (idx < nl + nr)
+        reinterpret_cast<uint16_t *>(buf + narrow_right_off<MODE>())[idx - nl] = (uint16_t)(right[idx - nl] >> 16);
+    if (idx < 128) reinterpret_cast<uint16_t *>(buf + narrow_zero_off<MODE>())[idx] = 0;
+}
+
+// exception masks, by comparison with the dense table: one thread per (offset, content, window)
+template <int MODE>
+__global__ __launch_bounds__(256) void narrow_mask_kernel(const uint8_t *__restrict__ buf, const uint16_t *__restrict__ dense,
+                                                          unsigned long long *__restrict__ xmask64, uint32_t *__restrict__ xmask32)
+{
+    using T = SplitTraits<MODE>;
+    constexpr int BITS = ModeTraits<MODE>::kBits, CB = ModeTraits<MODE>::kContentBits;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // ((o << CB) + content) << BITS) + window
+    if (idx >= ((size_t)ModeTraits<MODE>::kOffsets << (CB + BITS))) return;
+    const uint32_t m = idx & ((1u << BITS) - 1), c = (idx >> BITS) & ((1u << CB) - 1);
+    const int o = (int)(idx >> (BITS + CB)), odd = o & 1;
+    const uint32_t lr = split_row_left<MODE>(m, odd), rr = split_row_right<MODE>(m, odd);
+    const uint16_t *l1 = reinterpret_cast<const uint16_t *>(buf), *r1 = reinterpret_cast<const uint16_t *>(buf + narrow_right_off<MODE>());
+    const uint32_t v = (uint32_t)l1[((((size_t)o << T::kLeftCBits) + split_content_left<MODE>(c, odd)) << T::kLeftRowBits) + lr] +
+                       (uint32_t)r1[((((size_t)o << T::kRightCBits) + split_content_right<MODE>(c, odd)) << T::kRightRowBits) + rr];
+    if (v != dense[idx]) {
+        const uint32_t word = ((uint32_t)o << 6) + narrow_mask_content<MODE>(c, odd), bit = narrow_mask_index<MODE>(lr, rr, odd);
+        if (MODE == kDHGR) atomicOr(&xmask32[word], 1u << bit);
+        else atomicOr(&xmask64[word], 1ull << bit);
+    }
+}
+
+// every value as the kernels obtain it (narrow_offsets), for the exactness test; also counts the
+// (content, window) pairs that go through the dense table
+template <int MODE>
+__global__ __launch_bounds__(256) void narrow_expand_kernel(NarrowTables nt, uint16_t *__restrict__ out,
+                                                            unsigned long long *__restrict__ n_exceptions)
+{
+    using T = SplitTraits<MODE>;
+    constexpr int BITS = ModeTraits<MODE>::kBits, CB = ModeTraits<MODE>::kContentBits;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= ((size_t)ModeTraits<MODE>::kOffsets << (CB + BITS))) return;
+    const uint32_t m = idx & ((1u << BITS) - 1), c = (idx >> BITS) & ((1u << CB) - 1);
+    const int o = (int)(idx >> (BITS + CB)), odd = o & 1;
+    const uint32_t wd = wd_word(split_row_left<MODE>(m, odd), split_row_right<MODE>(m, odd), 0);
+    const uint32_t slab_l = (uint32_t)((((size_t)o << T::kLeftCBits) + split_content_left<MODE>(c, odd)) << (T::kLeftRowBits + 1));
+    const uint32_t slab_r =
+        nt.right_off + (uint32_t)((((size_t)o << T::kRightCBits) + split_content_right<MODE>(c, odd)) << (T::kRightRowBits + 1));
+    const uint32_t dense0 = nt.dense_off + (uint32_t)((((size_t)o << CB) + c) << (BITS + 1));
+    const uint32_t word = ((uint32_t)o << 6) + narrow_mask_content<MODE>(c, odd);
+    uint32_t off_l, off_r;
+    if (MODE == kDHGR) {
+        const uint32_t xm = reinterpret_cast<const uint32_t *>(nt.xmask)[word];
+        if (odd) narrow_offsets<MODE, 1>(wd, xm, nt.zero_off - slab_l, dense0 - slab_r, off_l, off_r);
+        else narrow_offsets<MODE, 0>(wd, xm, nt.zero_off - slab_l, dense0 - slab_r, off_l, off_r);
+    } else {
+        const unsigned long long xm = reinterpret_cast<const unsigned long long *>(nt.xmask)[word];
+        if (odd) narrow_offsets<MODE, 1>(wd, xm, nt.zero_off - slab_l, dense0 - slab_r, off_l, off_r);
+        else narrow_offsets<MODE, 0>(wd, xm, nt.zero_off - slab_l, dense0 - slab_r, off_l, off_r);
+    }
+    const uint32_t v = (uint32_t)*reinterpret_cast<const uint16_t *>(nt.base + slab_l + off_l) +
+                       (uint32_t)*reinterpret_cast<const uint16_t *>(nt.base + slab_r + off_r);
+    out[idx] = (uint16_t)v;
+    if (off_r >= nt.dense_off - slab_r) atomicAdd(n_exceptions, 1ull);
+}
+
+template <int MODE>
+static int build_narrow_impl(const uint32_t *d_left, const uint32_t *d_right, const uint16_t *d_store, NarrowTables *out,
+                             hipStream_t st)
+{
+    constexpr int BITS = ModeTraits<MODE>::kBits, CB = ModeTraits<MODE>::kContentBits;
+    uint8_t *buf = nullptr;
+    void *mask = nullptr;
+    IIV_HIP(hipMalloc(&buf, narrow_total_bytes<MODE>()));
+    hipError_t he = hipMalloc(&mask, 4 * 64 * 8);
+    if (he != hipSuccess) { (void)hipFree(buf); return hip_check(he, "hipMalloc(narrow masks)"); }
+    int rc = IIV_OK;
+    do {
+        if ((rc = hip_check(hipMemsetAsync(mask, 0, 4 * 64 * 8, st), "memset masks"))) break;
+        const size_t n_dense = (size_t)ModeTraits<MODE>::kOffsets << (CB + BITS);
+        if ((rc = hip_check(hipMemcpyAsync(buf + narrow_dense_off<MODE>(), d_store, n_dense * 2, hipMemcpyDeviceToDevice, st),
+                            "copy dense store table")))
+            break;
+        const size_t n_fill = split_left_entries<MODE>() + split_right_entries<MODE>();
+        hipLaunchKernelGGL(narrow_fill_kernel<MODE>, dim3((unsigned)((n_fill + 255) / 256)), dim3(256), 0, st, d_left, d_right, buf);
+        hipLaunchKernelGGL(narrow_mask_kernel<MODE>, dim3((unsigned)((n_dense + 255) / 256)), dim3(256), 0, st, buf, d_store,
+                           (unsigned long long *)mask, (uint32_t *)mask);
+        if ((rc = hip_check(hipGetLastError(), "narrow table kernels"))) break;
+        rc = hip_check(hipStreamSynchronize(st), "narrow tables sync");
+    } while (0);
+    if (rc) {
+        (void)hipFree(buf);
+        (void)hipFree(mask);
+        return rc;
+    }
+    out->base = buf;
+    out->zero_off = narrow_zero_off<MODE>();
+    out->right_off = narrow_right_off<MODE>();
+    out->dense_off = narrow_dense_off<MODE>();
+    out->xmask = mask;
+    return IIV_OK;
+}
+
+// d_left / d_right: the u32 halves (build_split_tables); d_store: the dense store table
+int build_narrow_tables(int mode, const uint32_t *d_left, const uint32_t *d_right, const uint16_t *d_store, NarrowTables *out,
+                        hipStream_t st)
+{
+    return mode == kDHGR ? build_narrow_impl<kDHGR>(d_left, d_right, d_store, out, st)
+                         : build_narrow_impl<kHGR>(d_left, d_right, d_store, out, st);
+}
+
+void free_narrow_tables(NarrowTables *nt)
+{
+    if (nt->base) (void)hipFree(const_cast<uint8_t *>(nt->base));
+    if (nt->xmask) (void)hipFree(const_cast<void *>(nt->xmask));
+    nt->base = nullptr;
+    nt->xmask = nullptr;
+}
+
+int expand_narrow_tables(int mode, const NarrowTables &nt, uint16_t *d_out, unsigned long long *n_exceptions, hipStream_t st)
+{
+    const size_t n = (size_t)num_offsets(mode) << (content_bits(mode) + masked_bits(mode));
+    unsigned long long *d_cnt = nullptr;
+    IIV_HIP(hipMalloc(&d_cnt, 8));
+    int rc = hip_check(hipMemsetAsync(d_cnt, 0, 8, st), "memset");
+    if (!rc) {
+        const dim3 grid((unsigned)((n + 255) / 256));
+        if (mode == kDHGR) hipLaunchKernelGGL(narrow_expand_kernel<kDHGR>, grid, dim3(256), 0, st, nt, d_out, d_cnt);
+        else hipLaunchKernelGGL(narrow_expand_kernel<kHGR>, grid, dim3(256), 0, st, nt, d_out, d_cnt);
+        rc = hip_check(hipGetLastError(), "narrow_expand_kernel launch");
+    }
+    if (!rc) rc = hip_check(hipMemcpyAsync(n_exceptions, d_cnt, 8, hipMemcpyDeviceToHost, st), "copy count");
+    if (!rc) rc = hip_check(hipStreamSynchronize(st), "sync");
+    (void)hipFree(d_cnt);
+    return rc;
+}
+
 // The halves with content innermost -- T[o][row][content part] -- for the joint content choice
 // (iiv_encode.hip, greedy_kernel<MODE, true>): one row's values for every byte value are one or
 // two cache lines.
@@ -645,6 +788,29 @@ int build_split_store_table(int mode, const int32_t dm[256], uint32_t *d_left, u
     if (tmp_r) (void)hipFree(tmp_r);
     if (rc) return rc;
     return hip_check(he, "sync");
+}
+
+// for the exactness test: halves from dm, narrow form from them and d_store, every value re-read
+// through narrow_offsets into d_expanded
+int build_narrow_store_table(int mode, const int32_t dm[256], const uint16_t *d_store, uint16_t *d_expanded,
+                             unsigned long long *n_exceptions, hipStream_t st)
+{
+    TableScratch sc;
+    int rc = prepare_scratch(mode, dm, sc, st);
+    if (rc) return rc;
+    uint32_t *d_l = nullptr, *d_r = nullptr;
+    NarrowTables nt{};
+    do {
+        if ((rc = hip_check(hipMalloc(&d_l, split_entries(mode, 0) * 4), "hipMalloc(split left)"))) break;
+        if ((rc = hip_check(hipMalloc(&d_r, split_entries(mode, 1) * 4), "hipMalloc(split right)"))) break;
+        if ((rc = build_split_tables(mode, sc.strings, sc.sub, d_l, d_r, st))) break;
+        if ((rc = build_narrow_tables(mode, d_l, d_r, d_store, &nt, st))) break;
+        rc = expand_narrow_tables(mode, nt, d_expanded, n_exceptions, st);
+    } while (0);
+    free_narrow_tables(&nt);
+    if (d_l) (void)hipFree(d_l);
+    if (d_r) (void)hipFree(d_r);
+    return rc;
 }
 
 int symmetrise_table(int mode, uint16_t *d_table, hipStream_t st)

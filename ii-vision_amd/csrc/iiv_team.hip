@@ -9,22 +9,21 @@ __global__ __launch_bounds__(64 * kScoringWaves) void greedy_team_kernel(StreamS
                                                                          const uint8_t *__restrict__ frames_main,
                                                                          const uint8_t *__restrict__ frames_aux, int n_frames,
                                                                          const LaunchSeg *__restrict__ segs, int seg_stride,
-                                                                         const uint32_t *__restrict__ left,
-                                                                         const uint32_t *__restrict__ right,
+                                                                         const NarrowTables nt,
                                                                          uint8_t *__restrict__ ops_out, size_t ops_stride)
 {
     const LaunchSeg g = segs[(size_t)blockIdx.x * seg_stride];
-    team_body<MODE, kScoringWaves>(states, frames_main, frames_aux, n_frames, g, left, right, ops_out, ops_stride);
+    team_body<MODE, kScoringWaves>(states, frames_main, frames_aux, n_frames, g, nt, ops_out, ops_stride);
 }
 
 int launch_greedy_team(int mode, const GreedyArgs &a, hipStream_t st)
 {
     if (mode == kDHGR)
         hipLaunchKernelGGL(greedy_team_kernel<kDHGR>, dim3(a.n_streams), dim3(64 * kScoringWaves), 0, st, a.states, a.frames_main,
-                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.left, a.right, a.ops_out, a.ops_stride);
+                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride);
     else
         hipLaunchKernelGGL(greedy_team_kernel<kHGR>, dim3(a.n_streams), dim3(64 * kScoringWaves), 0, st, a.states, a.frames_main,
-                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.left, a.right, a.ops_out, a.ops_stride);
+                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride);
     return hip_check(hipGetLastError(), "greedy_team_kernel launch");
 }
 

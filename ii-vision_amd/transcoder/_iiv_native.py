@@ -42,6 +42,7 @@ SYMBOLS = [
     "iiv_encode", "iiv_encode_streams",
     "iiv_encoder_check", "iiv_encoder_profile", "iiv_encoder_profile_read",
     "iiv_build_split_store_table", "iiv_split_table_entries", "iiv_check_split_diff_table",
+    "iiv_build_narrow_store_table",
     "iiv_emit_stream", "iiv_emit_chunk", "iiv_frames_to_memory_maps",
 ]
 
@@ -131,6 +132,7 @@ def lib():
     L.iiv_build_split_store_table.argtypes = [i32, vp, vp, vp, vp, vp]
     L.iiv_split_table_entries.restype = sz
     L.iiv_check_split_diff_table.argtypes = [i32, vp, vp, vp, vp]
+    L.iiv_build_narrow_store_table.argtypes = [i32, vp, vp, vp, vp, vp]
     L.iiv_split_table_entries.argtypes = [i32, i32]
     L.iiv_encoder_check.argtypes = [vp, C.POINTER(i32), vp]
     L.iiv_encoder_profile.argtypes = [vp, i32]
@@ -249,6 +251,18 @@ def check_split_diff_table(mode, dm, table):
     n = C.c_ulonglong(0)
     check(lib().iiv_check_split_diff_table(mode, hptr(dm), dptr(table), C.byref(n), stream_ptr()))
     return int(n.value)
+
+
+def build_narrow_store_table(mode, dm, store):
+    """(expanded, n_exceptions): every store value as the greedy kernels obtain it from the narrow
+    form of the split table (u16 halves + exception masks + the dense table), and the number of
+    (content, window) pairs that go through the dense table."""
+    torch = _torch()
+    dm = np.ascontiguousarray(dm, dtype=np.int32).reshape(256)
+    exp = torch.empty_like(store)
+    n = C.c_ulonglong(0)
+    check(lib().iiv_build_narrow_store_table(mode, hptr(dm), dptr(store), dptr(exp), C.byref(n), stream_ptr()))
+    return exp, int(n.value)
 
 
 def build_split_store_table(mode, dm, expanded=True):

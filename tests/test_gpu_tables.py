@@ -109,6 +109,19 @@ def test_split_store_table_is_exact(native, device_tables, dms, mode, pal):
 
 @pytest.mark.parametrize("mode", [1, 0])
 @pytest.mark.parametrize("pal", [5, 0])
+def test_narrow_store_table_is_exact(native, device_tables, dms, mode, pal):
+    """The narrow form the one-wave and team kernels read (csrc/iiv_stream.h): S = l1 + r1 from
+    2-byte halves, except where an exception mask sends the lookup to the dense table.  Re-read
+    with the kernels' own offset arithmetic it must equal the dense store table for EVERY (offset,
+    content, window), and the exceptions must stay rare (they are what the scheme pays for)."""
+    _, dense = device_tables.get(mode, pal)
+    exp, n_exc = native.build_narrow_store_table(mode, dms[pal], dense)
+    assert bool((exp == dense).all())
+    assert 0 < n_exc < 0.05 * dense.numel(), n_exc / dense.numel()
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("pal", [5, 0])
 def test_split_diff_weight_table_is_exact(native, device_tables, dms, mode, pal):
     """The split diff-weight table of the prologue's IIV_DW_SPLIT mode (csrc/iiv_stream.h): the same
     cut applied to Bitmap.diff_weights' table.  Combined with the prologue's own index
