@@ -211,19 +211,20 @@ template <int MODE, int ODD, typename M>
 __device__ static inline void narrow_offsets(uint32_t wd, M xm, uint32_t zrel, uint32_t drel, uint32_t &off_l, uint32_t &off_r)
 {
     const uint32_t rr = wd & kWdRowMask;
-    const uint32_t lr2 = (wd >> (kWdLeftShift - 1)) & 0x3feu;   // one v_bfe_u32: bit 9 of wd is 0
+    const uint32_t lr2 = __builtin_amdgcn_ubfe(wd, kWdLeftShift - 1, 10);   // left row << 1: bit 9 of wd is 0
+    // the byte's exception bit (v_bfe_u32 takes the low 5 bits of its offset operand as they are)
     uint32_t t;
-    if (MODE == kDHGR) t = (uint32_t)xm >> (wd & 31u);                              // (the shift takes wd's low bits as they are)
-    else if (!ODD) t = (uint32_t)(xm >> (wd & 63u));
-    else t = (uint32_t)(xm >> ((wd >> (kWdLeftShift + 3)) & 63u));
-    const uint32_t m = 0u - (t & 1u);
-    const uint32_t lrow = wd >> kWdLeftShift;
-    uint32_t win;
-    if (MODE == kDHGR) win = (rr << 4) | (lrow & 15u);
-    else if (!ODD) win = (rr << 5) | (lrow & 31u);
-    else win = ((rr >> 1) << 6) | (lrow & 63u);
-    off_l = (lr2 & ~m) | (zrel & m);
-    off_r = ((rr << 1) & ~m) | (((win << 1) + drel) & m);
+    if (MODE == kDHGR) t = __builtin_amdgcn_ubfe((uint32_t)xm, wd, 1);
+    else if (!ODD) t = (uint32_t)(xm >> (wd & 63u)) & 1u;
+    else t = (uint32_t)(xm >> ((wd >> (kWdLeftShift + 3)) & 63u)) & 1u;
+    // (window << 1) + drel, the window put back together from its rows (split_window_from_rows)
+    uint32_t dl;
+    if (MODE == kDHGR) dl = (rr << 5) + ((lr2 & 30u) + drel);
+    else if (!ODD) dl = (rr << 6) + ((lr2 & 62u) + drel);
+    else dl = ((rr >> 1) << 7) + ((lr2 & 126u) + drel);
+    const bool x = t != 0;
+    off_l = x ? zrel : lr2;
+    off_r = x ? dl : rr << 1;
 }
 
 // LDS accesses of one wave execute in order: making one lane's LDS writes visible to the
