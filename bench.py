@@ -44,6 +44,7 @@ for _p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "ii-vision_amd
 OPS_PER_FRAME = 490                # 14700 Hz / 30 fps (video.py:31-33)
 BYTES_PER_OPCODE = 534             # 256 x 2 B gathers + 6 B out + 2 x 8 B packed RMW
 BYTES_PER_PROLOGUE = 147456        # 2 x 32 KiB packed + 16 KiB gathers + 64 KiB priority r/w
+GATHER_CEILING_GLOADS = 1184.2   # tools/gather_ceiling.hip, variant D (profiles/r02l_gather_ceiling.txt)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
 HBM_MEASURED_READ_GBS = 5990.0     # tools/hbm_copy_bench.py on the same box (profiles/r01f_hbm_copy.txt); copy 4610, write 6900
 PALETTE_IDS = {"NTSC": 5, "IIGS": 0}   # palette.py:18-23
@@ -310,6 +311,19 @@ def main(argv=None, backend_cls=GpuBackend):
             "launches": prof["greedy_launches"],
             "lookups_per_s": float(op_count) * S * 256 / (g_ms * 1e-3) if g_ms > 0 else 0.0,
         }
+        if be.uses_wave_kernel() and args.mode == "DHGR":
+            # The bound that actually holds this kernel is not HBM but the L1's rate for divergent loads.
+            # Its yardstick is a measurement, not a datasheet figure: tools/gather_ceiling.hip runs the
+            # kernel's access pattern (a streamed 1 KiB row + 8 divergent table loads per opcode, narrow
+            # form: 2-byte slices + 1 lane in 64 into the dense table) with no arithmetic at all.
+            loads = float(op_count) * S * 512 / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
+            out["roofline_access_pattern"] = {
+                "kernel": "greedy_wave_kernel", "bound": "l1 divergent loads",
+                "achieved": loads, "peak": GATHER_CEILING_GLOADS, "unit": "G table loads/s",
+                "frac": loads / GATHER_CEILING_GLOADS,
+                "peak_source": "profiles/r02l_gather_ceiling.txt, variant D at 12288 waves (0.972 ms per launch): a "
+                               "committed microbenchmark run on an MI355X, not this run",
+            }
         pro_bytes = float(seg_count) * S * BYTES_PER_PROLOGUE
         out["roofline_prologue"] = {
             "kernel": "prologue_kernel",
