@@ -390,6 +390,7 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
     // diagnostic build: shader clocks of this wave per pipeline stage, and its start / end time
     unsigned long long ph[4] = {0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memtime();
     const unsigned long long wave_t0 = ph_t;
+    int n_steps = 0;
 #define IIV_PHASE(i)                                                  \
     do {                                                              \
         const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
@@ -430,13 +431,22 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         };
         // next live entry, or 0 when the list is used up; *next_head = list position after it
         auto take = [&](int &next_head) -> uint32_t {
-            while (qi >= n_dense) {
-                if (win_end >= n_sorted) return 0u;
-                refill();
+            for (;;) {
+                while (qi >= n_dense) {
+                    if (win_end >= n_sorted) return 0u;
+                    refill();
+                }
+                const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)dense_e, qi++);
+                // An entry can die between the compaction of its window and its turn (a step resolved its
+                // byte exactly, video.py:159-170): it would cost a full pipeline slot -- row, eight table
+                // loads, a step that finds it dead.  On image-like input that is 0.6 slots per opcode
+                // (tools/greedy_phases.py); one LDS word per entry taken avoids them.
+                const uint32_t loc = e & 0x1fffu;
+                const uint32_t w = IIV_SGPR(nz[loc >> 5]);
+                if (!((w >> (loc & 31)) & 1u)) continue;
+                next_head = win_base + (int)(e >> 24) + 1;
+                return e | 0x80000000u;  // (bit 31 marks a real entry: page 0 / offset 0 / content 0 is a valid one)
             }
-            const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)dense_e, qi++);
-            next_head = win_base + (int)(e >> 24) + 1;
-            return e | 0x80000000u;  // (bit 31 marks a real entry: page 0 / offset 0 / content 0 is a valid one)
         };
         auto row_of = [&](uint32_t e) -> uint4 { return wd_rows[((e >> 8) & 31) * 64 + lane]; };
 
@@ -487,6 +497,9 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
             if (!active) return false;
             twist_now();  // (the MT19937 block generation hides behind the loads)
             IIV_PHASE(1);   // MT19937 block generation
+#ifdef IIV_STAMPS
+            n_steps++;
+#endif
             (void)step(eA, cur);
             IIV_PHASE(2);   // wait for the table words, score, apply
             head = hA;
@@ -579,6 +592,7 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         S.stamps[24] = wave_t0;
         S.stamps[25] = __builtin_amdgcn_s_memtime();
         S.stamps[26] = (unsigned long long)done;
+        S.stamps[27] = (unsigned long long)n_steps;   // list entries that went through the pipeline (emitted or found dead)
 #endif
     }
 }

@@ -6,10 +6,14 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import numpy as np, torch
 import _iiv_native as native, stream_batch, palette
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 12288
+KIND = sys.argv[2] if len(sys.argv) > 2 else "iid"      # iid | coh | img
 _, dm = native.cie2000_matrix(palette.NTSCPalette.rgb_array())
 mode = native.DHGR
 table = native.build_table(mode, dm, True); store = native.build_store_table(mode, dm)
-fm, fa = stream_batch.synth_frames_torch(S, 6, True, seed=5)
+if KIND == "img":
+    fm, fa = stream_batch.synth_frames_img(S, 6, True, seed=5)
+else:
+    fm, fa = stream_batch.synth_frames_torch(S, 6, True, seed=5, coherent=KIND == "coh")
 b = stream_batch.StreamBatch(mode, table, store, S, seeds=[(i + 1, i + 1) for i in range(S)], dm=dm)
 b.enc.set_greedy_kernel(True)
 b.encode_frames(fm, fa, 4)
@@ -17,6 +21,8 @@ b.enc.encode(fm, fa, [(4, 0, 1, 292)])     # the measured launch: 292 opcodes pe
 b.enc.check()
 allst = np.stack([b.enc.get_state(100, i) for i in range(0, S, max(1, S // 512))]).astype(np.int64)
 rows, t0, t1, ops = allst[:, 16:20], allst[:, 24], allst[:, 25], allst[:, 26]
+print("S-%s: %.1f list entries through the pipeline per opcode emitted (the rest were dead when their turn came)" % (
+    KIND, allst[:, 27].sum() / max(ops.sum(), 1)))
 span = t1.max() - t0.min()
 life = t1 - t0
 print("S=%d: wave lifetimes mean %.0f  min %.0f  max %.0f clocks; launch span %.0f -> mean lifetime / span %.2f" % (
