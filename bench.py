@@ -76,7 +76,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("IIV_BENCH_STREAMS", "0")),
-                    help="independent clips per GPU (0 = the largest of 12288 / 6144 / 3072 / 1536 whose clips fit "
+                    help="independent clips per GPU (0 = the largest of 14336 / 12288 / 6144 / 3072 / 1536 whose clips fit "
                          "the free HBM: ~7000 fill the GPU, more hide the tail of a launch)")
     ap.add_argument("--frames-per-step", type=int, default=50)
     ap.add_argument("--mode", choices=["DHGR", "HGR"], default="DHGR")
@@ -211,7 +211,9 @@ def main(argv=None, backend_cls=GpuBackend):
     S = args.streams
     if S <= 0:
         per_clip = n_frames * 8192 * (2 if dhgr else 1) + 260 * 1024 + F * OPS_PER_FRAME * 6   # frames + stream state + opcodes
-        S = next((c for c in (12288, 6144, 3072, 1536) if c * per_clip + (3 << 30) <= 0.85 * be.free_bytes()), 1536)
+        # 7168 one-wave streams are resident at a time (28 per CU): 14336 = two full rounds per launch
+        # (+2 % over 12288, whose second round is 71 % full); it needs 246 of a free MI355X's 287 GiB
+        S = next((c for c in (14336, 12288, 6144, 3072, 1536) if c * per_clip + (3 << 30) <= 0.88 * be.free_bytes()), 1536)
         if use_dist:   # every rank runs the same number of clips
             import torch
             t = torch.tensor([S], dtype=torch.int64, device=be.device)
