@@ -147,6 +147,9 @@ class GpuBackend:
             self.fm, self.fa = self.sb.synth_frames_img(S, n_frames, self.dhgr, seed=seed)
         else:
             self.fm, self.fa = self.sb.synth_frames_torch(S, n_frames, self.dhgr, seed=seed, coherent=a.coherent)
+        # the generators' temporaries go back to the driver: libiivision allocates with hipMalloc,
+        # outside torch's caching allocator, and the clips leave it 40 GiB
+        self.torch.cuda.empty_cache()
 
     def make_batch(self, S, seeds):
         a = self.args
