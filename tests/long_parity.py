@@ -1,7 +1,7 @@
 """Long-horizon differential run: a few whole 1000-frame clips (BASELINE configs 3 / 4: DHGR and HGR,
 Movie pacing, bank flips), GPU through the C ABI against the oracle -- every opcode, the final
 screen, priorities and both RNG positions.  The oracle here is the checker.  On an MI355X:
-    python tests/long_parity.py [frames] [clips] [auto|wave]      (about a minute at 1000 x 8;
+    python tests/long_parity.py [frames] [clips] [auto|wave] [palette id] [iid|coh|img]   (about a minute at 1000 x 8;
 few clips run in the eight-waves-per-clip team kernel unless "wave" asks for the one-wave kernel)"""
 import concurrent.futures
 import os
@@ -21,13 +21,18 @@ import stream_batch  # noqa: E402
 n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 kernel = sys.argv[3] if len(sys.argv) > 3 else "auto"
+pal = int(sys.argv[4]) if len(sys.argv) > 4 else 5        # 5 = NTSC, 0 = //gs (palette.py:18-23)
+kind = sys.argv[5] if len(sys.argv) > 5 else "iid"        # iid | coh | img
 O.build()
-dm = O.cie2000_matrix(O.PALETTE_RGB[5])[1]
+dm = O.cie2000_matrix(O.PALETTE_RGB[pal])[1]
 for mode in (native.DHGR, native.HGR):
     t0 = time.time()
     otab = O.build_table(mode, dm, symmetric=True)
     table, store = native.build_table(mode, dm, True), native.build_store_table(mode, dm)
-    fm, fa = stream_batch.synth_frames_torch(n, n_frames, mode == native.DHGR, seed=77, coherent=False)
+    if kind == "img":
+        fm, fa = stream_batch.synth_frames_img(n, n_frames, mode == native.DHGR, seed=77)
+    else:
+        fm, fa = stream_batch.synth_frames_torch(n, n_frames, mode == native.DHGR, seed=77, coherent=kind == "coh")
     seeds = [(i + 1, 100 + i) for i in range(n)]
     b = stream_batch.StreamBatch(mode, table, store, n, seeds=seeds, dm=dm)
     b.enc.set_greedy_kernel(True if kernel == "wave" else None)
@@ -62,6 +67,6 @@ for mode in (native.DHGR, native.HGR):
             assert (b.enc.get_state(native.STATE_UP_AUX, i) == v.update_priority(1)).all()
         cnt = b.enc.get_state(native.STATE_COUNTERS, i)
         assert (int(cnt[0]), int(cnt[1])) == v.draws()
-    print("%s, %s kernel: %d clips x %d frames = %d opcodes each, all equal (%.0f s)" % (
-        "DHGR" if mode == native.DHGR else "HGR", kernel, n, n_frames, got.shape[1], time.time() - t0), flush=True)
+    print("%s, %s kernel, palette %d, S-%s: %d clips x %d frames = %d opcodes each, all equal (%.0f s)" % (
+        "DHGR" if mode == native.DHGR else "HGR", kernel, pal, kind, n, n_frames, got.shape[1], time.time() - t0), flush=True)
     b.close()
