@@ -100,7 +100,9 @@ def parse_args(argv=None):
     ap.add_argument("--full-sort", action="store_true", help="disable the prologue's prefix sort")
     ap.add_argument("--lds-pad", type=int, default=-1, help="tuning: extra LDS bytes per greedy wave (caps streams per CU)")
     ap.add_argument("--emit", action="store_true",
-                    help="also time encode -> .a2m byte emission -> pinned host memory (end to end)")
+                    help="(default unless --no-extras) also time encode -> .a2m byte emission -> pinned host "
+                         "memory, end to end; kept as a flag for older command lines")
+    ap.add_argument("--no-emit", action="store_true", help="skip the end-to-end emission leg")
     return ap.parse_args(argv)
 
 
@@ -343,7 +345,7 @@ def main(argv=None, backend_cls=GpuBackend):
 
         if n_gpus == 1 and not args.no_extras and be.is_gpu:
             out["single_stream"] = _single_stream(be, args)
-            if args.emit:
+            if not args.no_emit:   # the same steps with the bytes leaving the device (PCIe-inclusive; never `value`)
                 out["emit"] = _emit_end_to_end(be, args, fps)
             out["make_data_tables_s"] = _make_data_tables_seconds()
         if not args.no_cpu_baseline and n_gpus == 1 and be.is_gpu:
