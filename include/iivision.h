@@ -199,8 +199,10 @@ void iiv_encoder_destroy(iiv_encoder *enc);
                                   *   priority (what _compute_error would hand out); ties: the target byte, then
                                   *   the smallest c.  update_priority[primary] becomes nd_c[primary] instead of 0
                                   *   (video.py:140); everything else is the reference's step applied to c.
-                                  *   R(target byte) is what the reference's step removes, so a joint step never
-                                  *   removes less.  128 / 256 times the lookups of a reference step; runs in the
+                                  *   R(target byte) is what the reference's step removes by its own accounting (stores are
+                                  *   scored against the target's neighbours, screen.py:542-545), so a joint step never
+                                  *   removes less by that accounting; measured on the screen itself a single step may, a
+                                  *   frame of them does not (tests/test_gpu_joint.py).  128 / 256 times the lookups of a reference step; runs in the
                                   *   workgroup greedy kernel whatever IIV_OPT_GREEDY_KERNEL says. */
 int iiv_encoder_set_option(iiv_encoder *enc, int option, int value);
 

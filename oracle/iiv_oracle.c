@@ -921,7 +921,9 @@ static void emit_pad(orc_video *v, uint8_t *out)
  *         d1, d2 = the two smallest negative deltas nd_c[y] - dw[y] over the other bytes of the page
  *         whose priority is non-zero (exactly the offsets _compute_error would hand out; 0 if absent);
  *         ties: the primary's target byte first, then the smallest c.  R(target byte) is what
- *         the reference's step removes, so a joint step never removes less.
+ *         the reference's step removes by its own accounting (it scores a store against the
+ *         target's neighbours, screen.py:542-545), so a joint step never removes less by that
+ *         accounting; on the screen itself a single step may, a frame of them does not.
  *   :140  update_priority[page, offset] = nd_c[primary], the error the chosen byte leaves
  *         (0 when c is the target byte); it is not re-queued -- the next generator sees it.
  * Everything else (candidate order, nonce draws, re-queueing of the extra offsets) is the

@@ -87,8 +87,9 @@ def _screen_error(native, device_tables, mode, enc, frames, last, n):
 def test_joint_leaves_less_error_per_opcode(native, O, device_tables, mode):
     """What the mode is for: the same clips and opcode budget (three Movie-paced frames), less
     perceptual error left between screen and target.  R(target byte) <= R(chosen byte) holds step by
-    step by construction; over a run the two trajectories differ, so the claim is checked on the
-    outcome: every one of 8 clips ends with less error, 2-6 % less in total."""
+    step only in the step's own accounting (stores are scored against the target's neighbours,
+    screen.py:542-545), and the two trajectories differ, so the claim is checked on the outcome:
+    every one of 8 clips ends with less error, 2-6 % less in total."""
     n = 8
     sched = ([(0, 0, 292), (0, 1, 198), (1, 1, 94), (1, 0, 292), (1, 1, 104), (2, 1, 188), (2, 0, 292), (2, 1, 10)]
              if mode == 1 else [(0, 0, 490), (1, 0, 490), (2, 0, 490)])
