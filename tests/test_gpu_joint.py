@@ -172,3 +172,19 @@ def test_dropin_video_joint_content(O, oracle_tables):
     import ctypes as C
     assert [random.getrandbits(8) for _ in range(4)] == [L.orc_py_getrandbits8(C.byref(py)) for _ in range(4)]
     assert np.random.randint(0, 256, size=4).tolist() == [L.orc_np_randint256(C.byref(npd)) for _ in range(4)]
+
+
+def test_options_that_need_the_diff_matrix_say_so(native, device_tables):
+    """An encoder made without dm (caller's own tables) has no split tables: the joint content choice,
+    the split diff-weight mode and the one-wave / team kernels refuse instead of reading nothing."""
+    t, s = device_tables.get(1, 5)
+    enc = native.Encoder(1, t, s, 1)
+    for call in (lambda: enc.set_content_choice(True), lambda: enc.set_diff_weights_mode("split"),
+                 lambda: enc.set_greedy_kernel(True), lambda: enc.set_greedy_kernel("team")):
+        with pytest.raises(native.IIVError):
+            call()
+    enc.set_content_choice(False)      # (the defaults stay available)
+    enc.set_diff_weights_mode("table")
+    enc.close()
+    with pytest.raises(native.IIVError):
+        native.check(native.lib().iiv_build_narrow_store_table(1, None, None, None, None, None))
