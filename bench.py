@@ -324,12 +324,13 @@ def main(argv=None, backend_cls=GpuBackend):
             # kernel's access pattern (a streamed 1 KiB row + 8 divergent table loads per opcode, narrow
             # form: 2-byte slices + 1 lane in 64 into the dense table) with no arithmetic at all.
             loads = float(op_count) * S * 512 / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
+            peak, src = _gather_ceiling_live(S) if (be.is_gpu and not args.no_extras) else (None, None)
+            if peak is None:
+                peak, src = GATHER_CEILING_GLOADS, ("profiles/r02l_gather_ceiling.txt, variant D at 12288 waves (0.972 ms per "
+                                                    "launch): a committed microbenchmark run on an MI355X, not this run")
             out["roofline_access_pattern"] = {
                 "kernel": "greedy_wave_kernel", "bound": "l1 divergent loads",
-                "achieved": loads, "peak": GATHER_CEILING_GLOADS, "unit": "G table loads/s",
-                "frac": loads / GATHER_CEILING_GLOADS,
-                "peak_source": "profiles/r02l_gather_ceiling.txt, variant D at 12288 waves (0.972 ms per launch): a "
-                               "committed microbenchmark run on an MI355X, not this run",
+                "achieved": loads, "peak": peak, "unit": "G table loads/s", "frac": loads / peak, "peak_source": src,
             }
         pro_bytes = float(seg_count) * S * BYTES_PER_PROLOGUE
         out["roofline_prologue"] = {
@@ -357,6 +358,22 @@ def main(argv=None, backend_cls=GpuBackend):
     if use_dist:
         dist.destroy_process_group()
     return out
+
+
+def _gather_ceiling_live(S):
+    """The ceiling of the greedy step's access pattern, measured now: tools/gather_ceiling (built by
+    __graft_entry__.build()) runs that pattern -- a streamed 1 KiB row + 8 divergent table loads per
+    opcode, no arithmetic -- with as many waves as there are clips, in a child process."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "gather_ceiling")
+    try:
+        r = subprocess.run([exe, "D", str(int(S))], capture_output=True, text=True, timeout=120)
+        tag, waves, ms, gl = r.stdout.strip().split()[-4:]
+        if r.returncode == 0 and tag == "D":
+            return float(gl), "tools/gather_ceiling D %s, run by this bench.py beside the encode: %s ms per launch" % (waves, ms)
+    except Exception:
+        pass
+    return None, None
 
 
 def _pmc_traffic():

@@ -159,8 +159,57 @@ __global__ __launch_bounds__(64) void pattern_lds_kernel(const uint32_t *__restr
     sink[blockIdx.x * 64 + lane] = acc;
 }
 
+// `gather_ceiling D <waves>`: only variant D (the kernels' present access pattern) with that many
+// waves, one line "D <waves> <ms per launch> <G table loads per s>" -- what bench.py runs.
+static int run_d_only(int waves)
+{
+    const int n_ops = 183;
+    const size_t nl = 4 * 32 * 256, nr = 4 * 64 * 512, n_rows = (size_t)waves * n_ops * 64;
+    uint32_t *left, *right, *sink;
+    uint16_t *dense;
+    uint4 *rows;
+    if (hipMalloc(&left, nl * 4) != hipSuccess || hipMalloc(&right, nr * 4) != hipSuccess ||
+        hipMalloc(&rows, n_rows * sizeof(uint4)) != hipSuccess || hipMalloc(&sink, (size_t)waves * 64 * 4) != hipSuccess ||
+        hipMalloc(&dense, (size_t)8 << 20) != hipSuccess)
+        return 1;
+    (void)hipMemset(left, 1, nl * 4);
+    (void)hipMemset(right, 1, nr * 4);
+    (void)hipMemset(dense, 1, (size_t)8 << 20);
+    {
+        const size_t chunk = 1 << 24;
+        uint32_t *h = (uint32_t *)malloc(chunk * 4);
+        uint32_t s = 12345;
+        for (size_t o = 0; o < n_rows * 4; o += chunk) {
+            const size_t n = n_rows * 4 - o < chunk ? n_rows * 4 - o : chunk;
+            for (size_t i = 0; i < n; i++) { s = s * 1664525u + 1013904223u; h[i] = s >> 7; }
+            (void)hipMemcpy((uint32_t *)rows + o, h, n * 4, hipMemcpyHostToDevice);
+        }
+        free(h);
+    }
+    auto launch = [&] {
+        hipLaunchKernelGGL(pattern_u16_rare_kernel, dim3(waves), dim3(64), 5824, 0, (const uint16_t *)left, (const uint16_t *)right,
+                           dense, rows, n_ops, sink);
+    };
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    launch();
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(a);
+    for (int r = 0; r < 10; r++) launch();
+    (void)hipEventRecord(b);
+    (void)hipEventSynchronize(b);
+    float ms;
+    (void)hipEventElapsedTime(&ms, a, b);
+    ms /= 10;
+    if (hipGetLastError() != hipSuccess) return 1;
+    printf("D %d %.4f %.1f\n", waves, ms, (double)waves * n_ops * 512 / ms * 1e-6);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc >= 3 && argv[1][0] == 'D') return run_d_only(atoi(argv[2]));
     const int n_ops = 183;
     const size_t nl = 4 * 32 * 256, nr = 4 * 64 * 512;
     uint32_t *left, *right, *sink;
