@@ -44,6 +44,7 @@ for _p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "ii-vision_amd
 OPS_PER_FRAME = 490                # 14700 Hz / 30 fps (video.py:31-33)
 BYTES_PER_OPCODE = 534             # 256 x 2 B gathers + 6 B out + 2 x 8 B packed RMW
 BYTES_PER_PROLOGUE = 147456        # 2 x 32 KiB packed + 16 KiB gathers + 64 KiB priority r/w
+GATHER_CEILING_GLOADS_HGR = 995.0    # tools/gather_ceiling D 14336 HGR (3.61 ms per launch of 490 opcodes)
 GATHER_CEILING_GLOADS = 1184.2   # tools/gather_ceiling.hip, variant D (profiles/r02l_gather_ceiling.txt)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
 HBM_MEASURED_READ_GBS = 5990.0     # tools/hbm_copy_bench.py on the same box (profiles/r01f_hbm_copy.txt); copy 4610, write 6900
@@ -318,13 +319,15 @@ def main(argv=None, backend_cls=GpuBackend):
             "launches": prof["greedy_launches"],
             "lookups_per_s": float(op_count) * S * 256 / (g_ms * 1e-3) if g_ms > 0 else 0.0,
         }
-        if be.uses_wave_kernel() and args.mode == "DHGR":
+        if be.uses_wave_kernel():
             # The bound that actually holds this kernel is not HBM but the L1's rate for divergent loads.
             # Its yardstick is a measurement, not a datasheet figure: tools/gather_ceiling.hip runs the
             # kernel's access pattern (a streamed 1 KiB row + 8 divergent table loads per opcode, narrow
             # form: 2-byte slices + 1 lane in 64 into the dense table) with no arithmetic at all.
             loads = float(op_count) * S * 512 / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
-            peak, src = _gather_ceiling_live(S) if (be.is_gpu and not args.no_extras) else (None, None)
+            peak, src = _gather_ceiling_live(S, args.mode) if (be.is_gpu and not args.no_extras) else (None, None)
+            if peak is None and args.mode == "HGR":
+                peak, src = GATHER_CEILING_GLOADS_HGR, "tools/gather_ceiling D 14336 HGR, a run on an MI355X committed as a constant, not this run"
             if peak is None:
                 peak, src = GATHER_CEILING_GLOADS, ("profiles/r02l_gather_ceiling.txt, variant D at 12288 waves (0.972 ms per "
                                                     "launch): a committed microbenchmark run on an MI355X, not this run")
@@ -360,17 +363,18 @@ def main(argv=None, backend_cls=GpuBackend):
     return out
 
 
-def _gather_ceiling_live(S):
+def _gather_ceiling_live(S, mode="DHGR"):
     """The ceiling of the greedy step's access pattern, measured now: tools/gather_ceiling (built by
     __graft_entry__.build()) runs that pattern -- a streamed 1 KiB row + 8 divergent table loads per
     opcode, no arithmetic -- with as many waves as there are clips, in a child process."""
     import subprocess
     exe = os.path.join(ROOT, "tools", "gather_ceiling")
     try:
-        r = subprocess.run([exe, "D", str(int(S))], capture_output=True, text=True, timeout=120)
+        r = subprocess.run([exe, "D", str(int(S))] + (["HGR"] if mode == "HGR" else []), capture_output=True, text=True, timeout=180)
         tag, waves, ms, gl = r.stdout.strip().split()[-4:]
         if r.returncode == 0 and tag == "D":
-            return float(gl), "tools/gather_ceiling D %s, run by this bench.py beside the encode: %s ms per launch" % (waves, ms)
+            return float(gl), "tools/gather_ceiling D %s%s, run by this bench.py beside the encode: %s ms per launch" % (
+                waves, " HGR" if mode == "HGR" else "", ms)
     except Exception:
         pass
     return None, None

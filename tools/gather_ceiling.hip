@@ -69,10 +69,13 @@ __global__ __launch_bounds__(64) void pattern_u16_kernel(const uint16_t *__restr
 
 // Variant D: A plus, for one byte in 64 (the bytes whose colour strings can be transposed across the
 // cut), a 2-byte gather from the 8 MiB dense table under an execution mask.
+template <bool HGR>
 __global__ __launch_bounds__(64) void pattern_u16_rare_kernel(const uint16_t *__restrict__ left, const uint16_t *__restrict__ right,
                                                               const uint16_t *__restrict__ dense, const uint4 *__restrict__ rows,
                                                               int n_ops, uint32_t *__restrict__ sink)
 {
+    // DHGR: left 4 x 32 x 256, right 4 x 64 x 512, dense 4 x 128 x 2^13; HGR: left / right 2 x 64 x 512, dense 2 x 256 x 2^14
+    constexpr uint32_t LR = HGR ? 9 : 8, LM = (1u << LR) - 1, CM = HGR ? 255u : 127u, WB = HGR ? 14 : 13;
     extern __shared__ uint32_t pad[];
     const int lane = threadIdx.x;
     const uint4 *my = rows + (size_t)blockIdx.x * n_ops * 64 + lane;
@@ -82,18 +85,20 @@ __global__ __launch_bounds__(64) void pattern_u16_rare_kernel(const uint16_t *__
         const uint4 row = next;
         if (op + 1 < n_ops) next = my[(size_t)(op + 1) * 64];
         h = h * 1664525u + 1013904223u;
-        const uint32_t c = (h >> 16) & 127u;
-        const uint16_t *le = left + (((0u << 5) | (c & 31u)) << 8), *lo = left + (((2u << 5) | (c & 31u)) << 8);
-        const uint16_t *re = right + (((0u << 6) | ((c >> 1) & 63u)) << 9), *ro = right + (((2u << 6) | ((c >> 1) & 63u)) << 9);
-        const uint16_t *de = dense + ((size_t)c << 13), *dd = dense + ((size_t)(256 + c) << 13);
-        uint32_t a0 = le[row.x & 0xffu], b0 = re[(row.x >> 8) & 0x1ffu];
-        uint32_t a1 = lo[row.y & 0xffu], b1 = ro[(row.y >> 8) & 0x1ffu];
-        uint32_t a2 = le[row.z & 0xffu], b2 = re[(row.z >> 8) & 0x1ffu];
-        uint32_t a3 = lo[row.w & 0xffu], b3 = ro[(row.w >> 8) & 0x1ffu];
-        if (((row.x >> 20) & 63u) == 0) a0 = de[row.x & 0x1fffu];
-        if (((row.y >> 20) & 63u) == 0) a1 = dd[row.y & 0x1fffu];
-        if (((row.z >> 20) & 63u) == 0) a2 = de[row.z & 0x1fffu];
-        if (((row.w >> 20) & 63u) == 0) a3 = dd[row.w & 0x1fffu];
+        const uint32_t c = (h >> 16) & CM;
+        const uint32_t o_d = HGR ? 1u : 2u, cl = HGR ? (c & 63u) : (c & 31u), cr = HGR ? (c >> 2) : ((c >> 1) & 63u);
+        const uint32_t lcb = HGR ? 6 : 5;
+        const uint16_t *le = left + (((0u << lcb) | cl) << LR), *lo = left + (((o_d << lcb) | cl) << LR);
+        const uint16_t *re = right + (((0u << 6) | cr) << 9), *ro = right + (((o_d << 6) | cr) << 9);
+        const uint16_t *de = dense + ((size_t)c << WB), *dd = dense + ((size_t)((CM + 1) * (HGR ? 1 : 2) + c) << WB);
+        uint32_t a0 = le[row.x & LM], b0 = re[(row.x >> 9) & 0x1ffu];
+        uint32_t a1 = lo[row.y & LM], b1 = ro[(row.y >> 9) & 0x1ffu];
+        uint32_t a2 = le[row.z & LM], b2 = re[(row.z >> 9) & 0x1ffu];
+        uint32_t a3 = lo[row.w & LM], b3 = ro[(row.w >> 9) & 0x1ffu];
+        if (((row.x >> 20) & 63u) == 0) a0 = de[row.x & ((1u << WB) - 1)];
+        if (((row.y >> 20) & 63u) == 0) a1 = dd[row.y & ((1u << WB) - 1)];
+        if (((row.z >> 20) & 63u) == 0) a2 = de[row.z & ((1u << WB) - 1)];
+        if (((row.w >> 20) & 63u) == 0) a3 = dd[row.w & ((1u << WB) - 1)];
         acc += (a0 + b0) ^ (a1 + b1) ^ (a2 + b2) ^ (a3 + b3);
     }
     if (acc == 0x12345678u) pad[lane] = acc;
@@ -159,22 +164,23 @@ __global__ __launch_bounds__(64) void pattern_lds_kernel(const uint32_t *__restr
     sink[blockIdx.x * 64 + lane] = acc;
 }
 
-// `gather_ceiling D <waves>`: only variant D (the kernels' present access pattern) with that many
+// `gather_ceiling D <waves> [HGR]`: only variant D (the kernels' present access pattern) with that many
 // waves, one line "D <waves> <ms per launch> <G table loads per s>" -- what bench.py runs.
-static int run_d_only(int waves)
+static int run_d_only(int waves, bool hgr)
 {
-    const int n_ops = 183;
-    const size_t nl = 4 * 32 * 256, nr = 4 * 64 * 512, n_rows = (size_t)waves * n_ops * 64;
+    const int n_ops = hgr ? 490 : 183;   // opcodes per generator under Movie pacing
+    const size_t nl = hgr ? 2 * 64 * 512 : 4 * 32 * 256, nr = hgr ? 2 * 64 * 512 : 4 * 64 * 512, n_rows = (size_t)waves * n_ops * 64;
+    const size_t dense_bytes = hgr ? (size_t)16 << 20 : (size_t)8 << 20;
     uint32_t *left, *right, *sink;
     uint16_t *dense;
     uint4 *rows;
     if (hipMalloc(&left, nl * 4) != hipSuccess || hipMalloc(&right, nr * 4) != hipSuccess ||
         hipMalloc(&rows, n_rows * sizeof(uint4)) != hipSuccess || hipMalloc(&sink, (size_t)waves * 64 * 4) != hipSuccess ||
-        hipMalloc(&dense, (size_t)8 << 20) != hipSuccess)
+        hipMalloc(&dense, dense_bytes) != hipSuccess)
         return 1;
     (void)hipMemset(left, 1, nl * 4);
     (void)hipMemset(right, 1, nr * 4);
-    (void)hipMemset(dense, 1, (size_t)8 << 20);
+    (void)hipMemset(dense, 1, dense_bytes);
     {
         const size_t chunk = 1 << 24;
         uint32_t *h = (uint32_t *)malloc(chunk * 4);
@@ -187,8 +193,12 @@ static int run_d_only(int waves)
         free(h);
     }
     auto launch = [&] {
-        hipLaunchKernelGGL(pattern_u16_rare_kernel, dim3(waves), dim3(64), 5824, 0, (const uint16_t *)left, (const uint16_t *)right,
-                           dense, rows, n_ops, sink);
+        if (hgr)
+            hipLaunchKernelGGL(pattern_u16_rare_kernel<true>, dim3(waves), dim3(64), 5824, 0, (const uint16_t *)left,
+                               (const uint16_t *)right, dense, rows, n_ops, sink);
+        else
+            hipLaunchKernelGGL(pattern_u16_rare_kernel<false>, dim3(waves), dim3(64), 5824, 0, (const uint16_t *)left,
+                               (const uint16_t *)right, dense, rows, n_ops, sink);
     };
     hipEvent_t a, b;
     (void)hipEventCreate(&a);
@@ -196,12 +206,13 @@ static int run_d_only(int waves)
     launch();
     (void)hipDeviceSynchronize();
     (void)hipEventRecord(a);
-    for (int r = 0; r < 10; r++) launch();
+    const int reps = hgr ? 4 : 10;
+    for (int r = 0; r < reps; r++) launch();
     (void)hipEventRecord(b);
     (void)hipEventSynchronize(b);
     float ms;
     (void)hipEventElapsedTime(&ms, a, b);
-    ms /= 10;
+    ms /= reps;
     if (hipGetLastError() != hipSuccess) return 1;
     printf("D %d %.4f %.1f\n", waves, ms, (double)waves * n_ops * 512 / ms * 1e-6);
     return 0;
@@ -209,7 +220,7 @@ static int run_d_only(int waves)
 
 int main(int argc, char **argv)
 {
-    if (argc >= 3 && argv[1][0] == 'D') return run_d_only(atoi(argv[2]));
+    if (argc >= 3 && argv[1][0] == 'D') return run_d_only(atoi(argv[2]), argc >= 4 && argv[3][0] == 'H');
     const int n_ops = 183;
     const size_t nl = 4 * 32 * 256, nr = 4 * 64 * 512;
     uint32_t *left, *right, *sink;
@@ -287,7 +298,7 @@ int main(int argc, char **argv)
             (void)hipMalloc(&dense, (size_t)8 << 20);
             (void)hipMemset(dense, 1, (size_t)8 << 20);
             time("D: A + a dense-table gather for 1 byte in 64", [&] {
-                hipLaunchKernelGGL(pattern_u16_rare_kernel, dim3(waves), dim3(64), 5824, 0, (const uint16_t *)left,
+                hipLaunchKernelGGL(pattern_u16_rare_kernel<false>, dim3(waves), dim3(64), 5824, 0, (const uint16_t *)left,
                                    (const uint16_t *)right, dense, rows, n_ops, sink);
             });
             (void)hipFree(dense);
