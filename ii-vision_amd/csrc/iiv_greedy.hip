@@ -152,6 +152,9 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
     typedef typename std::conditional<MODE == kDHGR, uint32_t, unsigned long long>::type xmask_t;
     const xmask_t xm_e = reinterpret_cast<const xmask_t *>(nt.xmask)[(o_e << 6) + lane];
     const xmask_t xm_d = reinterpret_cast<const xmask_t *>(nt.xmask)[(o_d << 6) + lane];
+    // this stream's state as a raw buffer, for the stores of a step
+    const __amdgpu_buffer_rsrc_t rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void *)&S, 0, (int)sizeof(StreamState), 0x00020000);
+    const int up_off = (int)offsetof(StreamState, up) + is_aux * 8192 * 4, mem_off = (int)offsetof(StreamState, mem) + is_aux * 8192;
     // the allocation as a raw buffer (no bounds: every offset formed below lies inside it by construction)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)nt.base, 0, 0x7fffffff, 0x00020000);
     auto xmask_of = [&](xmask_t v, uint32_t part) -> xmask_t {
@@ -163,8 +166,6 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
     const uint8_t *tgt_frames = (MODE == kDHGR && is_aux ? frames_aux : frames_main) +
                                 ((size_t)blockIdx.x * n_frames + frame) * 8192;
     const uint4 *wd_rows = reinterpret_cast<const uint4 *>(S.wd);
-    int32_t *up = S.up[is_aux];
-    uint8_t *mem = S.mem[is_aux];
     const int wsel = lane >> 3;          // this lane's word inside a page's 8 bitmap words
     const int sh0 = (4 * lane) & 31;     // its 4 bits inside that word
     const uint32_t y0 = 4u * (uint32_t)lane;
@@ -237,19 +238,34 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
             return;
         }
         if (mt_idx + C + 2 >= 256) twist_now();
-        if (lane < 3) {
-            const int off = lane == 0 ? x : lane == 1 ? y1e : y2e;
-            const uint32_t val = lane == 0 ? 0u : lane == 1 ? v1 : v2;
-            up[p * 256 + off] = (int32_t)val;  // byte_pair_difference == store-table value (screen.py:383-398)
-            mem[p * 256 + off] = (uint8_t)c;
+        // lanes 0..2 = (x, 0), (y1e, v1), (y2e, v2): three scalars written into lanes of one register each
+        // (a `lane == k ? a : b` chain compiles to selects on loop-invariant lane masks, which the
+        // allocator then spills and reloads on every step)
+        uint32_t off_v = (uint32_t)x, val_v = 0u, k_v = 0u;
+        asm("v_writelane_b32 %0, %3, 1\n\tv_writelane_b32 %0, %4, 2\n\t"
+            "v_writelane_b32 %1, %5, 1\n\tv_writelane_b32 %1, %6, 2\n\t"
+            "v_writelane_b32 %2, %7, 2"
+            : "+v"(off_v), "+v"(val_v), "+v"(k_v)
+            : "s"(IIV_SGPR(y1e)), "s"(IIV_SGPR(y2e)), "s"(IIV_SGPR(v1)), "s"(IIV_SGPR(v2)), "s"(IIV_SGPR(f1)));
+        int ln = lane;
+        asm volatile("" : "+v"(ln));   // (keeps `lane < 3` from becoming one more hoisted, spilled mask)
+        if (ln < 3) {
+            const int off = (int)off_v;
+            const uint32_t val = val_v;
+            // (buffer stores into this stream's state: field offsets in scalar registers instead of
+            // 64-bit pointers added per lane)
+            const int loc = p * 256 + off;
+            __builtin_amdgcn_raw_buffer_store_b32(val, rsrc_s, loc * 4, up_off, 0);   // byte_pair_difference == store-table value (screen.py:383-398)
+            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)c, rsrc_s, loc, mem_off, 0);
             if (val == 0) {
                 atomicAnd(&nz[p * 8 + (off >> 5)], ~(1u << (off & 31)));
             } else {
-                const int k = lane == 2 ? f1 : 0;
+                const int k = (int)k_v;
                 const uint32_t nonce = mt_temper(mt[mt_idx + C + k]) >> 24;  // video.py:178
-                S.pushed[n_pushed + k] = ((2047u - val) << 21) | (nonce << 13) | ((uint32_t)p << 8) | (uint32_t)off;
+                __builtin_amdgcn_raw_buffer_store_b32(((2047u - val) << 21) | (nonce << 13) | ((uint32_t)p << 8) | (uint32_t)off, rsrc_s,
+                                                      (n_pushed + k) * 4, (int)offsetof(StreamState, pushed), 0);
             }
-            if (lane == 0) atomicOr(&pdone[p * 8 + (x >> 5)], 1u << (x & 31));
+            atomicOr(&pdone[p * 8 + (x >> 5)], 1u << (x & 31));   // (from all three lanes: idempotent)
         }
         // the opcode (page + 32, content, x, y1, y2, x) goes into lane (done - ob_base) of a
         // register pair; 64 of them leave in two coalesced stores
