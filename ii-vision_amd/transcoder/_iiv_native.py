@@ -472,11 +472,22 @@ class Encoder:
         assert frames_main.shape[0] == self.n_streams and frames_main.is_contiguous()
         segs = (Segment * len(segments))(*[Segment(int(f), int(a), int(r), int(k)) for (f, a, r, k) in segments])
         total = sum(int(s[3]) for s in segments)
+        need = self.n_streams * total * 6
         if ops_out is None:
             ops_out = torch.empty((self.n_streams, total, 6), dtype=torch.uint8, device="cuda")
+        else:
+            # iiv_encode packs stream s at byte s * total * 6 whatever the shape of the caller's buffer: a
+            # pre-allocated buffer may be larger than this call needs (calls of a Movie-paced driver differ
+            # in their opcode count), never smaller -- that would be a device write out of bounds
+            if not (ops_out.is_cuda and ops_out.dtype == torch.uint8 and ops_out.is_contiguous()):
+                raise ValueError("ops_out must be a contiguous CUDA uint8 tensor")
+            if ops_out.numel() < need:
+                raise ValueError("ops_out holds %d bytes, this call writes %d (n_streams * total opcodes * 6)"
+                                 % (ops_out.numel(), need))
         check(lib().iiv_encode(self._h, dptr(frames_main), dptr(frames_aux), int(n_frames), segs, len(segments),
                                dptr(ops_out), stream_ptr()))
-        return ops_out
+        # the rows as they were written: (n_streams, total, 6) over the front of the buffer
+        return ops_out.view(-1)[:need].view(self.n_streams, total, 6)
 
     def snapshot(self):
         check(lib().iiv_encoder_snapshot(self._h, stream_ptr()))

@@ -145,5 +145,120 @@ def main():
     print("make_data_tables: %.2f s" % (time.time() - t0))
 
 
+def implied_diff_matrix(bitmap_cls: Type[screen.Bitmap], lower: np.ndarray, samples: int = 60000, seed: int = 0):
+    """The 16x16 substitution-cost matrix a table was built from, recovered from its values alone.
+
+    A pair of equal-length pixel strings with no adjacent pair swapped (a[k] = b[k+1], a[k+1] = b[k]) has no
+    transposition to use, inserts and deletes cost 1e5, so its distance is the plain sum of the substitution
+    costs of its differing pixels (make_data_tables.py:92-108): every such table entry is one linear equation
+    in the 120 unknowns sub[u][v], u > v.  `lower` is the array a reference .npz holds (lower triangle).
+    Returns (matrix int64 (16,16) symmetric with -1 where no sampled pair involves the colour pair,
+    residual = max |equation error|: 0 means the table is consistent with the cost model)."""
+    bits = int(bitmap_cls.MASKED_BITS)
+    _, pix = native.pixel_strings(bitmap_cls.MODE)
+    pix = pix.cpu().numpy()                                   # (n_offsets, 2^bits, n_pixels)
+    rng = np.random.default_rng(seed)
+    n_off, n = pix.shape[0], 1 << bits
+    o = rng.integers(0, n_off, samples)
+    i = rng.integers(1, n, samples)
+    # neighbours in Hamming distance give short sums (well-conditioned); a few far pairs reach every colour pair
+    flips = np.where(rng.random(samples) < 0.7, 1 << rng.integers(0, bits, samples), rng.integers(1, n, samples))
+    j = i ^ flips
+    i, j = np.maximum(i, j), np.minimum(i, j)
+    keep = i != j
+    o, i, j = o[keep], i[keep], j[keep]
+    a, b = pix[o, i].astype(np.int64), pix[o, j].astype(np.int64)
+    swap = ((a[:, :-1] == b[:, 1:]) & (a[:, 1:] == b[:, :-1]) & (a[:, :-1] != a[:, 1:])).any(axis=1)
+    o, i, j, a, b = o[~swap], i[~swap], j[~swap], a[~swap], b[~swap]
+    hi, lo = np.maximum(a, b), np.minimum(a, b)
+    pair = np.where(hi != lo, hi * 16 + lo, -1)               # unknown index per pixel; -1: equal pixels cost 0
+    m = len(o)
+    A = np.zeros((m, 256), dtype=np.float64)
+    rows = np.repeat(np.arange(m), pair.shape[1])
+    ok = pair.reshape(-1) >= 0
+    np.add.at(A, (rows[ok], pair.reshape(-1)[ok]), 1.0)
+    y = lower[o, (i << bits) + j].astype(np.float64)
+    used = A.any(axis=0)
+    sol, *_ = np.linalg.lstsq(A[:, used], y, rcond=None)
+    residual = float(np.abs(A[:, used] @ np.rint(sol) - y).max()) if m else 0.0
+    out = np.full(256, -1, dtype=np.int64)
+    out[used] = np.rint(sol).astype(np.int64)
+    out = out.reshape(16, 16)
+    out = np.where(out >= 0, out, out.T)
+    out[np.arange(16), np.arange(16)] = 0
+    return out, residual
+
+
+def verify(data_dir: str = DATA_DIR, out=print) -> int:
+    """"Pin on arrival": compare the reference-format tables somebody already holds --
+    <data_dir>/<MODE>_palette_<id>_edit_distance.npz as the reference's make_data_tables.py wrote them with
+    the real colormath / weighted_levenshtein -- with the tables this build computes on the GPU, entry for
+    entry.  Those two packages are not available where this repo was built, so the table VALUES are the one
+    thing that could not be pinned to the reference; anybody with real tables closes
+    that gap by running
+        python make_data_tables.py --verify transcoder/data
+    On a mismatch the first differing (offset, i, j) is printed with both pixel strings and both values, and
+    the substitution-cost matrix the file was built from is recovered from the file itself
+    (implied_diff_matrix) and printed against this build's delta-E matrix: the entries that differ are
+    exactly where colormath's sRGB -> XYZ -> Lab constants differ from the restatement.  Until those are
+    fixed, Bitmap.LOAD_TABLE_FILES = True makes the encoder use the files (screen.Bitmap.edit_distances).
+    Returns the number of files that differ (missing files are reported and skipped)."""
+    torch = native._torch()
+    n_bad = 0
+    for p in palette.PALETTES.values():
+        dm = compute_diff_matrix(p)
+        sub = np.where(np.arange(16)[:, None] >= np.arange(16)[None, :], dm, dm.T)
+        for cls in (screen.HGRBitmap, screen.DHGRBitmap):
+            path = "%s/%s_palette_%d_edit_distance.npz" % (data_dir, cls.NAME, p.ID.value)
+            if not os.path.exists(path):
+                out("%s: missing, skipped" % path)
+                continue
+            theirs = np.load(path)["edit_distance"]
+            bits = int(cls.MASKED_BITS)
+            ours = native.build_table(cls.MODE, dm, symmetric=False)
+            if theirs.dtype != np.uint16 or tuple(theirs.shape) != tuple(ours.shape):
+                out("%s: DIFFERENT LAYOUT: dtype %s shape %s, expected uint16 %s" % (path, theirs.dtype, theirs.shape, tuple(ours.shape)))
+                n_bad += 1
+                continue
+            dev = torch.from_numpy(np.ascontiguousarray(theirs).view(np.int16)).cuda()
+            neq = dev != ours
+            n = int(neq.sum().item())
+            if n == 0:
+                out("%s: IDENTICAL to the GPU-built table (%d entries)" % (path, theirs.size))
+                continue
+            n_bad += 1
+            first = int(neq.view(-1).to(torch.uint8).argmax().item())
+            o, idx = divmod(first, 1 << (2 * bits))
+            i, j = idx >> bits, idx & ((1 << bits) - 1)
+            _, pix = native.pixel_strings(cls.MODE)
+            si = pixel_string(tuple(int(v) for v in pix[o, i].cpu().numpy()))
+            sj = pixel_string(tuple(int(v) for v in pix[o, j].cpu().numpy()))
+            out("%s: %d of %d entries DIFFER; first at (offset %d, i %d, j %d): strings %s / %s, file %d, GPU %d"
+                % (path, n, theirs.size, o, i, j, si, sj, int(theirs[o, idx]), int(table_value(ours, o, idx))))
+            implied, residual = implied_diff_matrix(cls, theirs)
+            if residual != 0:
+                out("   the file is NOT consistent with a substitution-cost model (max equation error %g): it was not "
+                    "built by make_data_tables' cost model, or is damaged" % residual)
+            for u in range(16):
+                for v in range(u):
+                    if implied[u, v] >= 0 and implied[u, v] != sub[u, v]:
+                        out("   implied dm[%d][%d] = %d (colours %s / %s), this build computes %d"
+                            % (u, v, implied[u, v], pixel_char(u), pixel_char(v), sub[u, v]))
+            fixed = np.where(implied >= 0, implied, sub).astype(np.int32)
+            again = native.build_table(cls.MODE, fixed, symmetric=False)
+            left = int((dev != again).sum().item())
+            out("   rebuilt on the GPU from the implied matrix: %d entries still differ%s"
+                % (left, "" if left else " -- the delta-E matrix is the whole difference"))
+            del dev, ours, again
+    return n_bad
+
+
+def table_value(table, o: int, idx: int) -> int:
+    return int(table[o, idx].item()) & 0xffff
+
+
 if __name__ == "__main__":
+    import sys
+    if len(sys.argv) >= 2 and sys.argv[1] == "--verify":
+        sys.exit(1 if verify(sys.argv[2] if len(sys.argv) > 2 else DATA_DIR) else 0)
     main()

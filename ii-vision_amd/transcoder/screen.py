@@ -262,7 +262,6 @@ class Bitmap:
     LOAD_TABLE_FILES = False   # True: load the .npz like the reference instead of rebuilding (see edit_distances)
 
     @classmethod
-    @functools.lru_cache(None)
     def edit_distances(cls, palette_id: pal.Palette) -> DeviceTable:
         """The symmetric edit-distance table for this mode and palette, in HBM.
 
@@ -272,9 +271,22 @@ class Bitmap:
         kept: transcoder/data/<NAME>_palette_<id>_edit_distance.npz (screen.py:347-350, relative
         to the cwd) is loaded and mirrored (screen.py:352-365, on the device) -- that is how a
         hand-made or third-party table is used.  Such a table has no diff matrix behind it, so
-        the encoder gathers its diff weights from the table and uses the workgroup kernel."""
-        if cls.LOAD_TABLE_FILES:
+        the encoder gathers its diff weights from the table and uses the workgroup kernel.
+
+        Cached like the reference's (functools.lru_cache there), but the flag is part of the key:
+        setting LOAD_TABLE_FILES after a first call yields the file's table, not the cached rebuild."""
+        return cls._edit_distances(palette_id, bool(cls.LOAD_TABLE_FILES))
+
+    @classmethod
+    @functools.lru_cache(None)
+    def _edit_distances(cls, palette_id: pal.Palette, from_file: bool) -> DeviceTable:
+        if from_file:
             data = "transcoder/data/%s_palette_%d_edit_distance.npz" % (cls.NAME, palette_id.value)
+            if not os.path.exists(data):
+                raise FileNotFoundError(
+                    "Bitmap.LOAD_TABLE_FILES is set but %s does not exist (the path is relative to the "
+                    "working directory %s, as in the reference); run make_data_tables.main() there or "
+                    "clear the flag to rebuild the table on the GPU" % (data, os.getcwd()))
             dist = np.load(data)["edit_distance"]
             table, store = native.load_table(cls.MODE, dist)
             return DeviceTable(cls.MODE, table, store, None)

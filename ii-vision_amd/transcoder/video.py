@@ -18,6 +18,13 @@ arrays it was handed, a reseeded or advanced `random` / `np.random` -- so code t
 points at which the reference's caller (movie.py) looks.
 `Video.STRICT_SYNC = True` restores the literal behaviour (every next() round-trips the
 whole state, global RNG states included), at about 1.5 k opcodes per second.
+Limitation of the default (lightweight) sync: WHILE a generator is live, the host's global
+`random` / `np.random` states are the stale pre-launch ones.  A caller that draws from or reseeds
+them between two next() calls of the same live generator (the reference's movie.py never does) and
+then starts another generator has its draws applied on top of that stale state, which rewinds the
+device's stream: the opcode stream then differs from the reference's.  Drawing or reseeding BETWEEN
+generators -- after the previous one was abandoned, exhausted or its state read -- is supported;
+for anything else set STRICT_SYNC.
 
 Budget: a generator may be abandoned after any next() (movie.py:94-109 does so at
 every frame and bank flip), and its side effects must then be exactly those of

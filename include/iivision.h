@@ -166,7 +166,13 @@ int iiv_check_split_diff_table(int mode, const int32_t dm[256], const uint16_t *
  * weights and store values into 11-bit fields): IIV_ERR_INVALID otherwise.
  * Initial state = Video.__init__ (video.py:21-62): blank screen, zero
  * priorities; both RNG streams seeded as random.seed(0) / np.random.seed(0)
- * until set with iiv_encoder_set_state. */
+ * until set with iiv_encoder_set_state.
+ * Threading / streams: ONE host thread and ONE hipStream_t per encoder.  The launch descriptors of
+ * iiv_encode / iiv_encode_streams live in a single device buffer per encoder that is safe only by
+ * stream order, so two asynchronous calls on different streams may overwrite descriptors the first
+ * call's kernels still read; iiv_encoder_set_option and the iiv_encoder_get_* / set_* state calls use
+ * the default stream and synchronise the device.  Different encoders are independent of each other
+ * (as different movie.Movie processes are in the reference). */
 int iiv_encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store_table,
                        const int32_t dm[256], int n_streams, iiv_encoder **out);
 void iiv_encoder_destroy(iiv_encoder *enc);

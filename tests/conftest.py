@@ -66,18 +66,26 @@ def native():
 
 
 class _DeviceTables:
-    def __init__(self, native, dms):
-        self.native, self.dms, self.cache, self.dm = native, dms, {}, {}
+    """Tables of the GPU tests, built on the device FROM THE DEVICE'S OWN delta-E matrix (cie2000_kernel):
+    RGB -> delta-E -> table -> encode runs on the HIP path end to end; the oracle's matrix is only the
+    checker the device's is compared with."""
+
+    def __init__(self, native, O, dms):
+        self.native, self.O, self.dms, self.cache, self.dm = native, O, dms, {}, {}
 
     def get(self, mode, pal=5):
         key = (mode, pal)
         if key not in self.cache:
-            self.cache[key] = (self.native.build_table(mode, self.dms[pal], True),
-                               self.native.build_store_table(mode, self.dms[pal]))
-            self.dm[key] = self.dms[pal]
+            f_dev, dm_dev = self.native.cie2000_matrix(self.O.PALETTE_RGB[pal])
+            f_orc, dm_orc = self.O.cie2000_matrix(self.O.PALETTE_RGB[pal])
+            assert np.array_equal(dm_dev, self.dms[pal]) and np.array_equal(dm_dev, dm_orc)
+            assert np.abs(f_dev - f_orc).max() < 1e-5          # north_star: float CIE2000 tables within 1e-5
+            self.cache[key] = (self.native.build_table(mode, dm_dev, True),
+                               self.native.build_store_table(mode, dm_dev))
+            self.dm[key] = dm_dev
         return self.cache[key]
 
 
 @pytest.fixture(scope="session")
-def device_tables(native, dms):
-    return _DeviceTables(native, dms)
+def device_tables(native, O, dms):
+    return _DeviceTables(native, O, dms)

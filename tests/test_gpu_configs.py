@@ -78,6 +78,62 @@ def test_long_movie_paced_clips(native, O, oracle_tables, device_tables, mode, k
                      kernel=kernel)
 
 
+@pytest.mark.parametrize("mode", [1, 0])
+def test_thousand_frame_clips(native, O, oracle_tables, device_tables, mode):
+    """BASELINE configs 3 / 4 at their full length: 1000-frame Movie-paced clips (490 000 opcodes each, ~2 680
+    generators and ~1 680 bank flips in DHGR), 50-frame driver steps with generators continued across calls --
+    every opcode, the final screens, priorities and both RNG positions against the oracle.  Clips 0-1 go through
+    the one-wave kernel of the big batches, and the same two clips through the eight-waves-per-clip team kernel."""
+    import concurrent.futures
+    import torch
+    n, nf = 2, 1000
+    fm, fa = stream_batch.synth_frames_torch(n, nf, mode == 1, seed=77 + mode, device="cpu")
+    fmh, fah = fm.numpy(), (fa.numpy() if fa is not None else None)
+    seeds = [(i + 1, 100 + i) for i in range(n)]
+    t, s = device_tables.get(mode, 5)
+    otab = oracle_tables.get(mode, 5)
+    fmd, fad = fm.cuda(), (fa.cuda() if fa is not None else None)
+    runs = {}
+    for kernel in (True, "team"):
+        b = stream_batch.StreamBatch(mode, t, s, n, seeds=seeds, dm=device_tables.dm[(mode, 5)])
+        b.enc.set_greedy_kernel(kernel)
+        got, segs = [], []
+        for start in range(0, nf, 50):
+            ops, sg = b.encode_frames(fmd, fad, 50)
+            got.append(ops.cpu().numpy())
+            segs += sg
+        b.enc.check()
+        runs[kernel] = (b, np.concatenate(got, axis=1), segs)
+    segs = runs[True][2]
+    assert segs == runs["team"][2]
+
+    def run(i):
+        v = O.Video(mode, otab, seed_py=seeds[i][0], seed_np=seeds[i][1])
+        out = []
+        for (fr, ia, restart, k) in segs:
+            if restart:
+                v.encode_frame(fmh[i, fr], fah[i, fr] if fah is not None else None, ia)
+            if k:
+                out.append(v.next(k))
+        return v, np.concatenate(out)
+
+    with concurrent.futures.ThreadPoolExecutor(n) as ex:     # (the oracle's C calls release the GIL)
+        res = list(ex.map(run, range(n)))
+    for kernel, (b, got, _) in runs.items():
+        for i, (v, exp) in enumerate(res):
+            assert got[i].shape == exp.shape and exp.shape[0] >= nf * 489
+            bad = np.nonzero((got[i] != exp).any(axis=1))[0]
+            assert len(bad) == 0, "%s kernel, clip %d: first differing opcode %d of %d" % (kernel, i, bad[0], len(exp))
+            assert (b.enc.get_state(native.STATE_MEM_MAIN, i) == v.memory(0)).all()
+            assert (b.enc.get_state(native.STATE_UP_MAIN, i) == v.update_priority(0)).all()
+            if mode == 1:
+                assert (b.enc.get_state(native.STATE_MEM_AUX, i) == v.memory(1)).all()
+                assert (b.enc.get_state(native.STATE_UP_AUX, i) == v.update_priority(1)).all()
+            cnt = b.enc.get_state(native.STATE_COUNTERS, i)
+            assert (int(cnt[0]), int(cnt[1])) == v.draws()
+        b.close()
+
+
 def test_main_py_defaults_long_clip(native, O, oracle_tables, device_tables):
     """main.py's own defaults: DHGR, NTSC, every_n_video_frames = 2 (980 opcodes per encoded frame)."""
     frames = _frames(1, 2, 120, 4100, ("coh", "iid"))

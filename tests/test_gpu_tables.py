@@ -182,8 +182,13 @@ def test_user_supplied_table_file(native, O, oracle_tables, device_tables, tmp_p
     os_dir.mkdir(parents=True)
     np.savez(str(os_dir / "DHGR_palette_5_edit_distance.npz"), edit_distance=custom_lower)
     monkeypatch.chdir(tmp_path)
+    # (the flag is part of the cache key -- a rebuild cached BEFORE the flag is set must not
+    # be what comes back after it, and a missing file is an error that names the path)
+    rebuilt = screen.DHGRBitmap.edit_distances(palette.Palette.NTSC)
+    assert rebuilt.dm is not None
     monkeypatch.setattr(screen.Bitmap, "LOAD_TABLE_FILES", True)
-    screen.DHGRBitmap.edit_distances.cache_clear()
+    with pytest.raises(FileNotFoundError, match="HGR_palette_5_edit_distance.npz"):
+        screen.HGRBitmap.edit_distances(palette.Palette.NTSC)
     try:
         tab = screen.DHGRBitmap.edit_distances(palette.Palette.NTSC)
         assert tab.dm is None
@@ -210,4 +215,42 @@ def test_user_supplied_table_file(native, O, oracle_tables, device_tables, tmp_p
         assert (got == np.concatenate(exp)).all()
         enc.close()
     finally:
-        screen.DHGRBitmap.edit_distances.cache_clear()
+        screen.DHGRBitmap._edit_distances.cache_clear()
+
+
+def test_verify_pins_a_users_tables_on_arrival(native, O, dms, tmp_path, capsys):
+    """make_data_tables.verify() compares the reference-format files somebody holds
+    with the GPU-built tables.  Stand-in for "real" colormath-built files: the DHGR NTSC table built from
+    a matrix with three entries moved (the size of the effect another sRGB matrix has: black <-> white
+    99 -> 100).  verify() must call the identical file identical, and for the moved one name the first
+    differing entry, recover exactly the moved matrix entries from the file's VALUES alone, and confirm
+    that a rebuild from the recovered matrix reproduces the file."""
+    import make_data_tables
+    import palette
+    import screen
+    d = tmp_path / "data"
+    d.mkdir()
+    dm = dms[5].copy()
+    moved = {(15, 0): 100, (9, 4): 59, (12, 3): int(dm[12, 3]) + 2}
+    for (u, v), val in moved.items():
+        dm[u, v] = dm[v, u] = val
+    t = native.table_to_numpy(native.build_table(1, dm, symmetric=False))
+    np.savez(str(d / "DHGR_palette_5_edit_distance.npz"), edit_distance=t)
+    same = native.table_to_numpy(native.build_table(1, dms[0], symmetric=False))
+    np.savez(str(d / "DHGR_palette_0_edit_distance.npz"), edit_distance=same)
+    lines = []
+    n_bad = make_data_tables.verify(str(d), out=lines.append)
+    text = "\n".join(lines)
+    assert n_bad == 1, text
+    assert "DHGR_palette_0_edit_distance.npz: IDENTICAL" in text
+    assert "HGR_palette_5_edit_distance.npz: missing, skipped" in text
+    assert "DHGR_palette_5_edit_distance.npz:" in text and "DIFFER; first at (offset" in text
+    for (u, v), val in moved.items():
+        assert "implied dm[%d][%d] = %d" % (u, v, val) in text, text
+    assert text.count("implied dm[") == len(moved), text
+    assert "0 entries still differ" in text
+    # the recovery alone, on an untouched table: the build's own matrix comes back, residual 0
+    implied, residual = make_data_tables.implied_diff_matrix(screen.DHGRBitmap, same)
+    assert residual == 0
+    known = implied >= 0
+    assert known.sum() >= 200 and (implied[known] == np.maximum(dms[0], dms[0].T)[known]).all()

@@ -105,6 +105,51 @@ __global__ __launch_bounds__(64) void pattern_u16_rare_kernel(const uint16_t *__
     sink[blockIdx.x * 64 + lane] = acc;
 }
 
+
+// Variant E: a workgroup of W one-wave streams shares the bank's whole L1 half (DHGR: 2 offsets x 32 x 256
+// u16 = 32 KiB), copied into LDS once per launch: four of the eight gathers become ds_read_u16, the other
+// four (R1) and the 1-in-64 dense load stay with the L1/TA.  LDS per workgroup = 32 KiB + W x per-stream bytes.
+template <int W>
+__global__ __launch_bounds__(64 * W) void pattern_shared_l1_kernel(const uint16_t *__restrict__ left, const uint16_t *__restrict__ right,
+                                                                   const uint16_t *__restrict__ dense, const uint4 *__restrict__ rows,
+                                                                   int n_ops, int n_streams, uint32_t *__restrict__ sink)
+{
+    extern __shared__ uint32_t lds[];   // [0, 8192): L1 of offsets 0 and 2; the rest: per-stream padding
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        const uint4 *src0 = reinterpret_cast<const uint4 *>(left), *src2 = reinterpret_cast<const uint4 *>(left + 2 * 32 * 256);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds);
+        for (int i = threadIdx.x; i < 1024; i += 64 * W) {
+            dst[i] = src0[i];
+            dst[1024 + i] = src2[i];
+        }
+    }
+    __syncthreads();
+    const int stream = blockIdx.x * W + wave;
+    if (stream >= n_streams) return;
+    const uint16_t *l16 = reinterpret_cast<const uint16_t *>(lds);
+    const uint4 *my = rows + (size_t)stream * n_ops * 64 + lane;
+    uint32_t acc = 0, h = stream * 2654435761u + 977u;
+    uint4 next = my[0];
+    for (int op = 0; op < n_ops; op++) {
+        const uint4 row = next;
+        if (op + 1 < n_ops) next = my[(size_t)(op + 1) * 64];
+        h = h * 1664525u + 1013904223u;
+        const uint32_t c = (h >> 16) & 127u;
+        const uint16_t *le = l16 + ((c & 31u) << 8), *lo = l16 + 8192 + ((c & 31u) << 8);
+        const uint16_t *re = right + (((0u << 6) | ((c >> 1) & 63u)) << 9), *ro = right + (((2u << 6) | ((c >> 1) & 63u)) << 9);
+        const uint16_t *de = dense + ((size_t)c << 13), *dd = dense + ((size_t)(256 + c) << 13);
+        uint32_t b0 = re[(row.x >> 9) & 0x1ffu], b1 = ro[(row.y >> 9) & 0x1ffu], b2 = re[(row.z >> 9) & 0x1ffu], b3 = ro[(row.w >> 9) & 0x1ffu];
+        uint32_t a0 = le[row.x & 255u], a1 = lo[row.y & 255u], a2 = le[row.z & 255u], a3 = lo[row.w & 255u];
+        if (((row.x >> 20) & 63u) == 0) a0 = de[row.x & 8191u];
+        if (((row.y >> 20) & 63u) == 0) a1 = dd[row.y & 8191u];
+        if (((row.z >> 20) & 63u) == 0) a2 = de[row.z & 8191u];
+        if (((row.w >> 20) & 63u) == 0) a3 = dd[row.w & 8191u];
+        acc += (a0 + b0) ^ (a1 + b1) ^ (a2 + b2) ^ (a3 + b3);
+    }
+    sink[stream * 64 + lane] = acc;
+}
+
 // Variant B: four 8-byte gathers (as if both halves of a byte's value sat side by side in one
 // 6 KiB slice per opcode): what a layout that serves a byte with ONE load would buy.
 __global__ __launch_bounds__(64) void pattern_x2_kernel(const uint2 *__restrict__ both, const uint4 *__restrict__ rows,
@@ -308,6 +353,37 @@ int main(int argc, char **argv)
             time("C: slices copied to LDS, gathers from LDS (13 waves per CU)", [&] {
                 hipLaunchKernelGGL(pattern_lds_kernel, dim3(waves), dim3(64), 5824 + 6144, 0, left, right, rows, n_ops, sink);
             });
+            {
+                uint16_t *dense2;
+                (void)hipMalloc(&dense2, (size_t)8 << 20);
+                (void)hipMemset(dense2, 1, (size_t)8 << 20);
+                // per-stream LDS: 5.8 KiB (today's), 3.8 KiB (bitmaps in registers)
+                (void)hipFuncSetAttribute((const void *)pattern_shared_l1_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void *)pattern_shared_l1_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void *)pattern_shared_l1_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void *)pattern_shared_l1_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                time("E: L1 half shared in LDS, W=8,  2 wg/CU (16 waves/CU, 5.8 KiB/stream)", [&] {
+                    hipLaunchKernelGGL(pattern_shared_l1_kernel<8>, dim3((waves + 7) / 8), dim3(512), 32768 + 8 * 5824, 0, (const uint16_t *)left,
+                                       (const uint16_t *)right, dense2, rows, n_ops, waves, sink);
+                });
+                time("E: L1 half shared in LDS, W=16, 1 wg/CU (16 waves/CU, 5.8 KiB/stream)", [&] {
+                    hipLaunchKernelGGL(pattern_shared_l1_kernel<16>, dim3((waves + 15) / 16), dim3(1024), 32768 + 16 * 5824, 0, (const uint16_t *)left,
+                                       (const uint16_t *)right, dense2, rows, n_ops, waves, sink);
+                });
+                time("E: L1 half shared in LDS, W=12, 2 wg/CU (24 waves/CU, 3.8 KiB/stream)", [&] {
+                    hipLaunchKernelGGL(pattern_shared_l1_kernel<12>, dim3((waves + 11) / 12), dim3(768), 32768 + 12 * 3840, 0, (const uint16_t *)left,
+                                       (const uint16_t *)right, dense2, rows, n_ops, waves, sink);
+                });
+                time("E: L1 half shared in LDS, W=10, 2 wg/CU (20 waves/CU, 4.7 KiB/stream)", [&] {
+                    hipLaunchKernelGGL(pattern_shared_l1_kernel<10>, dim3((waves + 9) / 10), dim3(640), 32768 + 10 * 4800, 0, (const uint16_t *)left,
+                                       (const uint16_t *)right, dense2, rows, n_ops, waves, sink);
+                });
+                time("E: L1 half shared in LDS, W=16, 1 wg/CU, then D with 16 waves/CU for comparison", [&] {
+                    hipLaunchKernelGGL(pattern_u16_rare_kernel<false>, dim3(waves), dim3(64), 10240, 0, (const uint16_t *)left,
+                                       (const uint16_t *)right, dense2, rows, n_ops, sink);
+                });
+                (void)hipFree(dense2);
+            }
             (void)hipFree(both);
         }
         (void)hipFree(left); (void)hipFree(right); (void)hipFree(rows); (void)hipFree(sink);

@@ -23,7 +23,7 @@ PASSES = [
 
 
 def short(name):
-    for k in ("greedy_wave_kernel", "greedy_kernel", "prologue_kernel"):
+    for k in ("greedy_wave_kernel", "greedy_lds_kernel", "greedy_team_kernel", "greedy_kernel", "prologue_kernel"):
         if k in name:
             return k + ("<DHGR>" if "<1" in name else "<HGR>" if "<0" in name else "")
     return None

@@ -31,7 +31,7 @@ def run(cmd, cwd):
 
 
 def short(name):
-    for k in ("greedy_wave_kernel", "greedy_kernel", "prologue_kernel", "table_kernel", "store_kernel"):
+    for k in ("greedy_wave_kernel", "greedy_lds_kernel", "greedy_team_kernel", "greedy_kernel", "prologue_kernel", "table_kernel", "store_kernel"):
         if k in name:
             return k + ("<DHGR>" if "<1" in name else "<HGR>" if "<0" in name else "")
     return None
@@ -45,7 +45,11 @@ def main():
     subprocess.run(["rm", "-rf", tmp])
     os.makedirs(tmp)
     bench = ["python3", os.path.join(ROOT, "bench.py")] + bench_args
-    run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp + "/stats", "--"] + bench, "/tmp")
+    r = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp + "/stats", "--"] + bench,
+                       cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, check=False)
+    bench_line = next((l for l in reversed(r.stdout.splitlines()) if l.startswith("{")), "")
+    if bench_line:
+        open(os.path.join(out, "bench_under_rocprof.json"), "w").write(bench_line + "\n")
     f = glob.glob(tmp + "/stats/*/*kernel_stats.csv")
     if f:
         rows = list(csv.reader(open(f[0])))
@@ -74,22 +78,41 @@ def main():
                 n = max(len(cnt[k][c]), 1)
                 g.write("   %-24s %.5g   (%d dispatches)\n" % (c, agg[k][c] / n, n))
             g.write("\n")
-    main_k = "greedy_wave_kernel<DHGR>" if "greedy_wave_kernel<DHGR>" in agg else None
-    if main_k:
+    # HBM bytes per greedy launch and PER STREAM, per mode, merged into OUTDIR/pmc_latest.json (bench.py multiplies
+    # by its own stream count, so roofline.traffic and algorithmic_bytes_per_launch share mode and streams)
+    streams = None
+    try:
+        streams = int(json.loads(bench_line)["config"]["streams_per_gpu"])
+    except Exception:
+        pass
+    latest_path = os.path.join(out, "pmc_latest.json")
+    try:
+        latest = json.load(open(latest_path))
+        if "DHGR" not in latest and "HGR" not in latest:
+            latest = {}
+    except Exception:
+        latest = {}
+    for mode in ("DHGR", "HGR"):
+        ks = [k for k in agg if k.startswith("greedy") and k.endswith("<%s>" % mode) and "FETCH_SIZE" in agg[k]]
+        if not ks or not streams:
+            continue
+        main_k = max(ks, key=lambda k: len(cnt[k]["FETCH_SIZE"]))
         a = agg[main_k]
         fetch = a["FETCH_SIZE"] / max(len(cnt[main_k]["FETCH_SIZE"]), 1)
         write = a["WRITE_SIZE"] / max(len(cnt[main_k]["WRITE_SIZE"]), 1)
-        json.dump({
+        latest[mode] = {
             "source": "tools/profile_summary.py (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
             "kernel": main_k,
             "bench_args": bench_args,
+            "streams": streams,
             "fetch_size_kib_per_launch_raw": fetch,
             "write_size_kib_per_launch_raw": write,
             "correction": "FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads, "
                           "MI355X_MICROARCH.md HBM section; uncalibrated for 2-byte gathers); WRITE_SIZE as reported",
-            "greedy_kernel_hbm_bytes_per_launch": (2 * fetch + write) * 1024,
-        }, open(os.path.join(out, "pmc_latest.json"), "w"), indent=1)
-
+            "greedy_hbm_bytes_per_launch": (2 * fetch + write) * 1024,
+            "greedy_hbm_bytes_per_launch_per_stream": (2 * fetch + write) * 1024 / streams,
+        }
+    json.dump(latest, open(latest_path, "w"), indent=1)
 
 if __name__ == "__main__":
     main()
