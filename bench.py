@@ -85,6 +85,11 @@ def parse_args(argv=None):
                     help="NTSC (main.py's default) or IIGS = the //gs RGB palette of BASELINE config 5")
     ap.add_argument("--coherent", action="store_true", help="S-coh input instead of S-iid")
     ap.add_argument("--img", action="store_true", help="S-img input (dithered moving bars) instead of S-iid")
+    ap.add_argument("--static", action="store_true",
+                    help="S-static input: converging content -- every frame is the previous one with 2 %% of its bytes redrawn "
+                         "(with --repeat N, every drawn frame is shown N times): the work list runs dry, the re-queued bag "
+                         "and the out-of-work padding are what gets timed")
+    ap.add_argument("--repeat", type=int, default=1, help="with --static: show every drawn frame this many times")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip make_data_tables / single-stream (profiling runs)")
     ap.add_argument("--cpu-frames", type=int, default=600, help="frames of stream 0 the CPU baseline encodes")
@@ -96,7 +101,7 @@ def parse_args(argv=None):
     ap.add_argument("--joint", action="store_true",
                     help="SURVEY 8(f4): choose every step's content byte jointly with its extra offsets "
                          "(IIV_CONTENT_JOINT; NOT the reference's output -- not the BASELINE workload)")
-    ap.add_argument("--greedy", choices=["auto", "wave", "workgroup"], default="auto",
+    ap.add_argument("--greedy", choices=["auto", "wave", "workgroup", "shared", "plain"], default="auto",
                     help="greedy kernel shape: one wave per stream, one 256-thread workgroup per stream, or auto")
     ap.add_argument("--full-sort", action="store_true", help="disable the prologue's prefix sort")
     ap.add_argument("--lds-pad", type=int, default=-1, help="tuning: extra LDS bytes per greedy wave (caps streams per CU)")
@@ -149,7 +154,8 @@ class GpuBackend:
         if a.img:
             self.fm, self.fa = self.sb.synth_frames_img(S, n_frames, self.dhgr, seed=seed)
         else:
-            self.fm, self.fa = self.sb.synth_frames_torch(S, n_frames, self.dhgr, seed=seed, coherent=a.coherent)
+            self.fm, self.fa = self.sb.synth_frames_torch(S, n_frames, self.dhgr, seed=seed, coherent=a.coherent or a.static,
+                                                          keep=0.98 if a.static else 0.9, repeat=a.repeat if a.static else 1)
         # the generators' temporaries go back to the driver: libiivision allocates with hipMalloc,
         # outside torch's caching allocator, and the clips leave it 40 GiB
         self.torch.cuda.empty_cache()
@@ -158,7 +164,7 @@ class GpuBackend:
         a = self.args
         b = self.sb.StreamBatch(self.mode, self.table, self.store, S, seeds=seeds, dm=self.dm, joint_content=a.joint)
         b.enc.set_diff_weights_mode("table" if a.dw_table else a.dw)
-        b.enc.set_greedy_kernel(None if a.greedy == "auto" else a.greedy == "wave")
+        b.enc.set_greedy_kernel({"auto": None, "wave": True, "workgroup": False}.get(a.greedy, a.greedy))
         if a.full_sort:
             b.enc.set_prefix_sort(False)
         if a.lds_pad >= 0:
@@ -173,10 +179,7 @@ class GpuBackend:
         region (steps x frames-per-step frames); the warm-up steps run on its first frames and the timed
         steps carry on from there and wrap around, so every frame of the clip is encoded exactly once inside
         the timed region and the clip count does not depend on --warmup."""
-        segs = self.batch.clock.segments(self.args.frames_per_step)
-        n_res = int(self.fm.shape[1])
-        self.last_ops = self.batch.enc.encode(self.fm, self.fa, [(f % n_res, a, r, k) for (f, a, r, k) in segs],
-                                              self.ops_buf)
+        self.last_ops, segs = self.batch.encode_frames(self.fm, self.fa, self.args.frames_per_step, self.ops_buf, loop=True)
         return segs
 
     def first_ops(self, segs):
@@ -264,7 +267,7 @@ def main(argv=None, backend_cls=GpuBackend):
             "workload": "%s %s palette %dx192 S-%s synthetic clips, %d frames each, %d independent clips per GPU, "
                         "Movie.encode control flow (490 opcodes/frame%s)%s" % (
                             args.mode, "//gs RGB (IIGS)" if args.palette == "IIGS" else "NTSC", 560 if dhgr else 280,
-                            "img" if args.img else "coh" if args.coherent else "iid",
+                            "img" if args.img else ("static (2 %% redrawn per frame, x%d)" % args.repeat) if args.static else "coh" if args.coherent else "iid",
                             args.steps * F, S, ", bank flip per 2 KiB" if dhgr else "",
                             "; JOINT content choice (f4, not the reference's output)" if args.joint else ""),
             "palette": args.palette,
@@ -529,7 +532,7 @@ def _single_stream(be, args):
     import torch
     fm, fa = be.sb.synth_frames_torch(1, 60, be.dhgr, seed=99, coherent=args.coherent)
     b = be.sb.StreamBatch(be.mode, be.table, be.store, 1, seeds=[(1, 1)], dm=be.dm, joint_content=args.joint)
-    b.enc.set_greedy_kernel(None if args.greedy == "auto" else args.greedy == "wave")
+    b.enc.set_greedy_kernel({"auto": None, "wave": True, "workgroup": False}.get(args.greedy, args.greedy))
     b.encode_frames(fm, fa, 10)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -590,11 +593,10 @@ def _emit_end_to_end(be, args, resident_fps):
     state = {"first_op": 0, "bytes": 0}
 
     def step(k):
-        _, segs = b.encode_frames(be.fm, be.fa, F, ops)
+        view, segs = b.encode_frames(be.fm, be.fa, F, ops, loop=True)   # (S, n, 6): the rows as they were packed
         n = sum(s[3] for s in segs)
         j = k & 1
         torch.cuda.current_stream().wait_event(done[j])          # the copy that last read dev[j] has finished
-        view = ops.view(-1)[: S * n * 6].view(S, n, 6)            # (streams are packed at the call's own opcode count)
         nb = native.emit_chunk_range(be.mode, state["first_op"], n)[1]
         out = dev[j][: S * nb].view(S, nb)                        # rows exactly as long as the slice: one contiguous copy
         native.emit_chunk(be.mode, view, state["first_op"], tick_addr, 0xBA72, out)

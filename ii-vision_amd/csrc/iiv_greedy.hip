@@ -41,29 +41,87 @@ namespace iiv {
 #define IIV_WAVE_OCC 6     // waves per SIMD the register allocation is held to
 #endif
 
-template <int MODE>
-__global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamState *__restrict__ states,
+// W = streams (waves) per workgroup.  W == 1: every table load goes to the L1/TA (both modes).
+// W > 1 (DHGR): the workgroup's streams all work on the same bank and share that bank's whole L1 half
+// (2 offsets x 32 content parts x 256 rows x 2 B = 32 KiB), copied into LDS once per launch: four of a
+// step's eight table loads become ds_read_u16.  What bounds a step is the TA's rate for divergent loads
+// (DESIGN.md 3.7); the LDS serves a random 2-byte gather in ~7 cycles where the TA needs 16-30
+// (tools/gather_ceiling.hip variant E: 0.74 ms per 12288-stream launch against 0.98).
+#ifndef IIV_SHARED_W
+#define IIV_SHARED_W 10
+#endif
+struct WaveLds {                // per stream: 4552 B
+    uint32_t nz[256];           // update_priority != 0
+    uint32_t pdone[256];        // byte already emitted as a primary (its diff weight counts as 0)
+    uint32_t mt[626];           // random's MT19937 state as a ring generated in place (see below) + a guard word
+};
+constexpr int kSharedL1Bytes = 2 * 32 * 256 * 2;           // DHGR: the L1 halves of one bank's two byte offsets
+constexpr int kSharedL1Zero = kSharedL1Bytes;              // a zero word behind them (excepted bytes, iiv_stream.h)
+constexpr int kSharedL1Pad = kSharedL1Bytes + 256;
+constexpr int kSharedW = IIV_SHARED_W;                              // 2 workgroups per CU: 2 x (32 KiB + 10 x 4.4 KiB)
+
+__device__ static inline WaveLds *own_wave_lds()
+{
+    __shared__ WaveLds w;
+    return &w;
+}
+
+template <int MODE, int W>
+__global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : (2 * W + 3) / 4 + (W % 4 ? 1 : 0)) void greedy_wave_kernel(StreamState *__restrict__ states,
                                                                    const uint8_t *__restrict__ frames_main,
                                                                    const uint8_t *__restrict__ frames_aux, int n_frames,
                                                                    const LaunchSeg *__restrict__ segs, int seg_stride,
                                                                    const NarrowTables nt,
-                                                                   uint8_t *__restrict__ ops_out, size_t ops_stride)
+                                                                   uint8_t *__restrict__ ops_out, size_t ops_stride, int n_streams, int bank, int *__restrict__ queue)
 {
     using T = SplitTraits<MODE>;
     constexpr uint32_t INF = 0xffffffffu;
     typedef uint32_t __attribute__((aligned(2))) u32_a2;
-    // LDS per stream: two 1 KiB bitmaps + 1.4 MT19937 blocks + a compaction scratch (5.7 KiB)
-    __shared__ uint32_t nz[256];        // update_priority != 0
-    __shared__ uint32_t pdone[256];     // byte already emitted as a primary (its diff weight counts as 0)
-    __shared__ uint32_t mt[624 + 256];  // random's current MT19937 block + the first 256 words of the next one
-    __shared__ uint32_t xw[64];         // compaction of a list window
+    static_assert(W == 1 || MODE == kDHGR, "the shared L1 half fits the LDS in DHGR only");
+    extern __shared__ uint32_t dyn_lds[];
+    const int lane0 = W == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
+    const int wave = W == 1 ? 0 : IIV_SGPR(threadIdx.x >> 6);
+    // W == 1: static (constant LDS offsets); W > 1: carved from dyn_lds behind the shared table
+    uint32_t *nz, *pdone, *mt;
+    if constexpr (W == 1) {
+        __shared__ uint32_t nz_s[256], pdone_s[256], mt_s[626];
+        nz = nz_s, pdone = pdone_s, mt = mt_s;
+    } else {
+        WaveLds *wl = reinterpret_cast<WaveLds *>(reinterpret_cast<char *>(dyn_lds) + kSharedL1Pad) + wave;
+        nz = wl->nz, pdone = wl->pdone, mt = wl->mt;
+    }
+    const char *const l1_lds = reinterpret_cast<const char *>(dyn_lds);
+    if (W > 1) {
+        // (`bank`: the host launches this kernel only when every stream that emits opcodes in this round works
+        // on the same bank, and says which)
+        const int o0 = byte_offset<MODE>(0, bank), o1 = byte_offset<MODE>(1, bank);
+        const uint4 *src0 = reinterpret_cast<const uint4 *>(nt.base + ((size_t)o0 << (T::kLeftCBits + T::kLeftRowBits + 1)));
+        const uint4 *src1 = reinterpret_cast<const uint4 *>(nt.base + ((size_t)o1 << (T::kLeftCBits + T::kLeftRowBits + 1)));
+        uint4 *dst = reinterpret_cast<uint4 *>(dyn_lds);
+        constexpr int kQuads = kSharedL1Bytes / 2 / 16;
+        for (int i = threadIdx.x; i < kQuads; i += 64 * W) {
+            dst[i] = src0[i];
+            dst[kQuads + i] = src1[i];
+        }
+        if (threadIdx.x < 64) dyn_lds[kSharedL1Zero / 4 + threadIdx.x] = 0u;
+        __syncthreads();
+    }
 
-    const int lane = threadIdx.x;
-    StreamState &S = states[blockIdx.x];
-    const LaunchSeg g = segs[(size_t)blockIdx.x * seg_stride];
+    // One stream from start to end (the whole body of the W == 1 kernel).  W > 1: the workgroups are PERSISTENT --
+    // as many as fit the GPU at once -- and every wave takes the next stream off a queue (one atomic counter per
+    // launch) as soon as it is done with one: a workgroup's LDS slot would otherwise idle until the slowest of its
+    // W streams ends, and a launch's last round would run partly empty (streams differ by +-20 % in how long a
+    // launch takes them; measured with s_memrealtime stamps: 13 of 16-20 wave slots per CU busy on average).
+    auto run_stream = [&](const int stream, const int lane) {
+    StreamState &S = states[stream];
+    const LaunchSeg g = segs[(size_t)stream * seg_stride];
     const int n_ops = IIV_SGPR(g.n_ops), is_aux = IIV_SGPR(g.is_aux), frame = IIV_SGPR(g.frame);
     if (n_ops <= 0) return;
-    uint8_t *out = ops_out + (size_t)blockIdx.x * ops_stride + (size_t)IIV_SGPR(g.ops_base) * 6;
+    if (W > 1 && is_aux != bank) {
+        if (lane == 0 && !S.error) S.error = kErrBankMix;
+        return;
+    }
+    uint8_t *out = ops_out + (size_t)stream * ops_stride + (size_t)IIV_SGPR(g.ops_base) * 6;
 
     if (!S.gen_active || S.error) {
         if (lane == 0 && !S.error) S.error = kErrNoGenerator;
@@ -74,62 +132,76 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         pdone[i] = S.pdone[i];
     }
     for (int i = lane; i < 624; i += 64) mt[i] = S.mt_py[i];
-    __syncthreads();
-    // A step reads nonces at mt_idx + t, t <= 256 (one per candidate, then <= 2 for the
-    // re-queued bytes), so it can run at most 256 words into the next block: only that much
-    // of it is kept ahead (`ahead`, computable from the current block alone plus itself).
-    // When the current block is used up, the head moves down, the other 368 words are
-    // generated in place (word i needs the old words i, i + 1 and the new word i - 227) and
-    // a new head is generated.
-    uint32_t *ahead = mt + 624;
-    auto gen_ahead = [&]() {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int i = lane + 64 * k;
-            if (k < 3 || i < 227) ahead[i] = mt[i + 397] ^ mt_mix(mt[i], mt[i + 1]);
+    if (W == 1) __syncthreads(); else wave_lds_sync();
+    // random's MT19937 state is a RING of 624 words generated in place, the way the reference generator
+    // itself does (mt[i] = mt[(i + 397) % 624] ^ twist(mt[i], mt[(i + 1) % 624]), ascending i), 64 words (one per
+    // lane) at a time and only over words that have been consumed: slots [mt_cons, mt_cons + mt_avail) mod 624
+    // hold the stream's next words.  A step reads nonces at mt_cons + t, t <= 257 (one per candidate, then <= 2
+    // for the re-queued bytes), so mt_avail >= 258 is established before every step (mt_topup: on average one
+    // batch of 156 words per opcode).  Slot 624 is a
+    // guard: a copy of the current lap's word 0, which is word 623's right-hand neighbour.
+    // The state in HBM stays in the standard form (a complete block + an index): at exit the current lap is
+    // completed if its tail has not been generated yet, and words of the NEXT lap that already replaced
+    // consumed words of this one are turned back by inverting the twist (mt_to_standard).
+    int mt_cons = IIV_SGPR(S.mt_py_idx), mt_avail;
+    uint32_t mt_w0 = 0;   // the lap's word 0 as it was before the next lap's word 0 replaced it
+    if (mt_cons >= 624) mt_cons = 0, mt_avail = 0;
+    else mt_avail = 624 - mt_cons;
+    if (lane == 0) mt[624] = mt[0];
+    wave_lds_sync();
+    // A batch = 156 consecutive words (a quarter of the ring: batches never straddle its end), three per lane on
+    // 52 lanes.  156 < 227, so no word of a batch depends on another one's new value: all reads precede all
+    // writes, and the six LDS reads of a lane are in flight together.
+    auto mt_gen = [&]() {
+        int pos = mt_cons + mt_avail;
+        pos = pos >= 624 ? pos - 624 : pos;          // 0, 156, 312 or 468
+        if (pos == 0) mt_w0 = (uint32_t)IIV_SGPR(mt[0]);
+        if (lane < 52) {
+            const int i0 = pos + lane, i1 = i0 + 52, i2 = i0 + 104;
+            const uint32_t a0 = mt[i0], b0 = mt[i0 + 1], a1 = mt[i1], b1 = mt[i1 + 1], a2 = mt[i2], b2 = mt[i2 + 1];
+            const uint32_t d0 = mt[i0 >= 227 ? i0 - 227 : i0 + 397], d1 = mt[i1 >= 227 ? i1 - 227 : i1 + 397],
+                           d2 = mt[i2 >= 227 ? i2 - 227 : i2 + 397];
+            const uint32_t v0 = d0 ^ mt_mix(a0, b0), v1 = d1 ^ mt_mix(a1, b1), v2 = d2 ^ mt_mix(a2, b2);
+            wave_lds_sync();   // every lane has read its old words before any lane overwrites one
+            mt[i0] = v0;
+            mt[i1] = v1;
+            mt[i2] = v2;
+            if (i0 == 0) mt[624] = v0;
         }
         wave_lds_sync();
-        {
-            const int i = 192 + lane;
-            if (i >= 227) ahead[i] = ahead[i - 227] ^ mt_mix(mt[i], mt[i + 1]);
-        }
-        wave_lds_sync();
+        mt_avail += 156;
     };
-    auto gen_rest = [&]() {
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const int i = 256 + 64 * k + lane;
-            if (k < 5 || i < 624) {
-                const uint32_t nv = i < 483 ? ahead[i - 227] : mt[i - 227];
-                const uint32_t nx = i == 623 ? ahead[0] : mt[i + 1];
-                const uint32_t v = nv ^ mt_mix(mt[i], nx);
-                wave_lds_sync();  // every lane has read its old words before any lane overwrites one
-                mt[i] = v;
+    auto mt_topup = [&]() {
+        while (mt_avail < 258) mt_gen();
+    };
+    auto mt_word = [&](int j) -> uint32_t { return mt[j >= 624 ? j - 624 : j]; };   // j < 2 * 624
+    auto mt_to_standard = [&]() {
+        while (mt_cons + mt_avail < 624) mt_gen();
+        const int g = mt_cons + mt_avail - 624;   // words of the next lap sitting in slots [0, g): 156 or 312
+        if (g <= 0) return;
+        // new[i] = dep ^ mix(old[i], old[i + 1]) with dep = old[i + 397] (i < 227) or new[i - 227]: y = new[i] ^ dep
+        // gives bit 31 of old[i] and bits 0..30 of old[i + 1].  Descending chunks: a chunk reads only lower slots.
+        for (int c = (g - 1) >> 6; c >= 0; c--) {
+            const int i = 64 * c + lane;
+            uint32_t comb = 0;
+            if (i < g) {
+                const uint32_t y = mt[i] ^ (i < 227 ? mt[i + 397] : mt[i - 227]);
+                const uint32_t odd = y >> 31, t = y ^ (odd ? 0x9908b0dfu : 0u);
+                comb = (t << 1) | odd;
             }
             wave_lds_sync();
+            if (i < g) mt[i] = comb;
+            wave_lds_sync();
         }
-    };
-    auto move_head = [&]() {
-#pragma unroll
-        for (int k = 0; k < 4; k++) mt[lane + 64 * k] = ahead[lane + 64 * k];
-        wave_lds_sync();
-    };
-    gen_ahead();
-    int mt_idx = IIV_SGPR(S.mt_py_idx);
-    if (mt_idx >= 624) {
-        move_head();
-        gen_rest();
-        gen_ahead();
-        mt_idx -= 624;
-    }
-    // after a block switch only words 0..255 of the current block are in place until twist_now()
-    bool twist_pending = false;
-    auto twist_now = [&]() {
-        if (twist_pending) {
-            gen_rest();
-            gen_ahead();
-            twist_pending = false;
+        for (int c = (g - 1) >> 6; c >= 0; c--) {
+            const int i = 64 * c + lane;
+            uint32_t w = mt_w0;
+            if (i < g && i > 0) w = (mt[i] & 0x80000000u) | (mt[i - 1] & 0x7fffffffu);
+            wave_lds_sync();
+            if (i < g) mt[i] = w;
+            wave_lds_sync();
         }
+        mt_avail = 624 - mt_cons;
     };
 
     const int n_sorted = IIV_SGPR(S.n_sorted);
@@ -164,7 +236,7 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         return (xmask_t)(((unsigned long long)hi << 32) | lo);
     };
     const uint8_t *tgt_frames = (MODE == kDHGR && is_aux ? frames_aux : frames_main) +
-                                ((size_t)blockIdx.x * n_frames + frame) * 8192;
+                                ((size_t)stream * n_frames + frame) * 8192;
     const uint4 *wd_rows = reinterpret_cast<const uint4 *>(S.wd);
     const int wsel = lane >> 3;          // this lane's word inside a page's 8 bitmap words
     const int sh0 = (4 * lane) & 31;     // its 4 bits inside that word
@@ -182,11 +254,12 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
     // slice's lines in L1)
     auto gather8 = [&](const uint4 &w, uint32_t c, Loaded &L) {
         // slice bases of this content byte, and where an excepted byte's loads go instead
-        const uint32_t sl_e = l1_e + (split_content_left<MODE>(c, 0) << (T::kLeftRowBits + 1));
-        const uint32_t sl_d = l1_d + (split_content_left<MODE>(c, 1) << (T::kLeftRowBits + 1));
+        // (W > 1: byte offsets into the LDS copy -- the bank's even-offset half, then its odd-offset half)
+        const uint32_t sl_e = (W == 1 ? l1_e : 0u) + (split_content_left<MODE>(c, 0) << (T::kLeftRowBits + 1));
+        const uint32_t sl_d = (W == 1 ? l1_d : (uint32_t)kSharedL1Bytes / 2) + (split_content_left<MODE>(c, 1) << (T::kLeftRowBits + 1));
         const uint32_t sr_e = r1_e + (split_content_right<MODE>(c, 0) << (T::kRightRowBits + 1));
         const uint32_t sr_d = r1_d + (split_content_right<MODE>(c, 1) << (T::kRightRowBits + 1));
-        const uint32_t zr_e = nt.zero_off - sl_e, zr_d = nt.zero_off - sl_d;
+        const uint32_t zr_e = (W == 1 ? nt.zero_off : (uint32_t)kSharedL1Zero) - sl_e, zr_d = (W == 1 ? nt.zero_off : (uint32_t)kSharedL1Zero) - sl_d;
         const uint32_t cd = (c & ((1u << CB) - 1)) << (BITS + 1);   // (a DHGR byte with bit 7 set is an error elsewhere)
         const uint32_t dr_e = ds_e + cd - sr_e, dr_d = ds_d + cd - sr_d;
         const xmask_t me = xmask_of(xm_e, narrow_mask_content<MODE>(c, 0)), md = xmask_of(xm_d, narrow_mask_content<MODE>(c, 1));
@@ -198,10 +271,17 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         narrow_offsets<MODE, 1>(wr[3], md, zr_d, dr_d, ol[3], orr[3]);
         // buffer loads: address = allocation + scalar slice offset + lane offset, so a slice base is
         // one 32-bit SGPR instead of a 64-bit pointer formed per opcode (-8 scalar instructions, +1 %)
-        L.gl[0] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)ol[0], (int)sl_e, 0);
-        L.gl[2] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)ol[2], (int)sl_e, 0);
-        L.gl[1] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)ol[1], (int)sl_d, 0);
-        L.gl[3] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)ol[3], (int)sl_d, 0);
+        if (W == 1) {
+            L.gl[0] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)ol[0], (int)sl_e, 0);
+            L.gl[2] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)ol[2], (int)sl_e, 0);
+            L.gl[1] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)ol[1], (int)sl_d, 0);
+            L.gl[3] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)ol[3], (int)sl_d, 0);
+        } else {
+            L.gl[0] = *reinterpret_cast<const uint16_t *>(l1_lds + (sl_e + ol[0]));
+            L.gl[2] = *reinterpret_cast<const uint16_t *>(l1_lds + (sl_e + ol[2]));
+            L.gl[1] = *reinterpret_cast<const uint16_t *>(l1_lds + (sl_d + ol[1]));
+            L.gl[3] = *reinterpret_cast<const uint16_t *>(l1_lds + (sl_d + ol[3]));
+        }
         L.gr[0] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)orr[0], (int)sr_e, 0);
         L.gr[2] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)orr[2], (int)sr_e, 0);
         L.gr[1] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)orr[1], (int)sr_d, 0);
@@ -229,7 +309,10 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
 
     // video.py:140-144, 170-187; screen.py:256-293.  Lanes 0..2 carry (x, y1, y2); a
     // missing secondary repeats the primary's stores.
-    auto apply = [&](int p, int x, uint32_t c, int y1, uint32_t nd1, int y2, uint32_t nd2, int C) {
+    // (phase B keeps per-lane minima of the re-queued bag up to date: `track` hands it the keys a step pushes)
+    uint32_t pkey_v = 0;          // lanes 1, 2: the keys pushed by the latest step (track only)
+    int push_f1 = 0, push_f2 = 0, push_base = 0;
+    auto apply = [&](auto track, int p, int x, uint32_t c, int y1, uint32_t nd1, int y2, uint32_t nd2, int C) {
         const uint32_t v1 = y1 >= 0 ? nd1 : 0u, v2 = y2 >= 0 ? nd2 : 0u;
         const int y1e = y1 >= 0 ? y1 : x, y2e = y2 >= 0 ? y2 : x;   // video.py:185-186
         const int f1 = v1 ? 1 : 0, f2 = v2 ? 1 : 0;
@@ -237,7 +320,6 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
             err = kErrPushedOverflow;
             return;
         }
-        if (mt_idx + C + 2 >= 256) twist_now();
         // lanes 0..2 = (x, 0), (y1e, v1), (y2e, v2): three scalars written into lanes of one register each
         // (a `lane == k ? a : b` chain compiles to selects on loop-invariant lane masks, which the
         // allocator then spills and reloads on every step)
@@ -261,9 +343,10 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
                 atomicAnd(&nz[p * 8 + (off >> 5)], ~(1u << (off & 31)));
             } else {
                 const int k = (int)k_v;
-                const uint32_t nonce = mt_temper(mt[mt_idx + C + k]) >> 24;  // video.py:178
-                __builtin_amdgcn_raw_buffer_store_b32(((2047u - val) << 21) | (nonce << 13) | ((uint32_t)p << 8) | (uint32_t)off, rsrc_s,
-                                                      (n_pushed + k) * 4, (int)offsetof(StreamState, pushed), 0);
+                const uint32_t nonce = mt_temper(mt_word(mt_cons + C + k)) >> 24;  // video.py:178
+                const uint32_t pkey = ((2047u - val) << 21) | (nonce << 13) | ((uint32_t)p << 8) | (uint32_t)off;
+                __builtin_amdgcn_raw_buffer_store_b32(pkey, rsrc_s, (n_pushed + k) * 4, (int)offsetof(StreamState, pushed), 0);
+                if (decltype(track)::value) pkey_v = pkey;
             }
             atomicOr(&pdone[p * 8 + (x >> 5)], 1u << (x & 31));   // (from all three lanes: idempotent)
         }
@@ -276,27 +359,36 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         asm("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
             : "+v"(ob0), "+v"(ob1)
             : "s"(IIV_SGPR(w0)), "s"(ob_lane), "s"(IIV_SGPR(w1)));
-        mt_idx += C + f1 + f2;
+        if (decltype(track)::value) push_f1 = f1, push_f2 = f2, push_base = n_pushed;
+        mt_cons += C + f1 + f2;
+        mt_avail -= C + f1 + f2;
+        mt_cons = mt_cons >= 624 ? mt_cons - 624 : mt_cons;
         draws += (uint32_t)(C + f1 + f2);
         n_pushed += f1 + f2;
         done++;
         if (done - ob_base == 64) flush_ops();
-        if (mt_idx >= 624) {
-            // the next block becomes the current one: its head moves down now, the rest of it
-            // and the new head are generated later, while table loads are in flight
-            // (twist_now), at the latest before a step reads past word 255
-            move_head();
-            mt_idx -= 624;
-            twist_pending = true;
-        }
     };
 
     // One greedy step on list entry e = page << 8 | offset | content << 16 with what was loaded
     // for it.  Returns false if the entry's priority is gone (video.py:130: nothing happens);
     // otherwise an opcode is emitted or err is set.
-    auto step = [&](uint32_t e, const Loaded &L) -> bool {
+    auto step = [&](auto track, uint32_t e, const Loaded &L) -> bool {
         const int p = (e >> 8) & 31, x = e & 255;
         const uint32_t c = (e >> 16) & 0xffu;  // video.py:134
+#ifdef IIV_EXP_SALU   // experiment: which issue pipe bounds the kernel?  N extra scalar / vector instructions per step
+        {
+            int dummy = (int)e;
+#pragma unroll
+            for (int q = 0; q < IIV_EXP_SALU; q++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(dummy));
+        }
+#endif
+#ifdef IIV_EXP_VALU
+        {
+            int dummy = lane;
+#pragma unroll
+            for (int q = 0; q < IIV_EXP_VALU; q++) asm volatile("v_add_u32 %0, 1, %0" : "+v"(dummy));
+        }
+#endif
         uint32_t nzw = nz[p * 8 + wsel], pdw = pdone[p * 8 + wsel];
         const uint32_t xword = (uint32_t)__builtin_amdgcn_readlane((int)nzw, (x >> 5) * 8);
         if (!((xword >> (x & 31)) & 1u)) return false;
@@ -363,15 +455,14 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
             // the reference's (delta, nonce, offset) heap order with every candidate's nonce
             // materialised: one random.getrandbits(8) per candidate in ascending offset
             // (video.py:290-293)
-            twist_now();
             uint32_t key[4];
             // candidates in lower lanes draw first, then this lane's bytes in ascending order
-            int run = mt_idx;
+            int run = mt_cons;
 #pragma unroll
             for (int q = 0; q < 4; q++) run += prefix_popc(cand[q]);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const uint32_t nonce = mt_temper(mt[run]) >> 24;
+                const uint32_t nonce = mt_temper(mt_word(run)) >> 24;
                 run += (int)((cand[r] >> lane) & 1ull);
                 const uint32_t k = ((uint32_t)((ke[r] >> kWdDwShift) + 2048) << 16) | (nonce << 8) | (y0 + r);
                 key[r] = ke[r] < 0 ? k : INF;  // video.py:159
@@ -400,7 +491,7 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
             nd1 = y1 >= 0 ? nd_of(y1) : 0u;
             nd2 = y2 >= 0 ? nd_of(y2) : 0u;
         }
-        apply(p, x, c, y1, nd1, y2, nd2, C);
+        apply(track, p, x, c, y1, nd1, y2, nd2, C);
         return true;
     };
 
@@ -408,7 +499,7 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
 #ifdef IIV_STAMPS
     // diagnostic build: shader clocks of this wave per pipeline stage, and its start / end time
     unsigned long long ph[4] = {0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memtime();
-    const unsigned long long wave_t0 = ph_t;
+    const unsigned long long wave_t0 = ph_t, wave_r0 = __builtin_amdgcn_s_memrealtime();
     int n_steps = 0;
 #define IIV_PHASE(i)                                                  \
     do {                                                              \
@@ -441,10 +532,10 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
             const unsigned long long mask = __ballot(v);
             n_dense = (int)__popcll(mask);
             qi = 0;
-            if (v) xw[prefix_popc(mask)] = (e & 0x00ffffffu) | ((uint32_t)lane << 24);
-            wave_lds_sync();
-            dense_e = xw[lane];
-            wave_lds_sync();
+            // compaction across lanes (no LDS memory): live entries go to lanes 0 .. n_dense - 1 in list order,
+            // the others fill the lanes behind them
+            const int dst = v ? prefix_popc(mask) : n_dense + prefix_popc(~mask);
+            dense_e = (uint32_t)__builtin_amdgcn_ds_permute(dst << 2, (int)((e & 0x00ffffffu) | ((uint32_t)lane << 24)));
             win_base = start;
             win_end = start + 64 < n_sorted ? start + 64 : n_sorted;
         };
@@ -514,12 +605,12 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
             row = row_of(eD);
             IIV_PHASE(0);   // wait for the row, issue eight table loads, take an entry, request its row
             if (!active) return false;
-            twist_now();  // (the MT19937 block generation hides behind the loads)
+            mt_topup();  // (the MT19937 generation hides behind the loads)
             IIV_PHASE(1);   // MT19937 block generation
 #ifdef IIV_STAMPS
             n_steps++;
 #endif
-            (void)step(eA, cur);
+            (void)step(std::false_type{}, eA, cur);
             IIV_PHASE(2);   // wait for the table words, score, apply
             head = hA;
             eA = eB;
@@ -541,43 +632,83 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         if (!eA && !err) head = n_sorted;  // every entry of the list has been processed or was dead
     }
 
-    // ---- phase B: the re-queued bag (video.py:124-131, 170-178), one entry at a time
-    while (done < n_ops && !err && !exhausted) {
-        if (--guard < 0) {
-            err = kErrGuard;
-            break;
-        }
-        if (truncated) {  // more initial entries exist than were ordered: host budget bug
-            err = kErrSortBudget;
-            break;
-        }
-        unsigned long long best = ~0ull;
+    // ---- phase B: the re-queued bag (video.py:124-131, 170-178), one entry at a time.
+    // Entry i of pushed[] belongs to sub-bag i % 64, and lane l keeps the smallest key of sub-bag l (and where it
+    // is) in a register: a pop is a wave minimum over that register; only the sub-bag it came from is read again
+    // (by all lanes, its <= 256 entries: one to four loads each, requested before the step and used after it);
+    // a push is a comparison with one lane's minimum.  (It was a scan of the whole bag per pop: on input that
+    // converges -- a static background -- every opcode comes from here, and the bag holds two entries per
+    // opcode emitted so far.)
+    if (done < n_ops && !err && !exhausted) {
+        uint32_t ck = INF, ci = 0;
         for (int i = lane; i < n_pushed; i += 64) {
-            unsigned long long k = ((unsigned long long)S.pushed[i] << 32) | (unsigned)i;
-            best = k < best ? k : best;
+            const uint32_t k = S.pushed[i];
+            ci = k < ck ? (uint32_t)i : ci;
+            ck = k < ck ? k : ck;
         }
+        // (gfx9 VOP3 reads one SGPR only; v_writelane may take its lane select from m0 besides)
+        auto writelane = [&](uint32_t &v, uint32_t val, int l) {
+            asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(IIV_SGPR(val)), "s"(IIV_SGPR(l)));
+        };
+        auto wave_min_u32 = [&](uint32_t v) -> uint32_t { return (uint32_t)wave_min_i32((int)(v ^ 0x80000000u)) ^ 0x80000000u; };
+        auto cache_merge = [&](uint32_t key, uint32_t idx) {   // scalars
+            const int sub = (int)(idx & 63u);
+            const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)ck, sub);
+            if (key < cur) {
+                writelane(ck, key, sub);
+                writelane(ci, idx, sub);
+            }
+        };
+        while (done < n_ops && !err) {
+            if (--guard < 0) {
+                err = kErrGuard;
+                break;
+            }
+            if (truncated) {  // more initial entries exist than were ordered: host budget bug
+                err = kErrSortBudget;
+                break;
+            }
+            const uint32_t bk = wave_min_u32(ck);
+            if (bk == INF) {
+                exhausted = 1;  // video.py:189
+                break;
+            }
+            const int wl = (int)__builtin_ctzll(__ballot(ck == bk));   // (equal keys are equal heap tuples: any of them)
+            const uint32_t bi = (uint32_t)__builtin_amdgcn_readlane((int)ci, wl);
+            if (lane == 0) S.pushed[bi] = INF;
+            // what is left of that sub-bag: entries wl + 64 j (the popped one excluded by its index, the store
+            // above is for later visits)
+            uint32_t rk[4], ridx[4];
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            unsigned long long other = __shfl_xor(best, d, 64);
-            best = other < best ? other : best;
+            for (int t = 0; t < 4; t++) {
+                ridx[t] = (uint32_t)wl + 64u * (uint32_t)(lane + 64 * t);
+                rk[t] = INF;
+                if (ridx[t] < (uint32_t)n_pushed && ridx[t] != bi) rk[t] = S.pushed[ridx[t]];
+            }
+            // pushed keys do not carry the content byte: it is the target byte of that offset
+            const uint32_t loc = bk & 0x1fffu;
+            const uint32_t c = (uint32_t)IIV_SGPR(tgt_frames[loc]);
+            const uint32_t e = loc | (c << 16);
+            const uint4 w = wd_rows[((e >> 8) & 31) * 64 + lane];
+            Loaded L;
+            gather8(w, c, L);
+            mt_topup();
+            push_f1 = push_f2 = 0;
+            (void)step(std::true_type{}, e, L);
+            // the sub-bag's new minimum, then what this step pushed
+            uint32_t mk = rk[0], mi = ridx[0];
+#pragma unroll
+            for (int t = 1; t < 4; t++) {
+                mi = rk[t] < mk ? ridx[t] : mi;
+                mk = rk[t] < mk ? rk[t] : mk;
+            }
+            const uint32_t nk = wave_min_u32(mk);
+            const uint32_t ni = (uint32_t)__builtin_amdgcn_readlane((int)mi, (int)__builtin_ctzll(__ballot(mk == nk)));
+            writelane(ck, nk, wl);
+            writelane(ci, ni, wl);
+            if (push_f1) cache_merge((uint32_t)__builtin_amdgcn_readlane((int)pkey_v, 1), (uint32_t)push_base);
+            if (push_f2) cache_merge((uint32_t)__builtin_amdgcn_readlane((int)pkey_v, 2), (uint32_t)(push_base + push_f1));
         }
-        const uint32_t bk = (uint32_t)IIV_SGPR((uint32_t)(best >> 32));
-        const uint32_t bi = (uint32_t)IIV_SGPR((uint32_t)best);
-        if (bk == INF) {
-            exhausted = 1;  // video.py:189
-            break;
-        }
-        if (lane == 0) S.pushed[bi] = INF;
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // that store precedes the next scan of pushed[]
-        // pushed keys do not carry the content byte: it is the target byte of that offset
-        const uint32_t loc = bk & 0x1fffu;
-        const uint32_t c = (uint32_t)IIV_SGPR(tgt_frames[loc]);
-        const uint32_t e = loc | (c << 16);
-        const uint4 w = wd_rows[((e >> 8) & 31) * 64 + lane];
-        Loaded L;
-        gather8(w, c, L);
-        twist_now();
-        (void)step(e, L);
     }
 
     flush_ops();
@@ -589,15 +720,15 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         pad_ops += (unsigned long long)(n_ops - done);
         done = n_ops;
     }
-    twist_now();
-    __syncthreads();
+    mt_to_standard();
+    if (W == 1) __syncthreads(); else wave_lds_sync();
     for (int i = lane; i < 256; i += 64) {
         S.nzbits[i] = nz[i];
         S.pdone[i] = pdone[i];
     }
     for (int i = lane; i < 624; i += 64) S.mt_py[i] = mt[i];
     if (lane == 0) {
-        S.mt_py_idx = mt_idx;
+        S.mt_py_idx = mt_cons;
         S.head = head;
         S.n_pushed = n_pushed;
         S.exhausted = exhausted;
@@ -612,19 +743,66 @@ __global__ __launch_bounds__(64, IIV_WAVE_OCC) void greedy_wave_kernel(StreamSta
         S.stamps[25] = __builtin_amdgcn_s_memtime();
         S.stamps[26] = (unsigned long long)done;
         S.stamps[27] = (unsigned long long)n_steps;   // list entries that went through the pipeline (emitted or found dead)
+        S.stamps[29] = wave_r0;   // start / end on the constant 100 MHz counter all XCDs share
+        S.stamps[30] = __builtin_amdgcn_s_memrealtime();
+        S.stamps[28] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 /* XCC_ID */) | (0 << 6) | (31 << 11)) << 32) |
+                       (unsigned)__builtin_amdgcn_s_getreg((4 /* HW_ID */) | (0 << 6) | (31 << 11));
 #endif
+    }
+    };   // run_stream
+
+    if constexpr (W == 1) {
+        run_stream((int)blockIdx.x, lane0);
+    } else {
+        for (;;) {
+            int next = 0;
+            if (lane0 == 0) next = atomicAdd(queue, 1);
+            next = IIV_SGPR(next);
+            if (next >= n_streams) break;
+            // (the lane index is laundered per stream: values derived from it would otherwise be hoisted out of this
+            // loop and held in registers across it -- 96 VGPRs instead of 78)
+            int lane_i = lane0;
+            asm volatile("" : "+v"(lane_i));
+            run_stream(next, lane_i);
+            wave_lds_sync();   // (this wave's LDS is reused by its next stream)
+        }
     }
 }
 #undef IIV_PHASE
 
 int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st)
 {
-    if (mode == kDHGR)
-        hipLaunchKernelGGL(greedy_wave_kernel<kDHGR>, dim3(a.n_streams), dim3(64), (size_t)a.lds_pad, st, a.states, a.frames_main,
-                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride);
+    if (mode == kDHGR && a.uniform_bank >= 0 && a.queue && (a.n_streams >= kSharedMinStreams || a.force_shared) && a.lds_pad == 0) {
+        // every stream of this round works on the same bank: eight streams per workgroup share that bank's L1 half in LDS
+        constexpr int kLds = kSharedL1Pad + kSharedW * (int)sizeof(WaveLds);
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hip_check(hipFuncSetAttribute((const void *)greedy_wave_kernel<kDHGR, kSharedW>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds),
+                          "greedy_wave_kernel LDS attribute"))
+                return IIV_ERR_HIP;
+            attr_set = true;
+        }
+        // persistent workgroups: as many as are resident at once (the queue hands out the streams)
+        static int resident = 0;
+        if (!resident) {
+            int per_cu = 0, dev = 0;
+            hipDeviceProp_t prop;
+            if (hip_check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)greedy_wave_kernel<kDHGR, kSharedW>, 64 * kSharedW, (size_t)kLds),
+                          "greedy_wave_kernel occupancy") ||
+                hip_check(hipGetDevice(&dev), "hipGetDevice") || hip_check(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties"))
+                return IIV_ERR_HIP;
+            resident = (per_cu > 0 ? per_cu : 1) * prop.multiProcessorCount;
+        }
+        const int wgs = (a.n_streams + kSharedW - 1) / kSharedW;
+        hipLaunchKernelGGL((greedy_wave_kernel<kDHGR, kSharedW>), dim3(wgs < resident ? wgs : resident), dim3(64 * kSharedW), (size_t)kLds, st,
+                           a.states, a.frames_main, a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank,
+                           a.queue);
+    } else if (mode == kDHGR)
+        hipLaunchKernelGGL((greedy_wave_kernel<kDHGR, 1>), dim3(a.n_streams), dim3(64), (size_t)a.lds_pad, st, a.states, a.frames_main,
+                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, (int *)nullptr);
     else
-        hipLaunchKernelGGL(greedy_wave_kernel<kHGR>, dim3(a.n_streams), dim3(64), (size_t)a.lds_pad, st, a.states, a.frames_main,
-                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride);
+        hipLaunchKernelGGL((greedy_wave_kernel<kHGR, 1>), dim3(a.n_streams), dim3(64), (size_t)a.lds_pad, st, a.states, a.frames_main,
+                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, (int *)nullptr);
     return hip_check(hipGetLastError(), "greedy_wave_kernel launch");
 }
 

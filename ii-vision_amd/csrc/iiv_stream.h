@@ -51,7 +51,7 @@ struct StreamState {
     unsigned long long stamps[32];  // diagnostic builds only (-DIIV_STAMPS): prologue s_memtime stamps [0,16), greedy phase cycles [16,24)
 };
 
-enum { kErrNone = 0, kErrHoles = 1, kErrNegative = 2, kErrPaletteBit = 3, kErrPushedOverflow = 4, kErrNoGenerator = 5, kErrGuard = 6, kErrSortBudget = 7 };
+enum { kErrNone = 0, kErrHoles = 1, kErrNegative = 2, kErrPaletteBit = 3, kErrPushedOverflow = 4, kErrNoGenerator = 5, kErrGuard = 6, kErrSortBudget = 7, kErrBankMix = 8 };
 
 // What one stream does in one launch round (iiv_encode builds these from the segment lists).
 // Shared schedule: every stream reads the same descriptor (stride 0); per-stream schedules:
@@ -274,7 +274,11 @@ struct GreedyArgs {
     uint8_t *ops_out;
     size_t ops_stride;       // bytes between the outputs of consecutive streams
     int lds_pad;             // extra dynamic LDS per stream (bytes): caps the streams resident per CU
+    int uniform_bank;        // 0 / 1: every stream that emits opcodes in this round works on this bank; -1: they differ
+    bool force_shared;       // the LDS-shared form below kSharedMinStreams too (tests)
+    int *queue;              // device: this launch's stream counter, zero (the LDS-shared form's persistent workgroups)
 };
+constexpr int kSharedMinStreams = 1024;   // below this the one-stream-per-workgroup form spreads over more CUs
 int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st);
 int launch_greedy_team(int mode, const GreedyArgs &a, hipStream_t st);   // iiv_team.hip
 

@@ -23,6 +23,7 @@ STATE_MEM_MAIN, STATE_MEM_AUX, STATE_UP_MAIN, STATE_UP_AUX = 0, 1, 2, 3
 STATE_RNG_PY, STATE_RNG_NP, STATE_OUT_OF_WORK, STATE_PACKED, STATE_COUNTERS = 4, 5, 6, 7, 8
 OPT_DIFF_WEIGHTS, DW_TABLE, DW_RECURRENCE, DW_SPLIT = 1, 0, 1, 2
 OPT_GREEDY_KERNEL, GREEDY_WAVE, GREEDY_WORKGROUP, GREEDY_AUTO, GREEDY_TEAM = 2, 0, 1, 2, 3
+GREEDY_WAVE_SHARED, GREEDY_WAVE_PLAIN = 4, 5
 OPT_PREFIX_SORT = 3
 OPT_GREEDY_LDS_PAD = 5
 OPT_CONTENT_CHOICE, CONTENT_TARGET, CONTENT_JOINT = 6, 0, 1
@@ -363,8 +364,10 @@ class Encoder:
 
     def set_greedy_kernel(self, wave_per_stream):
         """True: one wave per stream; False: one 256-thread workgroup; "team": eight waves per stream;
-        None: automatic."""
-        v = GREEDY_AUTO if wave_per_stream is None else GREEDY_TEAM if wave_per_stream == "team" else (
+        "shared" / "plain": one wave per stream with / without the bank's L1 table half shared in LDS by
+        the eight streams of a workgroup (True picks by batch size); None: automatic."""
+        v = {None: GREEDY_AUTO, "team": GREEDY_TEAM, "shared": GREEDY_WAVE_SHARED, "plain": GREEDY_WAVE_PLAIN}.get(
+            wave_per_stream if wave_per_stream is None or isinstance(wave_per_stream, str) else 0,
             GREEDY_WAVE if wave_per_stream else GREEDY_WORKGROUP)
         check(lib().iiv_encoder_set_option(self._h, OPT_GREEDY_KERNEL, v))
 

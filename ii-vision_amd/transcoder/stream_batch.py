@@ -123,10 +123,13 @@ def frame_budgets(mode_is_dhgr, n_frames, **kw):
     return clock.segments(n_frames)
 
 
-def synth_frames_torch(n_streams, n_frames, dhgr, seed, coherent=False, device="cuda"):
+def synth_frames_torch(n_streams, n_frames, dhgr, seed, coherent=False, device="cuda", keep=0.9, repeat=1):
     """SURVEY 8(d) synthetic memory maps, generated on the device: S-iid (every byte
     uniform in [0,128) DHGR / [0,256) HGR, screen holes zero) or S-coh (each byte
-    keeps its previous value with probability 0.9).  Returns (main, aux) uint8
+    keeps its previous value with probability `keep`, 0.9 in SURVEY 8d).  S-static (converging content, what
+    real video with a static background does: reference README.md:39) is S-coh with keep = 0.98, optionally
+    with every drawn frame shown `repeat` times in a row: the encoder's work list runs dry, it goes through its
+    re-queued bag and ends out of work (video.py:124-131, 189).  Returns (main, aux) uint8
     tensors (n_streams, n_frames, 32, 256); aux is None for HGR."""
     import torch
     g = torch.Generator(device=device)
@@ -138,8 +141,11 @@ def synth_frames_torch(n_streams, n_frames, dhgr, seed, coherent=False, device="
         t = torch.randint(0, hi, (n_streams, n_frames, 32, 256), dtype=torch.uint8, device=device, generator=g)
         if coherent:
             for f in range(1, n_frames):
-                keep = torch.rand((n_streams, 32, 256), device=device, generator=g) < 0.9
-                t[:, f] = torch.where(keep, t[:, f - 1], t[:, f])
+                if f % repeat:
+                    t[:, f] = t[:, f - 1]
+                    continue
+                k = torch.rand((n_streams, 32, 256), device=device, generator=g) < keep
+                t[:, f] = torch.where(k, t[:, f - 1], t[:, f])
         t[..., holes] = 0
         out.append(t)
     return out[0], (out[1] if dhgr else None)
@@ -222,12 +228,14 @@ class StreamBatch:
         self.enc.set_state_all(native.STATE_RNG_PY, py)
         self.enc.set_state_all(native.STATE_RNG_NP, nps)
 
-    def encode_frames(self, frames_main, frames_aux, n_video_frames, ops_out=None, max_ticks=None):
+    def encode_frames(self, frames_main, frames_aux, n_video_frames, ops_out=None, max_ticks=None, loop=False):
         """Advance every stream by n_video_frames input frames (targets are
         frames_*[:, clock.frame_number ...]) or max_ticks audio samples, whichever ends
-        first; returns (ops tensor, segments)."""
+        first; returns (ops tensor, segments).  loop=True: the clip repeats -- frame f of the movie is
+        frames_*[:, f % clip length] (the returned segments keep the movie's frame numbers)."""
         segs = self.clock.segments(n_video_frames, max_ticks=max_ticks)
-        ops = self.enc.encode(frames_main, frames_aux, segs, ops_out)
+        n = int(frames_main.shape[1])
+        ops = self.enc.encode(frames_main, frames_aux, [(f % n, a, r, k) for (f, a, r, k) in segs] if loop else segs, ops_out)
         return ops, segs
 
     def close(self):

@@ -46,7 +46,7 @@ for rnd in range(rounds):
             f = int(rng.integers(0, nf))
             ia = int(rng.integers(0, 2)) if mode == 1 else 0
         sched.append((f, ia, restart, k))
-    wave = (True, True, "team", "team", False)[int(rng.integers(0, 5))]
+    wave = (True, "shared", "shared", "team", "team", False)[int(rng.integers(0, 6))]
     recurrence = ("split", "split", True, True, False)[int(rng.integers(0, 5))]
     prefix = bool(rng.random() < 0.7)
     # one round in six: the joint content choice (f4) against the oracle's definition of it

@@ -19,6 +19,9 @@ def _frames(mode, n_streams, n_frames, seed, kinds):
         kind = kinds[i % len(kinds)]
         if kind == "img":
             fm, fa = stream_batch.synth_frames_img(1, n_frames, mode == 1, seed=seed + i, device="cpu")
+        elif kind.startswith("static"):      # S-static: 2 % of the bytes redrawn per frame; "static4": each frame shown 4 times
+            fm, fa = stream_batch.synth_frames_torch(1, n_frames, mode == 1, seed=seed + i, coherent=True, device="cpu",
+                                                     keep=0.98, repeat=4 if kind == "static4" else 1)
         else:
             fm, fa = stream_batch.synth_frames_torch(1, n_frames, mode == 1, seed=seed + i, coherent=kind == "coh",
                                                      device="cpu")
@@ -29,7 +32,8 @@ def _frames(mode, n_streams, n_frames, seed, kinds):
 
 
 def _run_and_compare(native, O, oracle_tables, device_tables, mode, pal, frames, seeds, step_frames, every_n=1,
-                     kernel=True):
+                     kernel=True, stats=None):
+    stats = [] if stats is None else stats      # per stream: (opcodes emitted, of which out-of-work padding)
     import torch
     n, nf = frames.shape[:2]
     t, s = device_tables.get(mode, pal)
@@ -63,12 +67,13 @@ def _run_and_compare(native, O, oracle_tables, device_tables, mode, pal, frames,
             assert (b.enc.get_state(native.STATE_UP_AUX, i) == v.update_priority(1)).all()
         cnt = b.enc.get_state(native.STATE_COUNTERS, i)
         assert (int(cnt[0]), int(cnt[1])) == v.draws()
+        stats.append((int(cnt[2]), int(cnt[3])))
     b.close()
     return got
 
 
 @pytest.mark.parametrize("mode", [1, 0])
-@pytest.mark.parametrize("kernel", [True, "team"])
+@pytest.mark.parametrize("kernel", [True, "team", "shared"])
 def test_long_movie_paced_clips(native, O, oracle_tables, device_tables, mode, kernel):
     """Configs 3 / 4: 210 frames (102 900 opcodes per stream, ~560 generators in DHGR) of an iid, a
     coherent and an image-like clip in one batch, 50 frames per iiv_encode call -- through the
@@ -82,8 +87,8 @@ def test_long_movie_paced_clips(native, O, oracle_tables, device_tables, mode, k
 def test_thousand_frame_clips(native, O, oracle_tables, device_tables, mode):
     """BASELINE configs 3 / 4 at their full length: 1000-frame Movie-paced clips (490 000 opcodes each, ~2 680
     generators and ~1 680 bank flips in DHGR), 50-frame driver steps with generators continued across calls --
-    every opcode, the final screens, priorities and both RNG positions against the oracle.  Clips 0-1 go through
-    the one-wave kernel of the big batches, and the same two clips through the eight-waves-per-clip team kernel."""
+    every opcode, the final screens, priorities and both RNG positions against the oracle.  The two clips go through
+    the one-wave kernel of the big batches (DHGR: its LDS-shared form) and through the eight-waves-per-clip team kernel."""
     import concurrent.futures
     import torch
     n, nf = 2, 1000
@@ -94,7 +99,7 @@ def test_thousand_frame_clips(native, O, oracle_tables, device_tables, mode):
     otab = oracle_tables.get(mode, 5)
     fmd, fad = fm.cuda(), (fa.cuda() if fa is not None else None)
     runs = {}
-    for kernel in (True, "team"):
+    for kernel in (("shared", "team") if mode == 1 else (True, "team")):   # (1000-frame clips through the plain one-wave form: HGR)
         b = stream_batch.StreamBatch(mode, t, s, n, seeds=seeds, dm=device_tables.dm[(mode, 5)])
         b.enc.set_greedy_kernel(kernel)
         got, segs = [], []
@@ -104,8 +109,8 @@ def test_thousand_frame_clips(native, O, oracle_tables, device_tables, mode):
             segs += sg
         b.enc.check()
         runs[kernel] = (b, np.concatenate(got, axis=1), segs)
-    segs = runs[True][2]
-    assert segs == runs["team"][2]
+    segs = runs["team"][2]
+    assert all(r[2] == segs for r in runs.values())
 
     def run(i):
         v = O.Video(mode, otab, seed_py=seeds[i][0], seed_np=seeds[i][1])
@@ -132,6 +137,24 @@ def test_thousand_frame_clips(native, O, oracle_tables, device_tables, mode):
             cnt = b.enc.get_state(native.STATE_COUNTERS, i)
             assert (int(cnt[0]), int(cnt[1])) == v.draws()
         b.close()
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("kernel", [True, "shared", "team", False])
+def test_converging_content(native, O, oracle_tables, device_tables, mode, kernel):
+    """S-static: content that converges (reference README.md:39: real video redraws the whole
+    screen 7.5-8 times a second, i.e. its work list does run dry).  Every frame is the previous one with 2 % of its
+    bytes redrawn (clip 1: each drawn frame shown four times), so after the first frames a generator goes through
+    its whole sorted list, then through the re-queued bag (video.py:124-131, 170-178), and ends out of work with
+    padding opcodes (video.py:189, 249-251) -- opcode streams and final state against the oracle."""
+    if kernel == "shared" and mode == 0:
+        pytest.skip("the LDS-shared form is DHGR only")
+    frames = _frames(mode, 3, 60, 4300 + mode, ("static", "static4", "static"))
+    stats = []
+    _run_and_compare(native, O, oracle_tables, device_tables, mode, 5, frames, [(51, 52), (53, 54), (55, 56)], 20,
+                     kernel=kernel, stats=stats)
+    for ops, pads in stats:
+        assert 0 < pads < ops      # the streams did run out of work, after real opcodes
 
 
 def test_main_py_defaults_long_clip(native, O, oracle_tables, device_tables):

@@ -52,7 +52,8 @@ def _next_draws(O, words, n, high):
 
 
 @pytest.mark.parametrize("recurrence,wave", [(True, True), (False, True), (True, False), (False, False), (True, "team"),
-                                             ("split", True), ("split", "team"), ("split", False)])
+                                             ("split", True), ("split", "team"), ("split", False), (True, "shared"),
+                                             (False, "shared")])
 def test_golden_runs(native, O, golden, device_tables, recurrence, wave):
     """recurrence=True: diff weights recomputed in the prologue; False: gathered from
     the HBM table; "split": combined from the two halves of the split diff-weight table.  wave=True: one wave per stream reading the split store table; False: one
@@ -110,7 +111,7 @@ def _oracle_run(O, oracle_tables, mode, pal, frames, sched, sp, sn):
     return v, np.concatenate(out)
 
 
-@pytest.mark.parametrize("mode,wave,prefix", [(1, True, True), (0, True, True), (1, False, True), (1, True, False),
+@pytest.mark.parametrize("mode,wave,prefix", [(1, True, True), (0, True, True), (1, False, True), (1, True, False), (1, "shared", True), (1, "shared", False),
                                               (0, False, False), (1, "team", True), (0, "team", False)])
 def test_batch_of_independent_streams(native, O, oracle_tables, device_tables, mode, wave, prefix):
     """12 streams with different data / seeds / coherence in ONE launch sequence,
@@ -195,7 +196,7 @@ def test_reference_asserts_are_reported(native, device_tables):
     enc.close()
 
 
-@pytest.mark.parametrize("mode,wave", [(1, True), (1, False), (0, True), (1, "team"), (0, "team")])
+@pytest.mark.parametrize("mode,wave", [(1, True), (1, False), (0, True), (1, "team"), (0, "team"), (1, "shared")])
 def test_image_like_streams(native, O, oracle_tables, device_tables, mode, wave):
     """S-img input (dithered moving bars): large coherent areas, many identical
     windows, so the two best deltas tie far more often than on random data -- the wave
@@ -226,7 +227,7 @@ def test_image_like_streams(native, O, oracle_tables, device_tables, mode, wave)
     enc.close()
 
 
-@pytest.mark.parametrize("mode,wave", [(1, True), (0, True), (1, False), (1, "team"), (0, "team")])
+@pytest.mark.parametrize("mode,wave", [(1, True), (0, True), (1, False), (1, "team"), (0, "team"), (1, "shared"), (0, "shared")])
 def test_per_stream_schedules(native, O, oracle_tables, device_tables, mode, wave):
     """iiv_encode_streams: every stream has its own movie clock (movie.py:16-54) -- different
     clip lengths, every_n_video_frames and frame rates in ONE batch, over two calls so that

@@ -48,7 +48,7 @@ def _oracle(O, oracle_tables, mode, frames1, sched, seed, init=None):
     return v, (np.concatenate(out) if out else np.zeros((0, 6), np.uint8))
 
 
-@pytest.mark.parametrize("wave", [True, False])
+@pytest.mark.parametrize("wave", [True, False, "shared"])
 def test_blank_target_on_blank_screen(native, O, device_tables, wave):
     """Nothing to do: no RNG draw, out_of_work at once, only padding opcodes."""
     frames = np.zeros((1, 1, 2, 32, 256), np.uint8)
@@ -58,7 +58,7 @@ def test_blank_target_on_blank_screen(native, O, device_tables, wave):
     assert enc.get_state(native.STATE_COUNTERS)[:2].tolist() == [0, 0]
 
 
-@pytest.mark.parametrize("mode,wave", [(1, True), (0, True), (1, False)])
+@pytest.mark.parametrize("mode,wave", [(1, True), (0, True), (1, False), (1, "shared")])
 def test_constant_target_degenerate_priorities(native, O, oracle_tables, device_tables, mode, wave):
     """Every byte has the same priority (one histogram bucket): the prefix selection
     must fall back to ordering everything; ties are broken by nonce/page/offset only."""
@@ -73,7 +73,7 @@ def test_constant_target_degenerate_priorities(native, O, oracle_tables, device_
     assert (enc.get_state(native.STATE_UP_MAIN) == v.update_priority(0)).all()
 
 
-@pytest.mark.parametrize("wave", [True, False])
+@pytest.mark.parametrize("wave", [True, False, "shared"])
 def test_few_changes_and_tiny_lists(native, O, oracle_tables, device_tables, wave):
     """Targets that differ from the screen in 0..70 bytes: lists shorter than one scan
     window, shorter than the opcode budget, exhaustion mid-segment, then padding."""
