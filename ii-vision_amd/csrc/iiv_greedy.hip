@@ -31,6 +31,8 @@
 // (2.7 % of the opcodes of the bench workload) it re-scores the entry with every nonce
 // materialised in reference order.  Exact either way.
 #include "iiv_host.h"
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 #include "iiv_stream.h"
 #include "iiv_wave.h"
@@ -48,17 +50,17 @@ namespace iiv {
 // (DESIGN.md 3.7); the LDS serves a random 2-byte gather in ~7 cycles where the TA needs 16-30
 // (tools/gather_ceiling.hip variant E: 0.74 ms per 12288-stream launch against 0.98).
 #ifndef IIV_SHARED_W
-#define IIV_SHARED_W 10
+#define IIV_SHARED_W 8
 #endif
-struct WaveLds {                // per stream: 4552 B
+struct WaveLds {                // per stream: 5568 B
     uint32_t nz[256];           // update_priority != 0
     uint32_t pdone[256];        // byte already emitted as a primary (its diff weight counts as 0)
-    uint32_t mt[626];           // random's MT19937 state as a ring generated in place (see below) + a guard word
+    uint32_t mt[624 + 256];     // random's current MT19937 block + the first 256 words of the next one
 };
 constexpr int kSharedL1Bytes = 2 * 32 * 256 * 2;           // DHGR: the L1 halves of one bank's two byte offsets
 constexpr int kSharedL1Zero = kSharedL1Bytes;              // a zero word behind them (excepted bytes, iiv_stream.h)
 constexpr int kSharedL1Pad = kSharedL1Bytes + 256;
-constexpr int kSharedW = IIV_SHARED_W;                              // 2 workgroups per CU: 2 x (32 KiB + 10 x 4.4 KiB)
+constexpr int kSharedW = IIV_SHARED_W;                              // 2 workgroups per CU: 2 x (32 KiB + 8 x 5.4 KiB)
 
 __device__ static inline WaveLds *own_wave_lds()
 {
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : (2 * W + 3) / 4 + (
     // W == 1: static (constant LDS offsets); W > 1: carved from dyn_lds behind the shared table
     uint32_t *nz, *pdone, *mt;
     if constexpr (W == 1) {
-        __shared__ uint32_t nz_s[256], pdone_s[256], mt_s[626];
+        __shared__ uint32_t nz_s[256], pdone_s[256], mt_s[624 + 256];
         nz = nz_s, pdone = pdone_s, mt = mt_s;
     } else {
         WaveLds *wl = reinterpret_cast<WaveLds *>(reinterpret_cast<char *>(dyn_lds) + kSharedL1Pad) + wave;
@@ -133,75 +135,61 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : (2 * W + 3) / 4 + (
     }
     for (int i = lane; i < 624; i += 64) mt[i] = S.mt_py[i];
     if (W == 1) __syncthreads(); else wave_lds_sync();
-    // random's MT19937 state is a RING of 624 words generated in place, the way the reference generator
-    // itself does (mt[i] = mt[(i + 397) % 624] ^ twist(mt[i], mt[(i + 1) % 624]), ascending i), 64 words (one per
-    // lane) at a time and only over words that have been consumed: slots [mt_cons, mt_cons + mt_avail) mod 624
-    // hold the stream's next words.  A step reads nonces at mt_cons + t, t <= 257 (one per candidate, then <= 2
-    // for the re-queued bytes), so mt_avail >= 258 is established before every step (mt_topup: on average one
-    // batch of 156 words per opcode).  Slot 624 is a
-    // guard: a copy of the current lap's word 0, which is word 623's right-hand neighbour.
-    // The state in HBM stays in the standard form (a complete block + an index): at exit the current lap is
-    // completed if its tail has not been generated yet, and words of the NEXT lap that already replaced
-    // consumed words of this one are turned back by inverting the twist (mt_to_standard).
-    int mt_cons = IIV_SGPR(S.mt_py_idx), mt_avail;
-    uint32_t mt_w0 = 0;   // the lap's word 0 as it was before the next lap's word 0 replaced it
-    if (mt_cons >= 624) mt_cons = 0, mt_avail = 0;
-    else mt_avail = 624 - mt_cons;
-    if (lane == 0) mt[624] = mt[0];
-    wave_lds_sync();
-    // A batch = 156 consecutive words (a quarter of the ring: batches never straddle its end), three per lane on
-    // 52 lanes.  156 < 227, so no word of a batch depends on another one's new value: all reads precede all
-    // writes, and the six LDS reads of a lane are in flight together.
-    auto mt_gen = [&]() {
-        int pos = mt_cons + mt_avail;
-        pos = pos >= 624 ? pos - 624 : pos;          // 0, 156, 312 or 468
-        if (pos == 0) mt_w0 = (uint32_t)IIV_SGPR(mt[0]);
-        if (lane < 52) {
-            const int i0 = pos + lane, i1 = i0 + 52, i2 = i0 + 104;
-            const uint32_t a0 = mt[i0], b0 = mt[i0 + 1], a1 = mt[i1], b1 = mt[i1 + 1], a2 = mt[i2], b2 = mt[i2 + 1];
-            const uint32_t d0 = mt[i0 >= 227 ? i0 - 227 : i0 + 397], d1 = mt[i1 >= 227 ? i1 - 227 : i1 + 397],
-                           d2 = mt[i2 >= 227 ? i2 - 227 : i2 + 397];
-            const uint32_t v0 = d0 ^ mt_mix(a0, b0), v1 = d1 ^ mt_mix(a1, b1), v2 = d2 ^ mt_mix(a2, b2);
-            wave_lds_sync();   // every lane has read its old words before any lane overwrites one
-            mt[i0] = v0;
-            mt[i1] = v1;
-            mt[i2] = v2;
-            if (i0 == 0) mt[624] = v0;
+    // A step reads nonces at mt_idx + t, t <= 256 (one per candidate, then <= 2 for the
+    // re-queued bytes), so it can run at most 256 words into the next block: only that much
+    // of it is kept ahead (`ahead`, computable from the current block alone plus itself).
+    // When the current block is used up, the head moves down, the other 368 words are
+    // generated in place (word i needs the old words i, i + 1 and the new word i - 227) and
+    // a new head is generated.
+    uint32_t *ahead = mt + 624;
+    auto gen_ahead = [&]() {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = lane + 64 * k;
+            if (k < 3 || i < 227) ahead[i] = mt[i + 397] ^ mt_mix(mt[i], mt[i + 1]);
         }
         wave_lds_sync();
-        mt_avail += 156;
+        {
+            const int i = 192 + lane;
+            if (i >= 227) ahead[i] = ahead[i - 227] ^ mt_mix(mt[i], mt[i + 1]);
+        }
+        wave_lds_sync();
     };
-    auto mt_topup = [&]() {
-        while (mt_avail < 258) mt_gen();
-    };
-    auto mt_word = [&](int j) -> uint32_t { return mt[j >= 624 ? j - 624 : j]; };   // j < 2 * 624
-    auto mt_to_standard = [&]() {
-        while (mt_cons + mt_avail < 624) mt_gen();
-        const int g = mt_cons + mt_avail - 624;   // words of the next lap sitting in slots [0, g): 156 or 312
-        if (g <= 0) return;
-        // new[i] = dep ^ mix(old[i], old[i + 1]) with dep = old[i + 397] (i < 227) or new[i - 227]: y = new[i] ^ dep
-        // gives bit 31 of old[i] and bits 0..30 of old[i + 1].  Descending chunks: a chunk reads only lower slots.
-        for (int c = (g - 1) >> 6; c >= 0; c--) {
-            const int i = 64 * c + lane;
-            uint32_t comb = 0;
-            if (i < g) {
-                const uint32_t y = mt[i] ^ (i < 227 ? mt[i + 397] : mt[i - 227]);
-                const uint32_t odd = y >> 31, t = y ^ (odd ? 0x9908b0dfu : 0u);
-                comb = (t << 1) | odd;
+    auto gen_rest = [&]() {
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int i = 256 + 64 * k + lane;
+            if (k < 5 || i < 624) {
+                const uint32_t nv = i < 483 ? ahead[i - 227] : mt[i - 227];
+                const uint32_t nx = i == 623 ? ahead[0] : mt[i + 1];
+                const uint32_t v = nv ^ mt_mix(mt[i], nx);
+                wave_lds_sync();  // every lane has read its old words before any lane overwrites one
+                mt[i] = v;
             }
             wave_lds_sync();
-            if (i < g) mt[i] = comb;
-            wave_lds_sync();
         }
-        for (int c = (g - 1) >> 6; c >= 0; c--) {
-            const int i = 64 * c + lane;
-            uint32_t w = mt_w0;
-            if (i < g && i > 0) w = (mt[i] & 0x80000000u) | (mt[i - 1] & 0x7fffffffu);
-            wave_lds_sync();
-            if (i < g) mt[i] = w;
-            wave_lds_sync();
+    };
+    auto move_head = [&]() {
+#pragma unroll
+        for (int k = 0; k < 4; k++) mt[lane + 64 * k] = ahead[lane + 64 * k];
+        wave_lds_sync();
+    };
+    gen_ahead();
+    int mt_idx = IIV_SGPR(S.mt_py_idx);
+    if (mt_idx >= 624) {
+        move_head();
+        gen_rest();
+        gen_ahead();
+        mt_idx -= 624;
+    }
+    // after a block switch only words 0..255 of the current block are in place until twist_now()
+    bool twist_pending = false;
+    auto twist_now = [&]() {
+        if (twist_pending) {
+            gen_rest();
+            gen_ahead();
+            twist_pending = false;
         }
-        mt_avail = 624 - mt_cons;
     };
 
     const int n_sorted = IIV_SGPR(S.n_sorted);
@@ -320,6 +308,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : (2 * W + 3) / 4 + (
             err = kErrPushedOverflow;
             return;
         }
+        if (mt_idx + C + 2 >= 256) twist_now();
         // lanes 0..2 = (x, 0), (y1e, v1), (y2e, v2): three scalars written into lanes of one register each
         // (a `lane == k ? a : b` chain compiles to selects on loop-invariant lane masks, which the
         // allocator then spills and reloads on every step)
@@ -343,7 +332,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : (2 * W + 3) / 4 + (
                 atomicAnd(&nz[p * 8 + (off >> 5)], ~(1u << (off & 31)));
             } else {
                 const int k = (int)k_v;
-                const uint32_t nonce = mt_temper(mt_word(mt_cons + C + k)) >> 24;  // video.py:178
+                const uint32_t nonce = mt_temper(mt[mt_idx + C + k]) >> 24;  // video.py:178
                 const uint32_t pkey = ((2047u - val) << 21) | (nonce << 13) | ((uint32_t)p << 8) | (uint32_t)off;
                 __builtin_amdgcn_raw_buffer_store_b32(pkey, rsrc_s, (n_pushed + k) * 4, (int)offsetof(StreamState, pushed), 0);
                 if (decltype(track)::value) pkey_v = pkey;
@@ -360,13 +349,19 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : (2 * W + 3) / 4 + (
             : "+v"(ob0), "+v"(ob1)
             : "s"(IIV_SGPR(w0)), "s"(ob_lane), "s"(IIV_SGPR(w1)));
         if (decltype(track)::value) push_f1 = f1, push_f2 = f2, push_base = n_pushed;
-        mt_cons += C + f1 + f2;
-        mt_avail -= C + f1 + f2;
-        mt_cons = mt_cons >= 624 ? mt_cons - 624 : mt_cons;
+        mt_idx += C + f1 + f2;
         draws += (uint32_t)(C + f1 + f2);
         n_pushed += f1 + f2;
         done++;
         if (done - ob_base == 64) flush_ops();
+        if (mt_idx >= 624) {
+            // the next block becomes the current one: its head moves down now, the rest of it
+            // and the new head are generated later, while table loads are in flight
+            // (twist_now), at the latest before a step reads past word 255
+            move_head();
+            mt_idx -= 624;
+            twist_pending = true;
+        }
     };
 
     // One greedy step on list entry e = page << 8 | offset | content << 16 with what was loaded
@@ -455,14 +450,15 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : (2 * W + 3) / 4 + (
             // the reference's (delta, nonce, offset) heap order with every candidate's nonce
             // materialised: one random.getrandbits(8) per candidate in ascending offset
             // (video.py:290-293)
+            twist_now();
             uint32_t key[4];
             // candidates in lower lanes draw first, then this lane's bytes in ascending order
-            int run = mt_cons;
+            int run = mt_idx;
 #pragma unroll
             for (int q = 0; q < 4; q++) run += prefix_popc(cand[q]);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const uint32_t nonce = mt_temper(mt_word(run)) >> 24;
+                const uint32_t nonce = mt_temper(mt[run]) >> 24;
                 run += (int)((cand[r] >> lane) & 1ull);
                 const uint32_t k = ((uint32_t)((ke[r] >> kWdDwShift) + 2048) << 16) | (nonce << 8) | (y0 + r);
                 key[r] = ke[r] < 0 ? k : INF;  // video.py:159
@@ -605,7 +601,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : (2 * W + 3) / 4 + (
             row = row_of(eD);
             IIV_PHASE(0);   // wait for the row, issue eight table loads, take an entry, request its row
             if (!active) return false;
-            mt_topup();  // (the MT19937 generation hides behind the loads)
+            twist_now();  // (the MT19937 block generation hides behind the loads)
             IIV_PHASE(1);   // MT19937 block generation
 #ifdef IIV_STAMPS
             n_steps++;
@@ -692,7 +688,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : (2 * W + 3) / 4 + (
             const uint4 w = wd_rows[((e >> 8) & 31) * 64 + lane];
             Loaded L;
             gather8(w, c, L);
-            mt_topup();
+            twist_now();
             push_f1 = push_f2 = 0;
             (void)step(std::true_type{}, e, L);
             // the sub-bag's new minimum, then what this step pushed
@@ -720,7 +716,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : (2 * W + 3) / 4 + (
         pad_ops += (unsigned long long)(n_ops - done);
         done = n_ops;
     }
-    mt_to_standard();
+    twist_now();
     if (W == 1) __syncthreads(); else wave_lds_sync();
     for (int i = lane; i < 256; i += 64) {
         S.nzbits[i] = nz[i];
@@ -728,7 +724,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : (2 * W + 3) / 4 + (
     }
     for (int i = lane; i < 624; i += 64) S.mt_py[i] = mt[i];
     if (lane == 0) {
-        S.mt_py_idx = mt_cons;
+        S.mt_py_idx = mt_idx;
         S.head = head;
         S.n_pushed = n_pushed;
         S.exhausted = exhausted;
@@ -772,7 +768,18 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : (2 * W + 3) / 4 + (
 
 int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st)
 {
-    if (mode == kDHGR && a.uniform_bank >= 0 && a.queue && (a.n_streams >= kSharedMinStreams || a.force_shared) && a.lds_pad == 0) {
+    static bool told = false;
+    if (!told && getenv("IIV_DEBUG_OCC")) {   // diagnostic: the runtime's own residency figures
+        told = true;
+        int n1 = 0, n0 = 0, nw = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, (const void *)greedy_wave_kernel<kDHGR, 1>, 64, (size_t)a.lds_pad);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n0, (const void *)greedy_wave_kernel<kHGR, 1>, 64, (size_t)a.lds_pad);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nw, (const void *)greedy_wave_kernel<kDHGR, kSharedW>, 64 * kSharedW,
+                                                           (size_t)(kSharedL1Pad + kSharedW * (int)sizeof(WaveLds)));
+        fprintf(stderr, "greedy_wave_kernel: workgroups per CU by hipOccupancyMaxActiveBlocksPerMultiprocessor: DHGR %d, HGR %d, shared (W = %d) %d\n",
+                n1, n0, kSharedW, nw);
+    }
+    if (mode == kDHGR && a.shared && a.uniform_bank >= 0 && a.queue && a.lds_pad == 0) {
         // every stream of this round works on the same bank: eight streams per workgroup share that bank's L1 half in LDS
         constexpr int kLds = kSharedL1Pad + kSharedW * (int)sizeof(WaveLds);
         static bool attr_set = false;

@@ -275,10 +275,10 @@ struct GreedyArgs {
     size_t ops_stride;       // bytes between the outputs of consecutive streams
     int lds_pad;             // extra dynamic LDS per stream (bytes): caps the streams resident per CU
     int uniform_bank;        // 0 / 1: every stream that emits opcodes in this round works on this bank; -1: they differ
-    bool force_shared;       // the LDS-shared form below kSharedMinStreams too (tests)
+    bool shared;             // IIV_GREEDY_WAVE_SHARED: the LDS-shared form wherever it applies (DHGR, one bank per round)
     int *queue;              // device: this launch's stream counter, zero (the LDS-shared form's persistent workgroups)
 };
-constexpr int kSharedMinStreams = 1024;   // below this the one-stream-per-workgroup form spreads over more CUs
+
 int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st);
 int launch_greedy_team(int mode, const GreedyArgs &a, hipStream_t st);   // iiv_team.hip
 

@@ -187,10 +187,12 @@ void iiv_encoder_destroy(iiv_encoder *enc);
 #define IIV_GREEDY_AUTO 2       /*   default: TEAM up to 768 streams, WAVE beyond (dm given at creation) */
 #define IIV_GREEDY_TEAM 3       /*   eight waves per stream score the next list entries concurrently and
                                  *   commit in order: the lowest latency for one or a few clips */
-#define IIV_GREEDY_WAVE_SHARED 4 /*   WAVE, and (DHGR) eight streams per workgroup share their bank's L1 half of the
-                                 *   narrow split store table in LDS in every launch whose streams all work on the same
-                                 *   bank, whatever the batch size (IIV_GREEDY_WAVE / AUTO do so from 1024 streams on) */
-#define IIV_GREEDY_WAVE_PLAIN 5  /*   WAVE with every table load from the L1/L2 (never the LDS-shared form) */
+#define IIV_GREEDY_WAVE_SHARED 4 /*   WAVE in its LDS-shared form (DHGR; measured, not the default): persistent workgroups of ten
+                                 *   streams share their bank's L1 half of the narrow split store table in LDS (four of a step's
+                                 *   eight table loads become ds_read_u16) in every launch whose streams all work on the same bank,
+                                 *   and take their streams off a queue.  Same output; 4 % slower than WAVE on an MI355X at 14336
+                                 *   clips, because the step is bound by instruction issue, not by its loads */
+#define IIV_GREEDY_WAVE_PLAIN 5  /*   = IIV_GREEDY_WAVE (kept for A/B command lines) */
 #define IIV_OPT_PREFIX_SORT 3    /* 1 (default): when a generator's opcode budget B is known
                                  * (another restart follows in the same iiv_encode call) and
                                  * 3B <= 2048, only that many highest priorities are ordered;
