@@ -120,6 +120,124 @@ __global__ __launch_bounds__(256) void ingest_kernel(int n, const uint8_t *__res
     }
 }
 
+// dither == IIV_DITHER_DIFFUSION: Floyd-Steinberg error diffusion (include/iivision.h).  A pixel needs the errors of
+// its left neighbour and of three pixels of the row above, so the rows of a frame advance as a skewed wavefront: one
+// thread per row, row y works on pixel t - 6 y at step t (six behind the row above: HGR fixes a screen byte's palette
+// bit from the accumulated error of up to four pixels ahead, which must have received everything the row above
+// sends them), one workgroup barrier per step, 140 + 6 * 191 steps per frame.  The accumulators of a row live in an
+// eight-slot ring in LDS (pixel k in slot k & 7): the row above writes slots k + 5 .. k + 7 while the row itself
+// reads k .. k + 3 and adds to k + 1.
+template <int MODE>
+__global__ __launch_bounds__(192) void ingest_diffusion_kernel(const uint8_t *__restrict__ rgb_frames, const uint8_t *__restrict__ palette,
+                                                               uint8_t *__restrict__ main_mem, uint8_t *__restrict__ aux_mem)
+{
+    constexpr int colour4[2][4] = {{0, 3, 12, 15}, {0, 6, 9, 15}};
+    __shared__ int ring[192][8][3];
+    __shared__ uint8_t patt[192][140];   // DHGR: colour value = dot quad; HGR: 2-dot pattern | palette bit << 2
+    __shared__ uint8_t pal[48];
+    const int y = threadIdx.x;
+    const size_t f = blockIdx.x;
+    const uint8_t *rgb = rgb_frames + f * (size_t)(192 * 280 * 3) + (size_t)y * 280 * 3;
+    if (y < 48) pal[y] = palette[y];
+    for (int i = 0; i < 24; i++) (&ring[y][0][0])[i] = 0;
+    __syncthreads();
+    auto value = [&](int k, IngestPixel &o) {
+        const uint8_t *p = rgb + 6 * k;
+        const int *a = ring[y][k & 7];
+        int v = ((int)p[0] + (int)p[3] + 1) / 2 + (a[0] >> 4);   // (>> 4 of a negative int: floor)
+        o.r = v < 0 ? 0 : v > 255 ? 255 : v;
+        v = ((int)p[1] + (int)p[4] + 1) / 2 + (a[1] >> 4);
+        o.g = v < 0 ? 0 : v > 255 ? 255 : v;
+        v = ((int)p[2] + (int)p[5] + 1) / 2 + (a[2] >> 4);
+        o.b = v < 0 ? 0 : v > 255 ? 255 : v;
+    };
+    int pb = 0;
+    for (int t = 0; t < 140 + 6 * 191; t++) {
+        const int k = t - 6 * y;
+        if (k >= 0 && k < 140) {
+            IngestPixel px;
+            int colour, pattern;
+            if (MODE == kDHGR) {
+                value(k, px);
+                int best = 0, be = 0x7fffffff;
+                for (int c = 0; c < 16; c++) {
+                    const int e = ingest_err(pal, c, px);
+                    if (e < be) {
+                        be = e;
+                        best = c;
+                    }
+                }
+                pattern = colour = best;
+            } else {
+                if (k == 0 || (2 * k) / 7 != (2 * k - 2) / 7) {   // the first dot of this pixel opens screen byte b
+                    const int b = (2 * k) / 7;
+                    long err0 = 0, err1 = 0;
+                    for (int kk = k; kk < 140 && (2 * kk) / 7 == b; kk++) {
+                        IngestPixel u;
+                        value(kk, u);
+                        const int w = (2 * kk + 1) / 7 == b ? 2 : 1;
+                        int b0 = 0x7fffffff, b1 = 0x7fffffff;
+                        for (int i = 0; i < 4; i++) {
+                            const int e0 = ingest_err(pal, colour4[0][i], u), e1 = ingest_err(pal, colour4[1][i], u);
+                            b0 = e0 < b0 ? e0 : b0;
+                            b1 = e1 < b1 ? e1 : b1;
+                        }
+                        err0 += (long)w * b0;
+                        err1 += (long)w * b1;
+                    }
+                    pb = err1 < err0 ? 1 : 0;
+                }
+                value(k, px);
+                int best = 0, be = 0x7fffffff;
+                for (int i = 0; i < 4; i++) {
+                    const int e = ingest_err(pal, colour4[pb][i], px);
+                    if (e < be) {
+                        be = e;
+                        best = i;
+                    }
+                }
+                pattern = best | (pb << 2);
+                colour = colour4[pb][best];
+            }
+            patt[y][k] = (uint8_t)pattern;
+            const int e[3] = {px.r - pal[3 * colour], px.g - pal[3 * colour + 1], px.b - pal[3 * colour + 2]};
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                ring[y][k & 7][c] = 0;   // the slot is pixel k + 8's from now on
+                if (k + 1 < 140) ring[y][(k + 1) & 7][c] += 7 * e[c];
+                if (y + 1 < 192) {
+                    if (k > 0) ring[y + 1][(k - 1) & 7][c] += 3 * e[c];
+                    ring[y + 1][k & 7][c] += 5 * e[c];
+                    if (k + 1 < 140) ring[y + 1][(k + 1) & 7][c] += e[c];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // the row's bytes (this thread wrote every pattern of its row itself)
+    const int base = y_to_offset(y);
+    if (MODE == kDHGR) {
+        for (int j = 0; j < 80; j++) {
+            int v = 0;
+            for (int i = 0; i < 7; i++) {
+                const int X = 7 * j + i;
+                v |= ((patt[y][X >> 2] >> (X & 3)) & 1) << i;
+            }
+            ((j & 1) ? main_mem : aux_mem)[f * 8192 + base + (j >> 1)] = (uint8_t)v;
+        }
+    } else {
+        for (int b = 0; b < 40; b++) {
+            // the byte's palette bit is that of the first pixel whose first dot lies in it
+            int v = ((patt[y][(7 * b + 1) >> 1] >> 2) & 1) << 7;
+            for (int i = 0; i < 7; i++) {
+                const int X = 7 * b + i;
+                v |= ((patt[y][X >> 1] >> (X & 1)) & 1) << i;
+            }
+            main_mem[f * 8192 + base + b] = (uint8_t)v;
+        }
+    }
+}
+
 int frames_to_memory_maps(int mode, const uint8_t palette_rgb[48], int n, const uint8_t *d_rgb, int dither, uint8_t *d_main,
                           uint8_t *d_aux, hipStream_t st)
 {
@@ -129,7 +247,13 @@ int frames_to_memory_maps(int mode, const uint8_t palette_rgb[48], int n, const 
     // screen holes (and everything else) start as zero, as bmp2dhr's files hold them
     if (!rc) rc = hip_check(hipMemsetAsync(d_main, 0, (size_t)n * 8192, st), "clear main");
     if (!rc && mode == kDHGR) rc = hip_check(hipMemsetAsync(d_aux, 0, (size_t)n * 8192, st), "clear aux");
-    if (!rc) {
+    if (!rc && dither == IIV_DITHER_DIFFUSION) {
+        if (mode == kDHGR)
+            hipLaunchKernelGGL(ingest_diffusion_kernel<kDHGR>, dim3((unsigned)n), dim3(192), 0, st, d_rgb, d_pal, d_main, d_aux);
+        else
+            hipLaunchKernelGGL(ingest_diffusion_kernel<kHGR>, dim3((unsigned)n), dim3(192), 0, st, d_rgb, d_pal, d_main, d_aux);
+        rc = hip_check(hipGetLastError(), "ingest_diffusion_kernel launch");
+    } else if (!rc) {
         const size_t total = (size_t)n * 192 * (mode == kDHGR ? 80 : 40);
         dim3 grid((unsigned)((total + 255) / 256));
         if (mode == kDHGR)
@@ -149,7 +273,7 @@ extern "C" int iiv_frames_to_memory_maps(int mode, const uint8_t palette_rgb[48]
                                          int dither, uint8_t *d_main, uint8_t *d_aux, void *stream)
 {
     if ((mode != IIV_HGR && mode != IIV_DHGR) || !palette_rgb || n_frames < 0 || !d_rgb || !d_main ||
-        (mode == IIV_DHGR && !d_aux) || dither < 0 || dither > 255)
+        (mode == IIV_DHGR && !d_aux) || dither < 0 || dither > IIV_DITHER_DIFFUSION)
         return iiv::set_error(IIV_ERR_INVALID, "iiv_frames_to_memory_maps: bad argument");
     if (n_frames == 0) return IIV_OK;
     return iiv::frames_to_memory_maps(mode, palette_rgb, n_frames, d_rgb, dither, d_main, d_aux, (hipStream_t)stream);

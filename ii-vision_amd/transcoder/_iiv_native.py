@@ -561,8 +561,12 @@ def emit_chunk(mode, ops, first_op, d_tick_addr, ack_addr, out, ticks=None, cons
 
 # ---- f3: frame ingest ---------------------------------------------------------------
 
+DITHER_DIFFUSION = 256   # IIV_DITHER_DIFFUSION: Floyd-Steinberg error diffusion instead of the ordered dither
+
+
 def frames_to_memory_maps(mode, palette_rgb, rgb, dither=0):
-    """rgb: CUDA uint8 (n, 192, 280, 3) -> (main, aux) CUDA uint8 (n, 32, 256); aux is None for HGR."""
+    """rgb: CUDA uint8 (n, 192, 280, 3) -> (main, aux) CUDA uint8 (n, 32, 256); aux is None for HGR.
+    dither: 0..255 = amplitude of the 4x4 ordered dither, DITHER_DIFFUSION = error diffusion."""
     torch = _torch()
     assert rgb.dtype == torch.uint8 and tuple(rgb.shape[1:]) == (192, 280, 3) and rgb.is_contiguous()
     n = int(rgb.shape[0])

@@ -48,7 +48,9 @@ class ArrayFrameGrabber(FrameGrabber):
             raise ValueError("frames must be uint8 (n, 192, 280, 3) (frame_grabber.py:75: 280x192 RGB)")
         self._rgb = rgb
         self.palette = palette
-        self.dither = int(dither)
+        # 0..255: amplitude of the 4x4 ordered dither; "diffusion" (= native.DITHER_DIFFUSION): Floyd-Steinberg error
+        # diffusion, the kind of dither the reference asks bmp2dhr for (D9, frame_grabber.py:80-82,106-108)
+        self.dither = native.DITHER_DIFFUSION if dither == "diffusion" else int(dither)
         self.input_frame_rate = input_frame_rate
         self.batch = int(batch)
 

@@ -355,10 +355,22 @@ int iiv_emit_stream(int mode, int n_streams, long n_ops, const uint8_t *d_ops, c
  *     smaller (ties to 0), then dot X = bit X & 1 of the 2-dot pattern of pixel X >> 1 under that
  *     palette bit (pattern bit 0 = the even dot column, colours.py:18-44);
  *   - bytes land at y_to_base_addr (screen.py:16-22); screen holes stay 0.
+ * dither == IIV_DITHER_DIFFUSION replaces the ordered dither by Floyd-Steinberg error diffusion (the reference calls
+ * bmp2dhr with D9, an error-diffusion dither: frame_grabber.py:80-82,106-108; bmp2dhr itself cannot be matched --
+ * it is not here).  Over the 140 x 192 colour pixels, rows top to bottom, pixels left to right, per channel:
+ *   value = clamp(mean of the two source pixels + floor(acc / 16), 0, 255); e = value - chosen colour;
+ *   acc[right] += 7 e, acc[below left] += 3 e, acc[below] += 5 e, acc[below right] += e (sixteenths; targets outside
+ *   the picture are dropped).  DHGR: the chosen colour is the nearest of the 16.  HGR: the palette bit of screen byte b
+ *   is fixed just before the first pixel whose first dot lies in b is quantised -- for both palette bits the nearest-
+ *   colour errors of the pixels whose first dot lies in b are summed (each weighted by the number of its dots in b:
+ *   2 or 1), their values taken with the error accumulated up to then; the smaller sum wins, ties to 0 -- and a pixel
+ *   takes the nearest of the four colours of the palette bit of the byte holding its first dot; bit 0 / 1 of its
+ *   pattern go to its first / second dot.
  * d_rgb: [n_frames][192][280][3] u8 (frame_grabber.py:75,100 resizes every frame to 280x192);
  * palette_rgb: 16 x 3 host bytes, row i = colour value i (palette.py:37-78); dither: amplitude
- * 0..255, 0 = none; d_main / d_aux: [n_frames][32][256] u8 memory maps (d_aux ignored for
+ * 0..255 of the ordered dither (0 = none), or IIV_DITHER_DIFFUSION; d_main / d_aux: [n_frames][32][256] u8 memory maps (d_aux ignored for
  * HGR).  Synchronises. */
+#define IIV_DITHER_DIFFUSION 256
 int iiv_frames_to_memory_maps(int mode, const uint8_t palette_rgb[48], int n_frames, const uint8_t *d_rgb,
                               int dither, uint8_t *d_main, uint8_t *d_aux, void *stream);
 

@@ -1254,11 +1254,113 @@ static int ingest_err(const uint8_t *pal, int colour, const int px[3])
 static const int kHgrColour[2][4] = {{0, 3, 12, 15}, {0, 6, 9, 15}};  /* black, violet|blue, green|orange, white */
 static const int kHgrPattern[4] = {0, 1, 2, 3};
 
+/* dither == ORC_DITHER_DIFFUSION (256): Floyd-Steinberg error diffusion over the 140 x 192 colour pixels, rows top
+ * to bottom, left to right, all integer (include/iivision.h): value = clamp(mean of the two source pixels +
+ * floor(acc / 16)); e = value - chosen colour; acc[right] += 7e, acc[below left] += 3e, acc[below] += 5e,
+ * acc[below right] += e.  HGR: the palette bit of screen byte b is fixed just before the first pixel whose first
+ * dot lies in b is quantised, by comparing, for both palette bits, the summed nearest-colour error of the pixels
+ * whose first dot lies in b (each weighted by how many of its dots lie in b), values taken with the error
+ * accumulated so far; ties to palette bit 0.  A pixel is quantised under the palette bit of the byte holding its
+ * first dot; its pattern's bit 0 / 1 go to its first / second dot. */
+static void frame_to_memory_map_diffusion(int mode, const uint8_t *pal, const uint8_t *rgb, uint8_t *main_mem, uint8_t *aux_mem)
+{
+    int acc[2][142][3];   /* [row parity][pixel + 1][channel], sixteenths */
+    memset(acc, 0, sizeof acc);
+    for (int y = 0; y < 192; y++) {
+        const int base = orc_y_to_base_addr(y, 0) - 0x2000;
+        int (*cur)[3] = acc[y & 1], (*nxt)[3] = acc[(y + 1) & 1];
+        memset(nxt, 0, sizeof acc[0]);
+        int pattern[140];   /* DHGR: colour value = dot quad; HGR: 2-dot pattern */
+        int pb = 0;
+        for (int k = 0; k < 140; k++) {
+            int v[3];
+#define ORC_VALUE(K, OUT)                                                                        \
+    do {                                                                                         \
+        const uint8_t *p_ = rgb + ((size_t)y * 280 + 2 * (K)) * 3;                               \
+        for (int c_ = 0; c_ < 3; c_++) {                                                         \
+            const int a_ = cur[(K) + 1][c_];                                                     \
+            int t_ = ((int)p_[c_] + (int)p_[3 + c_] + 1) / 2 + (a_ >= 0 ? a_ / 16 : -((-a_ + 15) / 16)); \
+            (OUT)[c_] = t_ < 0 ? 0 : t_ > 255 ? 255 : t_;                                        \
+        }                                                                                        \
+    } while (0)
+            int colour;
+            if (mode == ORC_DHGR) {
+                ORC_VALUE(k, v);
+                int best = 0, be = 0x7fffffff;
+                for (int c = 0; c < 16; c++) {
+                    const int e = ingest_err(pal, c, v);
+                    if (e < be) { be = e; best = c; }
+                }
+                pattern[k] = colour = best;
+            } else {
+                if ((2 * k) / 7 != (2 * k - 2) / 7 || k == 0) {   /* the first dot of this pixel opens screen byte b */
+                    const int b = (2 * k) / 7;
+                    long err[2] = {0, 0};
+                    for (int kk = k; kk < 140 && (2 * kk) / 7 == b; kk++) {
+                        int u[3];
+                        ORC_VALUE(kk, u);
+                        const int w = (2 * kk + 1) / 7 == b ? 2 : 1;
+                        for (int q = 0; q < 2; q++) {
+                            int be = 0x7fffffff;
+                            for (int i = 0; i < 4; i++) {
+                                const int e = ingest_err(pal, kHgrColour[q][i], u);
+                                if (e < be) be = e;
+                            }
+                            err[q] += (long)w * be;
+                        }
+                    }
+                    pb = err[1] < err[0] ? 1 : 0;
+                    main_mem[base + b] = (uint8_t)(pb << 7);
+                }
+                ORC_VALUE(k, v);
+                int best = 0, be = 0x7fffffff;
+                for (int i = 0; i < 4; i++) {
+                    const int e = ingest_err(pal, kHgrColour[pb][i], v);
+                    if (e < be) { be = e; best = i; }
+                }
+                pattern[k] = best;
+                colour = kHgrColour[pb][best];
+            }
+#undef ORC_VALUE
+            for (int c = 0; c < 3; c++) {
+                const int e = v[c] - pal[3 * colour + c];
+                cur[k + 2][c] += 7 * e;
+                nxt[k][c] += 3 * e;
+                nxt[k + 1][c] += 5 * e;
+                nxt[k + 2][c] += e;
+            }
+        }
+        if (mode == ORC_DHGR) {
+            for (int j = 0; j < 80; j++) {
+                int val = 0;
+                for (int i = 0; i < 7; i++) {
+                    const int X = 7 * j + i;
+                    val |= ((pattern[X >> 2] >> (X & 3)) & 1) << i;
+                }
+                ((j & 1) ? main_mem : aux_mem)[base + (j >> 1)] = (uint8_t)val;
+            }
+        } else {
+            for (int b = 0; b < 40; b++) {
+                int val = main_mem[base + b];
+                for (int i = 0; i < 7; i++) {
+                    const int X = 7 * b + i;
+                    val |= ((pattern[X >> 1] >> (X & 1)) & 1) << i;
+                }
+                main_mem[base + b] = (uint8_t)val;
+            }
+        }
+    }
+}
+
 void orc_frame_to_memory_map(int mode, const uint8_t palette_rgb[48], const uint8_t *rgb, int dither,
                              uint8_t *main_mem, uint8_t *aux_mem)
 {
     memset(main_mem, 0, 8192);
     if (mode == ORC_DHGR) memset(aux_mem, 0, 8192);
+    if (dither == ORC_DITHER_DIFFUSION) {
+        frame_to_memory_map_diffusion(mode, palette_rgb, rgb, main_mem, aux_mem);
+        return;
+    }
     for (int y = 0; y < 192; y++) {
         const int base = orc_y_to_base_addr(y, 0) - 0x2000;
         if (mode == ORC_DHGR) {

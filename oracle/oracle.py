@@ -278,6 +278,9 @@ def emit_stream(mode, ops, ticks, tick_addr, ack_addr, terminate_addr, max_bytes
     return out[:ln].copy()
 
 
+DITHER_DIFFUSION = 256   # ORC_DITHER_DIFFUSION: Floyd-Steinberg error diffusion instead of the ordered dither
+
+
 def frame_to_memory_map(mode, palette_rgb, rgb, dither=0):
     """(main, aux) (32,256) u8 memory maps of one 280x192 RGB frame (oracle's DEFINITION of f3)."""
     pal = np.ascontiguousarray(palette_rgb, dtype=np.uint8).reshape(48)

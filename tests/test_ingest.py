@@ -69,13 +69,80 @@ def test_ingest_definition_properties(O):
     assert (a == b).all()
 
 
+def _chosen_colours(O, mode, pal, main, aux):
+    """The palette colours a conversion chose, decoded back from the memory maps: (192, 140, 3) RGB.  DHGR: the
+    aligned dot quad of a colour pixel IS its colour value (colours.py:100-134); HGR: the 2-dot pattern of a pixel
+    under the palette bit of the byte holding its first dot (black, violet | blue, green | orange, white)."""
+    out = np.zeros((192, 140, 3), np.int64)
+    hgr = np.array([[0, 3, 12, 15], [0, 6, 9, 15]])
+    for y in range(192):
+        base = O.lib().orc_y_to_base_addr(y, 0) - 0x2000
+        if mode == 1:
+            row = np.zeros(80, np.int64)
+            row[0::2] = aux.reshape(-1)[base:base + 40]
+            row[1::2] = main.reshape(-1)[base:base + 40]
+            dots = ((row[:, None] >> np.arange(7)) & 1).reshape(-1)                 # 560 dots
+            val = (dots.reshape(140, 4) << np.arange(4)).sum(axis=1)
+        else:
+            row = main.reshape(-1)[base:base + 40].astype(np.int64)
+            dots = ((row[:, None] >> np.arange(7)) & 1).reshape(-1)                 # 280 dots
+            patt = dots[0::2] | (dots[1::2] << 1)
+            pb = (row >> 7)[(2 * np.arange(140)) // 7]
+            val = hgr[pb, patt]
+        out[y] = pal[val]
+    return out
+
+
+def _block_error(O, mode, pal, rgb, dither):
+    """Quality metric of a conversion: a dither trades pixel-exact colour for the right colour ON AVERAGE, so the
+    error is measured after a 4 x 4 block mean over the 140 x 192 colour pixels -- root mean square over the blocks
+    of the weighted RGB distance (the conversion's own 2 dr^2 + 4 dg^2 + 3 db^2) between the source's block mean
+    and the block mean of the colours chosen."""
+    main, aux = O.frame_to_memory_map(mode, pal, rgb, dither)
+    got = _chosen_colours(O, mode, np.asarray(pal, np.int64), main, aux).astype(np.float64)
+    src = (rgb[:, 0::2].astype(np.float64) + rgb[:, 1::2]) / 2
+    def blocks(a):
+        return a.reshape(48, 4, 35, 4, 3).mean(axis=(1, 3))
+    d = blocks(got) - blocks(src)
+    return float(np.sqrt((d ** 2 * np.array([2.0, 4.0, 3.0])).sum(axis=-1).mean()))
+
+
+def test_error_diffusion_beats_ordered_dither_on_average_colour(O):
+    """the reference asks its external tool for an error-diffusion dither (bmp2dhr D9,
+    frame_grabber.py:80-82); IIV_DITHER_DIFFUSION is this build's (Floyd-Steinberg, integer; bmp2dhr itself cannot be
+    matched here).  On smooth content -- a two-axis colour gradient, a grey ramp, a soft vignette -- its block-mean
+    colour error is below the ordered dither's and far below no dither's, in both modes; on content that already sits
+    on palette colours it changes nothing."""
+    pal = O.PALETTE_RGB[5]
+    y, x = np.mgrid[0:192, 0:280]
+    grad = np.stack([x * 255 // 279, y * 255 // 191, (x + y) * 255 // 470], -1).astype(np.uint8)
+    ramp = np.repeat((x * 255 // 279)[..., None], 3, -1).astype(np.uint8)
+    r2 = ((x - 140.0) / 140) ** 2 + ((y - 96.0) / 96) ** 2
+    vign = np.clip(np.stack([230 - 120 * r2, 140 - 60 * r2, 90 + 100 * r2], -1), 0, 255).astype(np.uint8)
+    report = []
+    for mode in (1, 0):
+        for name, img in (("gradient", grad), ("grey ramp", ramp), ("vignette", vign)):
+            e_none = _block_error(O, mode, pal, img, 0)
+            e_ord = _block_error(O, mode, pal, img, 32)
+            e_dif = _block_error(O, mode, pal, img, O.DITHER_DIFFUSION)
+            report.append("%s %-9s none %6.1f  ordered(32) %6.1f  diffusion %6.1f" % ("DHGR" if mode else "HGR ", name, e_none, e_ord, e_dif))
+            assert e_dif < e_ord < e_none, report[-1]
+            assert e_dif < 0.6 * e_none, report[-1]
+    print("\nblock-mean colour error (rms, weighted RGB):\n" + "\n".join(report))
+    solid = np.tile(np.asarray(pal[12], np.uint8), (192, 280, 1))
+    for mode in (1, 0):
+        a = O.frame_to_memory_map(mode, pal, solid, 0)
+        b = O.frame_to_memory_map(mode, pal, solid, O.DITHER_DIFFUSION)
+        assert (a[0] == b[0]).all() and (mode == 0 or (a[1] == b[1]).all())
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", [1, 0])
 @pytest.mark.parametrize("pal_id", [5, 0])
 def test_ingest_kernel_equals_definition(native, O, mode, pal_id):
     import torch
     rgb = _test_frames(9, 2 + mode)
-    for dither in (0, 32, 255):
+    for dither in (0, 32, 255, native.DITHER_DIFFUSION):
         main, aux = native.frames_to_memory_maps(mode, O.PALETTE_RGB[pal_id], torch.from_numpy(rgb).cuda(), dither)
         main = main.cpu().numpy()
         aux = aux.cpu().numpy() if aux is not None else None
