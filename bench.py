@@ -399,6 +399,9 @@ def _roofline_objects(be, args, prof, op_count, seg_count, S, elapsed, live_ceil
         "launches": prof["greedy_launches"],
         "lookups_per_s": float(op_count) * S * 256 / (g_ms * 1e-3) if g_ms > 0 else 0.0,
     }
+    if getattr(args, "static", False):
+        out["roofline"]["note"] = ("S-static: most opcodes are out-of-work padding (video.py:249-251), written 64 at a time without "
+                                   "any scoring; they are counted at 534 B like real opcodes here, so achieved / frac overstate the kernel")
     if be.uses_wave_kernel():
         # The bound that actually holds this kernel is not HBM but the L1's rate for divergent loads.
         # Its yardstick is a measurement, not a datasheet figure: tools/gather_ceiling.hip runs the

@@ -370,20 +370,6 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : (2 * W + 3) / 4 + (
     auto step = [&](auto track, uint32_t e, const Loaded &L) -> bool {
         const int p = (e >> 8) & 31, x = e & 255;
         const uint32_t c = (e >> 16) & 0xffu;  // video.py:134
-#ifdef IIV_EXP_SALU   // experiment: which issue pipe bounds the kernel?  N extra scalar / vector instructions per step
-        {
-            int dummy = (int)e;
-#pragma unroll
-            for (int q = 0; q < IIV_EXP_SALU; q++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(dummy));
-        }
-#endif
-#ifdef IIV_EXP_VALU
-        {
-            int dummy = lane;
-#pragma unroll
-            for (int q = 0; q < IIV_EXP_VALU; q++) asm volatile("v_add_u32 %0, 1, %0" : "+v"(dummy));
-        }
-#endif
         uint32_t nzw = nz[p * 8 + wsel], pdw = pdone[p * 8 + wsel];
         const uint32_t xword = (uint32_t)__builtin_amdgcn_readlane((int)nzw, (x >> 5) * 8);
         if (!((xword >> (x & 31)) & 1u)) return false;
@@ -768,8 +754,9 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : (2 * W + 3) / 4 + (
 
 int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st)
 {
+#ifdef IIV_STAMPS
     static bool told = false;
-    if (!told && getenv("IIV_DEBUG_OCC")) {   // diagnostic: the runtime's own residency figures
+    if (!told && getenv("IIV_DEBUG_OCC")) {   // diagnostic build: the runtime's own residency figures
         told = true;
         int n1 = 0, n0 = 0, nw = 0;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, (const void *)greedy_wave_kernel<kDHGR, 1>, 64, (size_t)a.lds_pad);
@@ -779,6 +766,7 @@ int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st)
         fprintf(stderr, "greedy_wave_kernel: workgroups per CU by hipOccupancyMaxActiveBlocksPerMultiprocessor: DHGR %d, HGR %d, shared (W = %d) %d\n",
                 n1, n0, kSharedW, nw);
     }
+#endif
     if (mode == kDHGR && a.shared && a.uniform_bank >= 0 && a.queue && a.lds_pad == 0) {
         // every stream of this round works on the same bank: eight streams per workgroup share that bank's L1 half in LDS
         constexpr int kLds = kSharedL1Pad + kSharedW * (int)sizeof(WaveLds);

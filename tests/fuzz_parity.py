@@ -31,12 +31,12 @@ for rnd in range(rounds):
         otab[key] = O.build_table(mode, dms[pal], symmetric=True)
         dtab[key] = (native.build_table(mode, dms[pal], True), native.build_store_table(mode, dms[pal]))
     n, nf = 8, 4
-    kind = ("iid", "coh", "img")[int(rng.integers(0, 3))]
+    kind = ("iid", "coh", "img", "static")[int(rng.integers(0, 4))]   # static: converging content (list -> bag -> out of work)
     if kind == "img":
         fm, fa = stream_batch.synth_frames_img(n, nf, mode == 1, seed=int(rng.integers(1 << 30)), device="cpu")
     else:
         fm, fa = stream_batch.synth_frames_torch(n, nf, mode == 1, seed=int(rng.integers(1 << 30)),
-                                                 coherent=kind == "coh", device="cpu")
+                                                 coherent=kind != "iid", device="cpu", keep=0.98 if kind == "static" else 0.9)
     # schedule: (frame, is_aux, restart, n_ops) with ragged lengths, continued generators, zero-length creations
     sched, f, ia = [], 0, 0
     for _ in range(int(rng.integers(4, 10))):
