@@ -341,16 +341,26 @@ def timed_leg(be, steps, warmup, barrier=lambda: None):
     return {"elapsed": t1 - t0, "prof": prof, "op_count": op_count, "seg_count": seg_count, "first_ops": first_ops}
 
 
-def _gather_ceiling_live(S, mode="DHGR"):
+def _gather_ceiling_live(S, mode="DHGR", shared=False):
     """The ceiling of the greedy step's access pattern, measured now: tools/gather_ceiling (built by
     __graft_entry__.build()) runs that pattern -- a streamed 1 KiB row + 8 divergent table loads per
-    opcode, no arithmetic -- with as many waves as there are clips, in a child process."""
+    opcode, no arithmetic -- with as many waves as there are clips, in a child process.  HGR batches of 4096 clips
+    and more run the LDS-shared form (sixteen streams per workgroup share the even bytes' L1 half in LDS): its
+    pattern is the microbenchmark's variant E."""
     import subprocess
     exe = os.path.join(ROOT, "tools", "gather_ceiling")
     try:
-        r = subprocess.run([exe, "D", str(int(S))] + (["HGR"] if mode == "HGR" else []), capture_output=True, text=True, timeout=180)
+        env = dict(os.environ)
+        if shared:
+            env["IIV_GATHER_E"] = "1"
+        r = subprocess.run([exe, "D", str(int(S))] + (["HGR"] if mode == "HGR" else []), capture_output=True, text=True, timeout=180, env=env)
         tag, waves, ms, gl = r.stdout.strip().split()[-4:]
         if r.returncode == 0 and tag == "D":
+            if shared:
+                e = [l for l in r.stdout.splitlines() if l.startswith("# E-HGR W=16")]
+                ms_e = float(e[0].split(":")[1].split()[0])
+                return float(S) * 490 * 512 / ms_e * 1e-6, ("tools/gather_ceiling variant E (HGR, W = 16: two of the eight loads from LDS) %s waves, run by "
+                                                         "this bench.py beside the encode: %.4f ms per launch (variant D, every load from the L1: %s ms)" % (waves, ms_e, ms))
             return float(gl), "tools/gather_ceiling D %s%s, run by this bench.py beside the encode: %s ms per launch" % (
                 waves, " HGR" if mode == "HGR" else "", ms)
     except Exception:
@@ -408,7 +418,8 @@ def _roofline_objects(be, args, prof, op_count, seg_count, S, elapsed, live_ceil
         # kernel's access pattern (a streamed 1 KiB row + 8 divergent table loads per opcode, narrow
         # form: 2-byte slices + 1 lane in 64 into the dense table) with no arithmetic at all.
         loads = float(op_count) * S * 512 / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
-        peak, src = _gather_ceiling_live(S, args.mode) if live_ceiling else (None, None)
+        hgr_shared = args.mode == "HGR" and S >= 4096 and args.greedy in ("auto", "wave", "shared")
+        peak, src = _gather_ceiling_live(S, args.mode, hgr_shared) if live_ceiling else (None, None)
         if peak is None and args.mode == "HGR":
             peak, src = GATHER_CEILING_GLOADS_HGR, "tools/gather_ceiling D 14336 HGR, a run on an MI355X committed as a constant, not this run"
         if peak is None:

@@ -57,10 +57,21 @@ struct WaveLds {                // per stream: 5568 B
     uint32_t pdone[256];        // byte already emitted as a primary (its diff weight counts as 0)
     uint32_t mt[624 + 256];     // random's current MT19937 block + the first 256 words of the next one
 };
-constexpr int kSharedL1Bytes = 2 * 32 * 256 * 2;           // DHGR: the L1 halves of one bank's two byte offsets
-constexpr int kSharedL1Zero = kSharedL1Bytes;              // a zero word behind them (excepted bytes, iiv_stream.h)
-constexpr int kSharedL1Pad = kSharedL1Bytes + 256;
-constexpr int kSharedW = IIV_SHARED_W;                              // 2 workgroups per CU: 2 x (32 KiB + 8 x 5.4 KiB)
+// What the LDS-shared form keeps in LDS per workgroup, and how many streams share it:
+//   DHGR: the L1 halves of BOTH byte offsets of the bank (2 x 16 KiB), eight streams, two workgroups per CU;
+//   HGR:  the L1 half of the EVEN byte offset only (64 KiB: both would be 128), sixteen streams, one workgroup per CU
+//         -- two of a step's eight table loads come from LDS.  HGR's step IS bound by its loads (0.97 of the ceiling of
+//         its access pattern), and that ceiling drops from 3.12 to 2.56 ms per 12288-stream launch this way
+//         (tools/gather_ceiling D 12288 HGR with IIV_GATHER_E=1).
+template <int MODE> struct SharedCfg {
+    static constexpr int kOffsets = MODE == kDHGR ? 2 : 1;                                  // byte offsets whose L1 lives in LDS
+    static constexpr int kHalfBytes = 2 << (SplitTraits<MODE>::kLeftCBits + SplitTraits<MODE>::kLeftRowBits);   // one offset's L1
+    static constexpr int kL1Bytes = kOffsets * kHalfBytes;
+    static constexpr int kZero = kL1Bytes;       // a zero word behind them (excepted bytes, iiv_stream.h)
+    static constexpr int kPad = kL1Bytes + 256;
+    static constexpr int kW = MODE == kDHGR ? IIV_SHARED_W : 16;
+    static constexpr int kLds = kPad + kW * (int)sizeof(WaveLds);
+};
 
 __device__ static inline WaveLds *own_wave_lds()
 {
@@ -69,7 +80,7 @@ __device__ static inline WaveLds *own_wave_lds()
 }
 
 template <int MODE, int W>
-__global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : (2 * W + 3) / 4 + (W % 4 ? 1 : 0)) void greedy_wave_kernel(StreamState *__restrict__ states,
+__global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? W / 4 : (2 * W + 3) / 4 + (W % 4 ? 1 : 0)) void greedy_wave_kernel(StreamState *__restrict__ states,
                                                                    const uint8_t *__restrict__ frames_main,
                                                                    const uint8_t *__restrict__ frames_aux, int n_frames,
                                                                    const LaunchSeg *__restrict__ segs, int seg_stride,
@@ -79,7 +90,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : (2 * W + 3) / 4 + (
     using T = SplitTraits<MODE>;
     constexpr uint32_t INF = 0xffffffffu;
     typedef uint32_t __attribute__((aligned(2))) u32_a2;
-    static_assert(W == 1 || MODE == kDHGR, "the shared L1 half fits the LDS in DHGR only");
+    using SC = SharedCfg<MODE>;
     extern __shared__ uint32_t dyn_lds[];
     const int lane0 = W == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
     const int wave = W == 1 ? 0 : IIV_SGPR(threadIdx.x >> 6);
@@ -89,23 +100,22 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : (2 * W + 3) / 4 + (
         __shared__ uint32_t nz_s[256], pdone_s[256], mt_s[624 + 256];
         nz = nz_s, pdone = pdone_s, mt = mt_s;
     } else {
-        WaveLds *wl = reinterpret_cast<WaveLds *>(reinterpret_cast<char *>(dyn_lds) + kSharedL1Pad) + wave;
+        WaveLds *wl = reinterpret_cast<WaveLds *>(reinterpret_cast<char *>(dyn_lds) + SC::kPad) + wave;
         nz = wl->nz, pdone = wl->pdone, mt = wl->mt;
     }
     const char *const l1_lds = reinterpret_cast<const char *>(dyn_lds);
     if (W > 1) {
         // (`bank`: the host launches this kernel only when every stream that emits opcodes in this round works
         // on the same bank, and says which)
-        const int o0 = byte_offset<MODE>(0, bank), o1 = byte_offset<MODE>(1, bank);
-        const uint4 *src0 = reinterpret_cast<const uint4 *>(nt.base + ((size_t)o0 << (T::kLeftCBits + T::kLeftRowBits + 1)));
-        const uint4 *src1 = reinterpret_cast<const uint4 *>(nt.base + ((size_t)o1 << (T::kLeftCBits + T::kLeftRowBits + 1)));
         uint4 *dst = reinterpret_cast<uint4 *>(dyn_lds);
-        constexpr int kQuads = kSharedL1Bytes / 2 / 16;
-        for (int i = threadIdx.x; i < kQuads; i += 64 * W) {
-            dst[i] = src0[i];
-            dst[kQuads + i] = src1[i];
+        constexpr int kQuads = SC::kHalfBytes / 16;
+#pragma unroll
+        for (int h = 0; h < SC::kOffsets; h++) {
+            const int o = byte_offset<MODE>(h, bank);
+            const uint4 *src = reinterpret_cast<const uint4 *>(nt.base + ((size_t)o << (T::kLeftCBits + T::kLeftRowBits + 1)));
+            for (int i = threadIdx.x; i < kQuads; i += 64 * W) dst[h * kQuads + i] = src[i];
         }
-        if (threadIdx.x < 64) dyn_lds[kSharedL1Zero / 4 + threadIdx.x] = 0u;
+        if (threadIdx.x < 64) dyn_lds[SC::kZero / 4 + threadIdx.x] = 0u;
         __syncthreads();
     }
 
@@ -244,10 +254,11 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : (2 * W + 3) / 4 + (
         // slice bases of this content byte, and where an excepted byte's loads go instead
         // (W > 1: byte offsets into the LDS copy -- the bank's even-offset half, then its odd-offset half)
         const uint32_t sl_e = (W == 1 ? l1_e : 0u) + (split_content_left<MODE>(c, 0) << (T::kLeftRowBits + 1));
-        const uint32_t sl_d = (W == 1 ? l1_d : (uint32_t)kSharedL1Bytes / 2) + (split_content_left<MODE>(c, 1) << (T::kLeftRowBits + 1));
+        constexpr bool kOddInLds = W > 1 && SC::kOffsets == 2;   // (HGR: the odd bytes' L1 stays with the L1 / TA)
+        const uint32_t sl_d = (kOddInLds ? (uint32_t)SC::kHalfBytes : l1_d) + (split_content_left<MODE>(c, 1) << (T::kLeftRowBits + 1));
         const uint32_t sr_e = r1_e + (split_content_right<MODE>(c, 0) << (T::kRightRowBits + 1));
         const uint32_t sr_d = r1_d + (split_content_right<MODE>(c, 1) << (T::kRightRowBits + 1));
-        const uint32_t zr_e = (W == 1 ? nt.zero_off : (uint32_t)kSharedL1Zero) - sl_e, zr_d = (W == 1 ? nt.zero_off : (uint32_t)kSharedL1Zero) - sl_d;
+        const uint32_t zr_e = (W == 1 ? nt.zero_off : (uint32_t)SC::kZero) - sl_e, zr_d = (kOddInLds ? (uint32_t)SC::kZero : nt.zero_off) - sl_d;
         const uint32_t cd = (c & ((1u << CB) - 1)) << (BITS + 1);   // (a DHGR byte with bit 7 set is an error elsewhere)
         const uint32_t dr_e = ds_e + cd - sr_e, dr_d = ds_d + cd - sr_d;
         const xmask_t me = xmask_of(xm_e, narrow_mask_content<MODE>(c, 0)), md = xmask_of(xm_d, narrow_mask_content<MODE>(c, 1));
@@ -267,8 +278,13 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : (2 * W + 3) / 4 + (
         } else {
             L.gl[0] = *reinterpret_cast<const uint16_t *>(l1_lds + (sl_e + ol[0]));
             L.gl[2] = *reinterpret_cast<const uint16_t *>(l1_lds + (sl_e + ol[2]));
-            L.gl[1] = *reinterpret_cast<const uint16_t *>(l1_lds + (sl_d + ol[1]));
-            L.gl[3] = *reinterpret_cast<const uint16_t *>(l1_lds + (sl_d + ol[3]));
+            if (kOddInLds) {
+                L.gl[1] = *reinterpret_cast<const uint16_t *>(l1_lds + (sl_d + ol[1]));
+                L.gl[3] = *reinterpret_cast<const uint16_t *>(l1_lds + (sl_d + ol[3]));
+            } else {
+                L.gl[1] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)ol[1], (int)sl_d, 0);
+                L.gl[3] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)ol[3], (int)sl_d, 0);
+            }
         }
         L.gr[0] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)orr[0], (int)sr_e, 0);
         L.gr[2] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)orr[2], (int)sr_e, 0);
@@ -752,52 +768,42 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : (2 * W + 3) / 4 + (
 }
 #undef IIV_PHASE
 
+// the LDS-shared form: persistent workgroups -- as many as are resident at once -- whose waves take streams off a queue
+template <int MODE> static int launch_shared(const GreedyArgs &a, hipStream_t st)
+{
+    using SC = SharedCfg<MODE>;
+    static int resident = 0;
+    if (!resident) {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hip_check(hipFuncSetAttribute((const void *)greedy_wave_kernel<MODE, SC::kW>, hipFuncAttributeMaxDynamicSharedMemorySize, SC::kLds),
+                      "greedy_wave_kernel LDS attribute") ||
+            hip_check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)greedy_wave_kernel<MODE, SC::kW>, 64 * SC::kW, (size_t)SC::kLds),
+                      "greedy_wave_kernel occupancy") ||
+            hip_check(hipGetDevice(&dev), "hipGetDevice") || hip_check(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties"))
+            return IIV_ERR_HIP;
+        resident = (per_cu > 0 ? per_cu : 1) * prop.multiProcessorCount;
+    }
+    const int wgs = (a.n_streams + SC::kW - 1) / SC::kW;
+    hipLaunchKernelGGL((greedy_wave_kernel<MODE, SC::kW>), dim3(wgs < resident ? wgs : resident), dim3(64 * SC::kW), (size_t)SC::kLds, st, a.states,
+                       a.frames_main, a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, a.queue);
+    return IIV_OK;
+}
+
 int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st)
 {
-#ifdef IIV_STAMPS
-    static bool told = false;
-    if (!told && getenv("IIV_DEBUG_OCC")) {   // diagnostic build: the runtime's own residency figures
-        told = true;
-        int n1 = 0, n0 = 0, nw = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, (const void *)greedy_wave_kernel<kDHGR, 1>, 64, (size_t)a.lds_pad);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n0, (const void *)greedy_wave_kernel<kHGR, 1>, 64, (size_t)a.lds_pad);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nw, (const void *)greedy_wave_kernel<kDHGR, kSharedW>, 64 * kSharedW,
-                                                           (size_t)(kSharedL1Pad + kSharedW * (int)sizeof(WaveLds)));
-        fprintf(stderr, "greedy_wave_kernel: workgroups per CU by hipOccupancyMaxActiveBlocksPerMultiprocessor: DHGR %d, HGR %d, shared (W = %d) %d\n",
-                n1, n0, kSharedW, nw);
-    }
-#endif
-    if (mode == kDHGR && a.shared && a.uniform_bank >= 0 && a.queue && a.lds_pad == 0) {
-        // every stream of this round works on the same bank: eight streams per workgroup share that bank's L1 half in LDS
-        constexpr int kLds = kSharedL1Pad + kSharedW * (int)sizeof(WaveLds);
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hip_check(hipFuncSetAttribute((const void *)greedy_wave_kernel<kDHGR, kSharedW>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds),
-                          "greedy_wave_kernel LDS attribute"))
-                return IIV_ERR_HIP;
-            attr_set = true;
-        }
-        // persistent workgroups: as many as are resident at once (the queue hands out the streams)
-        static int resident = 0;
-        if (!resident) {
-            int per_cu = 0, dev = 0;
-            hipDeviceProp_t prop;
-            if (hip_check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)greedy_wave_kernel<kDHGR, kSharedW>, 64 * kSharedW, (size_t)kLds),
-                          "greedy_wave_kernel occupancy") ||
-                hip_check(hipGetDevice(&dev), "hipGetDevice") || hip_check(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties"))
-                return IIV_ERR_HIP;
-            resident = (per_cu > 0 ? per_cu : 1) * prop.multiProcessorCount;
-        }
-        const int wgs = (a.n_streams + kSharedW - 1) / kSharedW;
-        hipLaunchKernelGGL((greedy_wave_kernel<kDHGR, kSharedW>), dim3(wgs < resident ? wgs : resident), dim3(64 * kSharedW), (size_t)kLds, st,
-                           a.states, a.frames_main, a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank,
-                           a.queue);
-    } else if (mode == kDHGR)
+    // (the shared form needs every stream of the round on one bank -- always so in HGR -- and the host's stream counter)
+    const bool shared = a.shared && a.uniform_bank >= 0 && a.queue && a.lds_pad == 0;
+    int rc = IIV_OK;
+    if (shared)
+        rc = mode == kDHGR ? launch_shared<kDHGR>(a, st) : launch_shared<kHGR>(a, st);
+    else if (mode == kDHGR)
         hipLaunchKernelGGL((greedy_wave_kernel<kDHGR, 1>), dim3(a.n_streams), dim3(64), (size_t)a.lds_pad, st, a.states, a.frames_main,
                            a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, (int *)nullptr);
     else
         hipLaunchKernelGGL((greedy_wave_kernel<kHGR, 1>), dim3(a.n_streams), dim3(64), (size_t)a.lds_pad, st, a.states, a.frames_main,
                            a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, (int *)nullptr);
+    if (rc) return rc;
     return hip_check(hipGetLastError(), "greedy_wave_kernel launch");
 }
 

@@ -99,7 +99,7 @@ def test_thousand_frame_clips(native, O, oracle_tables, device_tables, mode):
     otab = oracle_tables.get(mode, 5)
     fmd, fad = fm.cuda(), (fa.cuda() if fa is not None else None)
     runs = {}
-    for kernel in (("shared", "team") if mode == 1 else (True, "team")):   # (1000-frame clips through the plain one-wave form: HGR)
+    for kernel in (("shared", "team") if mode == 1 else (True, "shared", "team")):   # (the plain one-wave form at this length: HGR)
         b = stream_batch.StreamBatch(mode, t, s, n, seeds=seeds, dm=device_tables.dm[(mode, 5)])
         b.enc.set_greedy_kernel(kernel)
         got, segs = [], []
@@ -147,8 +147,6 @@ def test_converging_content(native, O, oracle_tables, device_tables, mode, kerne
     bytes redrawn (clip 1: each drawn frame shown four times), so after the first frames a generator goes through
     its whole sorted list, then through the re-queued bag (video.py:124-131, 170-178), and ends out of work with
     padding opcodes (video.py:189, 249-251) -- opcode streams and final state against the oracle."""
-    if kernel == "shared" and mode == 0:
-        pytest.skip("the LDS-shared form is DHGR only")
     frames = _frames(mode, 3, 60, 4300 + mode, ("static", "static4", "static"))
     stats = []
     _run_and_compare(native, O, oracle_tables, device_tables, mode, 5, frames, [(51, 52), (53, 54), (55, 56)], 20,

@@ -111,7 +111,7 @@ def _oracle_run(O, oracle_tables, mode, pal, frames, sched, sp, sn):
     return v, np.concatenate(out)
 
 
-@pytest.mark.parametrize("mode,wave,prefix", [(1, True, True), (0, True, True), (1, False, True), (1, True, False), (1, "shared", True), (1, "shared", False),
+@pytest.mark.parametrize("mode,wave,prefix", [(1, True, True), (0, True, True), (1, False, True), (1, True, False), (1, "shared", True), (1, "shared", False), (0, "shared", True),
                                               (0, False, False), (1, "team", True), (0, "team", False)])
 def test_batch_of_independent_streams(native, O, oracle_tables, device_tables, mode, wave, prefix):
     """12 streams with different data / seeds / coherence in ONE launch sequence,
@@ -196,7 +196,7 @@ def test_reference_asserts_are_reported(native, device_tables):
     enc.close()
 
 
-@pytest.mark.parametrize("mode,wave", [(1, True), (1, False), (0, True), (1, "team"), (0, "team"), (1, "shared")])
+@pytest.mark.parametrize("mode,wave", [(1, True), (1, False), (0, True), (1, "team"), (0, "team"), (1, "shared"), (0, "shared")])
 def test_image_like_streams(native, O, oracle_tables, device_tables, mode, wave):
     """S-img input (dithered moving bars): large coherent areas, many identical
     windows, so the two best deltas tie far more often than on random data -- the wave

@@ -58,7 +58,7 @@ def test_blank_target_on_blank_screen(native, O, device_tables, wave):
     assert enc.get_state(native.STATE_COUNTERS)[:2].tolist() == [0, 0]
 
 
-@pytest.mark.parametrize("mode,wave", [(1, True), (0, True), (1, False), (1, "shared")])
+@pytest.mark.parametrize("mode,wave", [(1, True), (0, True), (1, False), (1, "shared"), (0, "shared")])
 def test_constant_target_degenerate_priorities(native, O, oracle_tables, device_tables, mode, wave):
     """Every byte has the same priority (one histogram bucket): the prefix selection
     must fall back to ordering everything; ties are broken by nonce/page/offset only."""

@@ -150,6 +150,49 @@ __global__ __launch_bounds__(64 * W) void pattern_shared_l1_kernel(const uint16_
     sink[stream * 64 + lane] = acc;
 }
 
+
+// Variant E for HGR: the L1 table of ONE of the bank's two byte offsets (64 content parts x 512 rows x 2 B = 64 KiB) shared in
+// LDS by a workgroup of W one-wave streams (one workgroup per CU): two of the eight gathers become ds_read_u16.
+template <int W>
+__global__ __launch_bounds__(64 * W) void pattern_shared_l1_hgr_kernel(const uint16_t *__restrict__ left, const uint16_t *__restrict__ right,
+                                                                       const uint16_t *__restrict__ dense, const uint4 *__restrict__ rows,
+                                                                       int n_ops, int n_streams, uint32_t *__restrict__ sink)
+{
+    extern __shared__ uint32_t lds[];   // [0, 16384): L1 of offset 0
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        const uint4 *src0 = reinterpret_cast<const uint4 *>(left);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds);
+        for (int i = threadIdx.x; i < 4096; i += 64 * W) dst[i] = src0[i];
+    }
+    __syncthreads();
+    const int stream = blockIdx.x * W + wave;
+    if (stream >= n_streams) return;
+    const uint16_t *l16 = reinterpret_cast<const uint16_t *>(lds);
+    const uint4 *my = rows + (size_t)stream * n_ops * 64 + lane;
+    uint32_t acc = 0, h = stream * 2654435761u + 977u;
+    uint4 next = my[0];
+    for (int op = 0; op < n_ops; op++) {
+        const uint4 row = next;
+        if (op + 1 < n_ops) next = my[(size_t)(op + 1) * 64];
+        h = h * 1664525u + 1013904223u;
+        const uint32_t c = (h >> 16) & 255u;
+        const uint32_t cl = c & 63u, cr = c >> 2;
+        const uint16_t *le = l16 + (cl << 9), *lo = left + (((1u << 6) | cl) << 9);
+        const uint16_t *re = right + (cr << 9), *ro = right + (((1u << 6) | cr) << 9);
+        const uint16_t *de = dense + ((size_t)c << 14), *dd = dense + ((size_t)(256 + c) << 14);
+        uint32_t b0 = re[(row.x >> 9) & 0x1ffu], b1 = ro[(row.y >> 9) & 0x1ffu], b2 = re[(row.z >> 9) & 0x1ffu], b3 = ro[(row.w >> 9) & 0x1ffu];
+        uint32_t a1 = lo[row.y & 511u], a3 = lo[row.w & 511u];
+        uint32_t a0 = le[row.x & 511u], a2 = le[row.z & 511u];
+        if (((row.x >> 20) & 63u) == 0) a0 = de[row.x & 16383u];
+        if (((row.y >> 20) & 63u) == 0) a1 = dd[row.y & 16383u];
+        if (((row.z >> 20) & 63u) == 0) a2 = de[row.z & 16383u];
+        if (((row.w >> 20) & 63u) == 0) a3 = dd[row.w & 16383u];
+        acc += (a0 + b0) ^ (a1 + b1) ^ (a2 + b2) ^ (a3 + b3);
+    }
+    sink[stream * 64 + lane] = acc;
+}
+
 // Variant B: four 8-byte gathers (as if both halves of a byte's value sat side by side in one
 // 6 KiB slice per opcode): what a layout that serves a byte with ONE load would buy.
 __global__ __launch_bounds__(64) void pattern_x2_kernel(const uint2 *__restrict__ both, const uint4 *__restrict__ rows,
@@ -259,6 +302,31 @@ static int run_d_only(int waves, bool hgr)
     (void)hipEventElapsedTime(&ms, a, b);
     ms /= reps;
     if (hipGetLastError() != hipSuccess) return 1;
+    if (hgr && getenv("IIV_GATHER_E")) {   // variant E for HGR beside D (diagnostic)
+        (void)hipFuncSetAttribute((const void *)pattern_shared_l1_hgr_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)pattern_shared_l1_hgr_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (int w : {16, 12}) {
+            auto le = [&] {
+                if (w == 16)
+                    hipLaunchKernelGGL(pattern_shared_l1_hgr_kernel<16>, dim3((waves + 15) / 16), dim3(1024), 65536 + 16 * 5632, 0, (const uint16_t *)left,
+                                       (const uint16_t *)right, dense, rows, n_ops, waves, sink);
+                else
+                    hipLaunchKernelGGL(pattern_shared_l1_hgr_kernel<12>, dim3((waves + 11) / 12), dim3(768), 65536 + 12 * 5632, 0, (const uint16_t *)left,
+                                       (const uint16_t *)right, dense, rows, n_ops, waves, sink);
+            };
+            le();
+            (void)hipDeviceSynchronize();
+            (void)hipEventRecord(a);
+            for (int r = 0; r < reps; r++) le();
+            (void)hipEventRecord(b);
+            (void)hipEventSynchronize(b);
+            float ms2;
+            (void)hipEventElapsedTime(&ms2, a, b);
+            printf("# E-HGR W=%d (one offset's L1 in LDS, 1 workgroup per CU): %.4f ms per launch  err=%d\n", w, ms2 / reps, (int)hipGetLastError());
+        }
+        printf("D %d %.4f %.1f\n", waves, ms, (double)waves * n_ops * 512 / ms * 1e-6);
+        return 0;
+    }
     printf("D %d %.4f %.1f\n", waves, ms, (double)waves * n_ops * 512 / ms * 1e-6);
     return 0;
 }
