@@ -144,6 +144,60 @@ __device__ inline uint32_t edit_distance_bytes(const uint32_t (&src)[G], const u
     return e1;
 }
 
+// Two distances at once in packed 16-bit arithmetic (every value of the recurrence is <= 18 x 113 < 2^11): the
+// two strings' steps share the v_pk_add / v_pk_min, only the two cost lookups stay separate.  The transposition
+// test becomes arithmetic: x = (this byte) ^ (previous byte with its nibbles swapped) is 0 exactly where the
+// transposition exists, and its cost is then 1 + 0x3fff * min(x, 1) -- a value no path through a missing
+// transposition can undercut (e2 + 0x4000 > e1 + any substitution cost, and nothing overflows 16 bits).
+typedef unsigned short edit_u16x2 __attribute__((ext_vector_type(2)));
+// byte KB of string a in bits 0..7, byte KB of string b in bits 16..23 (v_perm_b32: bytes 0..3 of the second
+// operand are selectors 0..3, of the first 4..7; 0x0c = the constant 0)
+template <int KB> __device__ static inline uint32_t edit_pair_bytes(uint32_t a, uint32_t b)
+{
+    return __builtin_amdgcn_perm(b, a, 0x0c000c00u | (uint32_t)KB | ((uint32_t)(4 + KB) << 16));
+}
+template <int K, int N> struct EditStepPair {
+    template <typename X>
+    __device__ static inline void run(const X &xa, const X &ya, const X &xb, const X &yb, const uint16_t *lut, uint32_t prev_swapped,
+                                      edit_u16x2 &e1, edit_u16x2 &e2)
+    {
+        const uint32_t idx = edit_pair_bytes<(K & 3)>(xa[K >> 2], xb[K >> 2]);   // the two lookup indices, one per half
+        const uint32_t s = (uint32_t)lut[idx & 0xffu] | ((uint32_t)lut[idx >> 16] << 16);
+        edit_u16x2 e = e1 + __builtin_bit_cast(edit_u16x2, s);
+        if (K >= 1) {
+            // (inline assembly: written as min / multiply-add the compiler turns it into two compares, two
+            // selects and a repack)
+            uint32_t tc;
+            asm("v_pk_min_u16 %0, %1, %2\n\tv_pk_mad_u16 %0, %0, %3, %2" : "=&v"(tc) : "v"(idx ^ prev_swapped), "v"(0x00010001u), "v"(0x3fff3fffu));
+            e = __builtin_elementwise_min(e, e2 + __builtin_bit_cast(edit_u16x2, tc));
+        }
+        e2 = e1;
+        e1 = e;
+        EditStepPair<K + 1, N>::run(xa, ya, xb, yb, lut, K + 1 < N ? edit_pair_bytes<(K & 3)>(ya[K >> 2], yb[K >> 2]) : 0u, e1, e2);
+    }
+};
+template <int N> struct EditStepPair<N, N> {
+    template <typename X>
+    __device__ static inline void run(const X &, const X &, const X &, const X &, const uint16_t *, uint32_t, edit_u16x2 &, edit_u16x2 &) {}
+};
+template <int N, int G>
+__device__ inline void edit_distance_bytes_pair(const uint32_t (&src_a)[G], const uint32_t (&tgt_a)[G], const uint32_t (&src_b)[G],
+                                                const uint32_t (&tgt_b)[G], const uint16_t *lut, uint32_t &d_a, uint32_t &d_b)
+{
+    uint32_t xa[G], ya[G], xb[G], yb[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        xa[g] = (src_a[g] << 4) | tgt_a[g];
+        ya[g] = (tgt_a[g] << 4) | src_a[g];
+        xb[g] = (src_b[g] << 4) | tgt_b[g];
+        yb[g] = (tgt_b[g] << 4) | src_b[g];
+    }
+    edit_u16x2 e1 = {0, 0}, e2 = {0, 0};
+    EditStepPair<0, N>::run(xa, ya, xb, yb, lut, 0u, e1, e2);
+    d_a = e1.x;
+    d_b = e1.y;
+}
+
 // HGR colour strings from three small lookups: pixels 0..5, 6..11 and 12..17 of a window's string
 // depend on only 7, 6 and 7 of its 14 bits (found by brute force over all 2 x 2^14 windows: flip a
 // bit, see which pixels can change -- the palette bit of the byte itself reaches every pixel of
