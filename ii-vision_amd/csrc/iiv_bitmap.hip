@@ -6,7 +6,7 @@
 // K7 delta_pages_kernel   Bitmap.compute_delta_page        screen.py:525-547
 //
 // These are the stand-alone forms behind screen.HGRBitmap / DHGRBitmap; the
-// encoder kernels (iiv_encode.hip) fuse the same arithmetic into their prologue
+// encoder kernels (iiv_prologue.hip, iiv_greedy.hip) fuse the same arithmetic into their prologue
 // and greedy loop and never materialise the packed array.
 #include "iiv_host.h"
 

@@ -1,5 +1,5 @@
 // iiv_edit.h -- colour strings and the edit-distance recurrence, shared by the
-// table builder (iiv_tables.hip) and the encoder prologue (iiv_encode.hip).
+// table builder (iiv_tables.hip) and the encoder prologue (iiv_prologue.hip).
 // Reference: transcoder/screen.py:712-789, 983-990; colours.py:100-148;
 // make_data_tables.py:30-41, 92-108.
 #pragma once

@@ -1,20 +1,10 @@
-// iiv_encode.hip -- video.Video.encode_frame on gfx950
-// (reference: transcoder/video.py:72-301, transcoder/screen.py:383-547).
+// iiv_encode.hip -- video.Video.encode_frame on gfx950: the encoder object, its launch planning and the C ABI
+// (reference: transcoder/video.py:72-301, transcoder/screen.py:383-547, transcoder/movie.py:56-111).
 //
-// One workgroup per independent video stream; all stream state lives in HBM
-// (StreamState) between launches and in LDS / registers inside one.
-//
-//   prologue_kernel (1024 threads / stream)           video.py:104-119, 254-271
-//     diff weights of current screen vs target (edit-distance recurrence on colour
-//     strings from LDS LUTs, or a gather from the precomputed table), hole masking,
-//     update_priority accumulation, the numpy MT19937 draws (generated by one wave
-//     beside the scoring), 64-bit keys, counting sort -> `order[]`.
-//   greedy_wave_kernel (one 64-lane wave / stream, 4 page bytes per lane; >= 1536 streams)
-//   greedy_kernel      (256 threads = one lane per page byte / stream; few streams)
-//                                                     video.py:121-187, 275-301
-//     pop `order[]` (then the re-queued bag), score every byte of the page against
-//     the popped content via the store table, find the two best candidates, apply
-//     <= 3 stores, emit one opcode per step.
+// One workgroup (or wave) per independent video stream; all stream state lives in HBM (StreamState) between
+// launches and in LDS / registers inside one.  A launch round = for every stream, optionally a new generator
+// (iiv_prologue.hip: prologue_kernel) and then its next n_ops opcodes (iiv_greedy.hip / iiv_team.hip /
+// iiv_workgroup.hip).
 //
 // How the reference's heap is restated (proved equivalent on the CPU by
 // oracle/iiv_oracle.c:step_struct against the imported reference):
@@ -39,1107 +29,9 @@
 
 namespace iiv {
 
-// ------------------------------------------------------------------------- prologue
-
-constexpr int kProThreads = 1024;
-
-#ifdef IIV_STAMPS
-#define IIV_STAMP(i)                                                        \
-    do {                                                                    \
-        __syncthreads();                                                    \
-        if (threadIdx.x == 0) S.stamps[i] = __builtin_amdgcn_s_memtime();   \
-    } while (0)
-#else
-#define IIV_STAMP(i) do { } while (0)
-#endif
-
-// Bitonic sort of 8*NT u64 keys, 8 consecutive elements per thread.  Exchange
-// distances 1,2,4 stay inside a thread's registers, 8..256 are wave shuffles, and
-// only distances >= 512 (10 of the 91 stages at 8192 keys) go through LDS.
-__device__ static inline void cmpx(unsigned long long &lo, unsigned long long &hi, bool asc)
-{
-    bool sw = (lo > hi) == asc;
-    unsigned long long t = lo;
-    lo = sw ? hi : lo;
-    hi = sw ? t : hi;
-}
-
-// Bitonic sort of KPT * NT u64 keys held KPT consecutive keys per thread by all NT
-// threads of the workgroup.  Exchange distances below KPT stay in registers, up to
-// 32 * KPT they are wave shuffles, and only larger ones go through LDS (xbuf).
-template <int KPT, int NT>
-__device__ static inline void bitonic_sort(unsigned long long (&v)[KPT], unsigned long long *xbuf, int tid)
-{
-    constexpr int N = KPT * NT;
-#pragma unroll
-    for (int k = 2; k <= KPT; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j >= 1; j >>= 1) {
-#pragma unroll
-            for (int r = 0; r < KPT; r++)
-                if ((r & j) == 0) cmpx(v[r], v[r | j], (((KPT * tid + r) & k) == 0));
-        }
-    }
-    for (int k = 2 * KPT; k <= N; k <<= 1) {
-        const bool asc = ((KPT * tid) & k) == 0;
-        for (int j = k >> 1; j >= KPT; j >>= 1) {
-            const int d = j / KPT;
-            const bool take_min = ((tid & d) == 0) == asc;
-            if (d < 64) {
-#pragma unroll
-                for (int r = 0; r < KPT; r++) {
-                    unsigned long long p = __shfl_xor(v[r], d, 64);
-                    v[r] = take_min ? (p < v[r] ? p : v[r]) : (p > v[r] ? p : v[r]);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < KPT; r++) xbuf[r * NT + tid] = v[r];
-                __syncthreads();
-#pragma unroll
-                for (int r = 0; r < KPT; r++) {
-                    unsigned long long p = xbuf[r * NT + (tid ^ d)];
-                    v[r] = take_min ? (p < v[r] ? p : v[r]) : (p > v[r] ? p : v[r]);
-                }
-                __syncthreads();
-            }
-        }
-#pragma unroll
-        for (int j = KPT >> 1; j >= 1; j >>= 1) {
-#pragma unroll
-            for (int r = 0; r < KPT; r++)
-                if ((r & j) == 0) cmpx(v[r], v[r | j], asc);
-        }
-    }
-}
-
-// sorted keys -> order[] entries (page << 8 | offset | content << 16)
-template <int KPT> __device__ static inline void write_order(uint32_t *order, const unsigned long long (&v)[KPT], int tid)
-{
-    uint32_t o[KPT];
-#pragma unroll
-    for (int j = 0; j < KPT; j++) o[j] = ((uint32_t)(v[j] >> 8) & 0x1fffu) | (((uint32_t)v[j] & 0xffu) << 16);
-    if (KPT == 2) {
-        *reinterpret_cast<uint2 *>(order + 2 * tid) = make_uint2(o[0], o[1]);
-    } else {
-        uint4 *q = reinterpret_cast<uint4 *>(order + KPT * tid);
-#pragma unroll
-        for (int j = 0; j < KPT / 4; j++) q[j] = make_uint4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
-    }
-}
-
-// exclusive prefix sum of one int per thread over the workgroup (row-major thread order)
-template <int NT> __device__ static inline int block_scan_excl(int v, int tid, uint32_t *wsum, int &total)
-{
-    int incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int o = __shfl_up(incl, d, 64);
-        if ((tid & 63) >= d) incl += o;
-    }
-    __syncthreads();  // wsum may still be read from a previous use
-    if ((tid & 63) == 63) wsum[tid >> 6] = (uint32_t)incl;
-    __syncthreads();
-    int wbase = 0;
-    total = 0;
-    for (int w = 0; w < NT / 64; w++) {
-        int x = (int)wsum[w];
-        if (w < (tid >> 6)) wbase += x;
-        total += x;
-    }
-    return wbase + incl - v;
-}
-
 constexpr int kSharedHgrMinStreams = 4096;   // 16 streams per workgroup x 256 CUs
 constexpr int kTeamMaxStreams = 768;   // IIV_GREEDY_AUTO: at most this many streams run the team kernel
-constexpr int kSelNeedMax = 2048;  // partial sort is used when 3 * opcode budget <= this
-constexpr int kBucketMax = 96;      // buckets larger than this fall back to the bitonic sort
 
-// DP == IIV_DW_TABLE: diff weights are gathered from the precomputed table (one random
-// HBM line per screen byte).  IIV_DW_RECURRENCE: they are recomputed by running the
-// edit-distance recurrence on the two colour strings (an L2-resident 16 B LUT
-// entry each) -- bit-identical by construction (same recurrence that built the
-// table), and far cheaper than an HBM line fetch per byte.  IIV_DW_SPLIT: the chain is cut
-// in the middle like the store table's (iiv_stream.h): two 4-byte gathers from L2-sized
-// halves indexed by the row parts of both windows, combined by one min-plus product.
-template <int MODE, int DP>
-__device__ __forceinline__ void prologue_body(StreamState *__restrict__ states, const uint8_t *__restrict__ frames_main,
-                                              const uint8_t *__restrict__ frames_aux, int n_frames, const LaunchSeg &seg,
-                                              const uint16_t *__restrict__ table, const ulonglong2 *__restrict__ strings,
-                                              const uint16_t *__restrict__ sub, const uint32_t *__restrict__ dwl,
-                                              const uint32_t *__restrict__ dwr, const uint2 *__restrict__ hgr_slut)
-{
-    const int need = __builtin_amdgcn_readfirstlane(seg.need);
-    if (need < 0) return;  // this stream starts no generator in this round
-    const int frame = __builtin_amdgcn_readfirstlane(seg.frame), is_aux = __builtin_amdgcn_readfirstlane(seg.is_aux);
-    constexpr int BITS = ModeTraits<MODE>::kBits;
-    constexpr int NB = ModeTraits<MODE>::kBanks;
-    // One LDS block, carved by hand so that the small lookup tables sit at the lowest
-    // addresses: their offsets then fold into the 16-bit offset field of ds_read and the
-    // recurrence needs no address add per lookup.
-    //      0  lut    16x16 substitute costs (u16)
-    //    512  aux4k  DHGR colour-string LUTs | handed-over diff weights, then histogram, then bucket cursors
-    //   4608  mtb    [0] = the stream's current MT19937 block; later the bucket starts
-    //   9600  wsum, flags
-    //   9728  smem   64 KiB: staged memory maps (cur | tgt) + generated MT blocks, then -- once
-    //                every diff weight is in registers -- the sort's key buffer
-    __shared__ __attribute__((aligned(16))) unsigned char lds[9728 + 65536];
-    uint16_t *lut = reinterpret_cast<uint16_t *>(lds);
-    uint32_t *aux4k = reinterpret_cast<uint32_t *>(lds + 512);
-    uint32_t(*mtb)[624] = reinterpret_cast<uint32_t(*)[624]>(lds + 4608);
-    uint32_t *wsum = reinterpret_cast<uint32_t *>(lds + 9600);
-    int &flag_bad = *reinterpret_cast<int *>(lds + 9664);
-    int &sel_bucket = *reinterpret_cast<int *>(lds + 9668);
-    int &sel_count = *reinterpret_cast<int *>(lds + 9672);
-    int &big_bucket = *reinterpret_cast<int *>(lds + 9676);
-    unsigned char *smem = lds + 9728;
-    uint8_t(*cur)[8192] = reinterpret_cast<uint8_t(*)[8192]>(smem);
-    uint8_t(*tgt)[8192] = reinterpret_cast<uint8_t(*)[8192]>(smem + NB * 8192);
-    unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);
-    // np.random's MT19937 blocks 1..13 -- every block the <= 7680 draws of this call can reach --
-    // are generated above cur | tgt by the last wave while the other waves score
-    uint32_t *gen = reinterpret_cast<uint32_t *>(smem + 2 * NB * 8192);
-
-    const int tid = threadIdx.x;
-    StreamState &S = states[blockIdx.x];
-    const size_t fbase = ((size_t)blockIdx.x * n_frames + frame) * 8192;
-
-    IIV_STAMP(0);
-    const int first = S.mt_np_idx;  // (read before the first barrier: thread 0 updates it later)
-    if (tid == 0) flag_bad = 0;
-    // stage current screen and target memory maps (16 B per lane per load)
-    for (int i = tid; i < 512 * NB; i += kProThreads) {
-        int b = i >> 9, k = i & 511;
-        reinterpret_cast<uint4 *>(cur[b])[k] = reinterpret_cast<const uint4 *>(S.mem[b])[k];
-        const uint8_t *src = (b == 0 ? frames_main : frames_aux) + fbase;
-        reinterpret_cast<uint4 *>(tgt[b])[k] = reinterpret_cast<const uint4 *>(src)[k];
-    }
-    IIV_STAMP(10);
-    for (int i = tid; i < 624; i += kProThreads) mtb[0][i] = S.mt_np[i];
-    if (DP == IIV_DW_RECURRENCE) load_cost_lut(lut, sub, tid);
-    IIV_STAMP(11);
-    // DHGR colour strings from three LDS lookups instead of ten rotates: pixels 0..3
-    // depend on dots 0..6, pixels 4..6 on dots 4..9, pixels 7..9 on dots 7..12
-    // (colours.py:100-134).  slut[odd][0..127 | 128..191 | 192..255], one pixel per byte.
-    // The ten pixels of a string occupy byte slots 0..9 of three words: pixels 0..3 in word
-    // 0, 4..6 in bytes 0..2 of word 1, 7 in byte 3 of word 1, 8..9 in word 2 -- so the
-    // third LUT delivers a pair (lo: pixel 7 in byte 3; hi: pixels 8, 9).
-    uint32_t *slut = aux4k;  // 2 parities x (128 + 64) words + 2 x 64 x 2 words = 2.5 KiB
-    if (DP == IIV_DW_RECURRENCE && MODE == kDHGR && tid < 512) {
-        const int odd = tid >> 8, e = tid & 255;
-        const int ph = phase_of(kDHGR, byte_offset<kDHGR>(odd, is_aux));
-        const int k0 = e < 128 ? 0 : e < 192 ? 4 : 7, nk = e < 128 ? 4 : 3;
-        const uint32_t v = e < 128 ? e : (e - 128) & 63;
-        uint32_t px[4] = {0, 0, 0, 0};
-        for (int k = 0; k < nk; k++) {
-            const uint32_t win = (v >> k) & 0xf;
-            px[k] = ((win | (win << 4)) >> (4 - ((ph + k0 + k) & 3))) & 0xf;
-        }
-        if (e < 192) {
-            slut[odd * 320 + e] = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
-        } else {
-            slut[odd * 320 + 192 + 2 * (e - 192)] = px[0] << 24;
-            slut[odd * 320 + 192 + 2 * (e - 192) + 1] = px[1] | (px[2] << 8);
-        }
-    }
-    // HGR colour strings likewise from three LDS lookups (iiv_edit.h: hgr_group_index): the 5 KiB table
-    // is built once per encoder and copied into the 16 KiB that HGR's single bank leaves free above
-    // the generated MT blocks (the L2-resident 16 B-per-window LUT it replaces cost two divergent
-    // loads per byte: 0.17 of the kernel's 1.06 ms)
-    uint2 *hslut = reinterpret_cast<uint2 *>(smem + 49152);
-    if (DP == IIV_DW_RECURRENCE && MODE == kHGR && tid < 2 * kHgrGroupEntries) hslut[tid] = hgr_slut[tid];
-    __syncthreads();
-    IIV_STAMP(1);
-    const int tgt_first = tgt[(MODE == kDHGR && is_aux) ? 1 : 0][0];
-    const int own_b = (MODE == kDHGR && is_aux) ? 1 : 0;
-    // 8 consecutive bytes of one page row per thread (row-major, as nonzero() walks them)
-    const int i0 = tid * 8;
-    // The last wave generates the MT19937 blocks instead of scoring its 512 bytes (pages 30, 31);
-    // other threads score them (DHGR: the threads sitting on hole groups, see below; HGR: the
-    // first 512 threads, one byte each on top of their own eight) and hand the diff weights over
-    // through LDS.
-    const bool mt_wave = tid >= kProThreads - 64;
-    uint16_t *dwx = reinterpret_cast<uint16_t *>(aux4k + 768);  // (the string LUTs end at word 640)
-
-    int32_t upv[8];
-    {
-        const int4 *p = reinterpret_cast<const int4 *>(S.up[is_aux] + i0);
-        int4 a = p[0], b = p[1];
-        upv[0] = a.x; upv[1] = a.y; upv[2] = a.z; upv[3] = a.w;
-        upv[4] = b.x; upv[5] = b.y; upv[6] = b.z; upv[7] = b.w;
-    }
-    if (mt_wave) {
-        __builtin_amdgcn_s_setprio(3);  // the other waves only have to wait for this one
-        const uint32_t *src = mtb[0];
-        for (int k = 0; k < 13; k++) {
-            mt_twist_wave(src, gen + k * 624, tid & 63);
-            src = gen + k * 624;
-        }
-        __builtin_amdgcn_s_setprio(0);
-    }
-    IIV_STAMP(12);
-
-    // windows of page byte (page, y) on the current screen and in the target (0, 0 for a hole)
-    auto windows = [&](int page, int y, uint32_t &cm, uint32_t &tm) {
-        const uint8_t *cur_own = cur[own_b] + page * 256, *cur_oth = cur[NB - 1 - own_b] + page * 256;
-        const uint8_t *tgt_own = tgt[own_b] + page * 256, *tgt_oth = tgt[NB - 1 - own_b] + page * 256;
-        uint32_t cp, cn, tp, tn;
-        neighbours<MODE>(cur_own, cur_oth, y, is_aux, cp, cn);
-        neighbours<MODE>(tgt_own, tgt_oth, y, is_aux, tp, tn);
-        cm = masked_window<MODE>(cp, cur_own[y], cn, y & 1);
-        tm = masked_window<MODE>(tp, tgt_own[y], tn, y & 1);
-    };
-    // diff weight of one byte = edit distance current window -> target window (screen.py:400-449)
-    auto diff_weight = [&](uint32_t cm, uint32_t tm, int y) -> uint32_t {
-        const int odd = y & 1;
-        const int o = byte_offset<MODE>(y, is_aux);
-        if (DP == IIV_DW_TABLE) return table[((size_t)o << (2 * BITS)) + ((size_t)cm << BITS) + tm];  // screen.py:441-443
-        if (DP == IIV_DW_SPLIT) {
-            using T = SplitTraits<MODE>;
-            const uint32_t l = dwl[((((uint32_t)o << T::kLeftRowBits) + split_row_left<MODE>(cm, odd)) << T::kLeftRowBits) +
-                                   split_row_left<MODE>(tm, odd)];
-            const uint32_t r = dwr[((((uint32_t)o << T::kRightRowBits) + split_row_right<MODE>(cm, odd)) << T::kRightRowBits) +
-                                   split_row_right<MODE>(tm, odd)];
-            return combine(l, r);
-        }
-        if constexpr (MODE == kDHGR) {
-            // (no early-out for equal windows: the recurrence returns 0 by itself, and a branch per
-            // byte keeps the compiler from overlapping one byte's LDS reads with another's arithmetic)
-            // DHGR windows are already dot strings (screen.py:983-990)
-            const uint32_t *sl = slut + 320 * odd;
-            const uint2 ca = reinterpret_cast<const uint2 *>(sl + 192)[cm >> 7];
-            const uint2 ct = reinterpret_cast<const uint2 *>(sl + 192)[tm >> 7];
-            const uint32_t src[3] = {sl[cm & 127], sl[128 + ((cm >> 4) & 63)] | ca.x, ca.y};
-            const uint32_t tgt[3] = {sl[tm & 127], sl[128 + ((tm >> 4) & 63)] | ct.x, ct.y};
-            return edit_distance_bytes<ModeTraits<MODE>::kDots, 3>(src, tgt, lut);
-        } else {
-            const uint2 *hl = hslut + kHgrGroupEntries * odd;
-            uint32_t src[5], tgt5[5];
-            {
-                const uint2 a = hl[hgr_group_index(cm, 0, odd)], b = hl[128 + hgr_group_index(cm, 1, odd)],
-                            c = hl[192 + hgr_group_index(cm, 2, odd)];
-                src[0] = a.x; src[1] = a.y | b.x; src[2] = b.y; src[3] = c.x; src[4] = c.y;
-            }
-            {
-                const uint2 a = hl[hgr_group_index(tm, 0, odd)], b = hl[128 + hgr_group_index(tm, 1, odd)],
-                            c = hl[192 + hgr_group_index(tm, 2, odd)];
-                tgt5[0] = a.x; tgt5[1] = a.y | b.x; tgt5[2] = b.y; tgt5[3] = c.x; tgt5[4] = c.y;
-            }
-            return edit_distance_bytes<ModeTraits<MODE>::kDots, 5>(src, tgt5, lut);
-        }
-    };
-
-    // HGR, recurrence mode: the diff weights of two bytes (an even one, then the odd one after it) in packed 16-bit
-    // arithmetic (iiv_edit.h: edit_distance_bytes_pair)
-    auto diff_weight_pair = [&](uint32_t cm0, uint32_t tm0, uint32_t cm1, uint32_t tm1, int y0, uint32_t &d0, uint32_t &d1) {
-        if constexpr (DP == IIV_DW_RECURRENCE && MODE == kHGR) {
-            uint32_t sa[5], ta[5], sb[5], tb[5];
-            auto strings = [&](uint32_t m, int odd, uint32_t(&out)[5]) {
-                const uint2 *hl = hslut + kHgrGroupEntries * odd;
-                const uint2 a = hl[hgr_group_index(m, 0, odd)], b = hl[128 + hgr_group_index(m, 1, odd)],
-                            c = hl[192 + hgr_group_index(m, 2, odd)];
-                out[0] = a.x; out[1] = a.y | b.x; out[2] = b.y; out[3] = c.x; out[4] = c.y;
-            };
-            strings(cm0, y0 & 1, sa);
-            strings(tm0, y0 & 1, ta);
-            strings(cm1, (y0 + 1) & 1, sb);
-            strings(tm1, (y0 + 1) & 1, tb);
-            edit_distance_bytes_pair<ModeTraits<MODE>::kDots, 5>(sa, ta, sb, tb, lut, d0, d1);
-        } else {
-            d0 = diff_weight(cm0, tm0, y0);
-            d1 = diff_weight(cm1, tm1, y0 + 1);
-        }
-    };
-
-    uint32_t dwv[8], tmv[8];
-    uint32_t cpk[2] = {0, 0};  // the 8 target bytes, packed (needed again when the keys are built)
-    int bad = 0;
-    if (MODE == kDHGR) {
-        // the thread's eight bytes and their neighbours in dot order (the other bank's bytes
-        // y-1..y+7 for an aux byte, y..y+8 for a main byte) as 64-bit words: a window is then
-        // three bit-field extracts instead of three byte loads with their address arithmetic
-        const bool hole = is_hole(i0 & 255);  // holes come in aligned groups of eight (120..127, 248..255)
-        if (hole && (cur[own_b][i0] | cur[own_b][i0 + 1] | cur[own_b][i0 + 2] | cur[own_b][i0 + 3] | cur[own_b][i0 + 4] |
-                     cur[own_b][i0 + 5] | cur[own_b][i0 + 6] | cur[own_b][i0 + 7]))
-            bad = kErrHoles;  // video.py:87
-        // A thread on a hole group has nothing to score (video.py:111), and the 60 of them outside
-        // the MT wave are exactly as many as the MT wave's non-hole groups: each scores one of
-        // those groups in the same instructions its neighbours spend on their own bytes.
-        const bool proxy = hole && !mt_wave;
-        int grp = tid;  // group of eight bytes this thread scores
-        if (proxy) {
-            const int k = tid >> 4;          // 0..59
-            grp = 960 + k + k / 15;          // skips the MT wave's own hole groups
-        }
-        const int page = grp >> 5, yb = (grp * 8) & 255;
-#pragma unroll
-        for (int j = 0; j < 8; j++) tmv[j] = dwv[j] = 0;
-        const int oth_b = NB - 1 - own_b;
-        unsigned long long own8[2], prv8[2], nxt8[2];  // [0] current screen, [1] target
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const uint8_t *own = (k ? tgt : cur)[own_b] + page * 256 + yb;
-            const uint8_t *oth = (k ? tgt : cur)[oth_b] + page * 256 + yb;
-            own8[k] = *reinterpret_cast<const unsigned long long *>(own);
-            const unsigned long long o8 = *reinterpret_cast<const unsigned long long *>(oth);
-            if (is_aux) {  // prev = other[y - 1], next = other[y]
-                const unsigned long long before = yb > 0 ? oth[-1] : 0;
-                prv8[k] = (o8 << 8) | before;
-                nxt8[k] = o8;
-            } else {       // prev = other[y], next = other[y + 1]
-                const unsigned long long after = yb + 8 < 256 ? oth[8] : 0;
-                prv8[k] = o8;
-                nxt8[k] = (o8 >> 8) | (after << 56);
-            }
-        }
-        if (!proxy) {
-            cpk[0] = (uint32_t)own8[1];
-            cpk[1] = (uint32_t)(own8[1] >> 32);
-        } else {  // (a hole group's own target bytes: needed when the keys are built -- all keys stay unused)
-            const unsigned long long t8 = *reinterpret_cast<const unsigned long long *>(tgt[own_b] + i0);
-            cpk[0] = (uint32_t)t8;
-            cpk[1] = (uint32_t)(t8 >> 32);
-        }
-        if (!hole || proxy) {
-            // (tried: the eight distances as one unpredicated basic block, results sorted out afterwards
-            // -- 0.623 ms per launch against 0.602: the longer live ranges cost more than the branches)
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                uint32_t wn[2];
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    const uint32_t pb = (uint32_t)(prv8[k] >> (8 * j)), ob = (uint32_t)(own8[k] >> (8 * j)),
-                                   nb = (uint32_t)(nxt8[k] >> (8 * j));
-                    wn[k] = ((pb >> 4) & 7u) | ((ob & 0x7fu) << 3) | ((nb & 7u) << 10);  // = masked_window<kDHGR>
-                }
-                if (!proxy) tmv[j] = wn[1];
-                if (!mt_wave) {
-                    const uint32_t d = diff_weight(wn[0], wn[1], yb + j);
-                    if (proxy) dwx[(grp - 960) * 8 + j] = (uint16_t)d;
-                    else dwv[j] = d;
-                }
-            }
-        }
-    } else {
-        const int page = i0 >> 8;
-        const uint8_t *cur_own = cur[own_b] + page * 256, *tgt_own = tgt[own_b] + page * 256;
-        const bool hole = is_hole(i0 & 255);   // holes come in aligned groups of eight (120..127, 248..255)
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-            const int y = (i0 & 255) + j;
-            tmv[j] = tmv[j + 1] = 0;
-            dwv[j] = dwv[j + 1] = 0;
-            cpk[j >> 2] |= ((uint32_t)tgt_own[y] << (8 * (j & 3))) | ((uint32_t)tgt_own[y + 1] << (8 * ((j + 1) & 3)));
-            if (hole) {  // video.py:111
-                if ((cur_own[y] | cur_own[y + 1]) != 0) bad = kErrHoles;  // video.py:87
-                continue;
-            }
-            uint32_t cm0, tm0, cm1, tm1;
-            windows(page, y, cm0, tm0);
-            windows(page, y + 1, cm1, tm1);
-            tmv[j] = tm0;
-            tmv[j + 1] = tm1;
-            if (!mt_wave) diff_weight_pair(cm0, tm0, cm1, tm1, y, dwv[j], dwv[j + 1]);
-        }
-    }
-    if (MODE != kDHGR && tid < 512) {
-        const int page = 30 + (tid >> 8), y = tid & 255;
-        uint32_t d = 0;
-        if (!is_hole(y)) {
-            uint32_t cm, tm;
-            windows(page, y, cm, tm);
-            d = diff_weight(cm, tm, y);
-        }
-        dwx[tid] = (uint16_t)d;
-    }
-    __syncthreads();
-    if (mt_wave && !is_hole(i0 & 255)) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) dwv[j] = dwx[(tid - (kProThreads - 64)) * 8 + j];
-    }
-    uint32_t nzmask = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        int32_t u = upv[j];
-        if (dwv[j] == 0) u = 0;  // video.py:115
-        u += (int32_t)dwv[j];    // video.py:116
-        if (u < 0) bad = kErrNegative;  // video.py:117
-        upv[j] = u;
-        if (u != 0) nzmask |= 1u << j;
-    }
-    {
-        int4 *p = reinterpret_cast<int4 *>(S.up[is_aux] + i0);
-        p[0] = make_int4(upv[0], upv[1], upv[2], upv[3]);
-        p[1] = make_int4(upv[4], upv[5], upv[6], upv[7]);
-        uint4 *q = reinterpret_cast<uint4 *>(S.wd + i0);
-        // wd = left row | right row | diff weight (iiv_stream.h); byte i0 + j has parity j & 1
-        uint32_t wv[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            wv[j] = wd_word(split_row_left<MODE>(tmv[j], j & 1), split_row_right<MODE>(tmv[j], j & 1), dwv[j]);
-        q[0] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
-        q[1] = make_uint4(wv[4], wv[5], wv[6], wv[7]);
-        reinterpret_cast<uint8_t *>(S.nzbits)[tid] = (uint8_t)nzmask;  // bit j of byte tid = byte 8*tid+j
-        if (tid < 256) S.pdone[tid] = 0;
-    }
-    if (bad) flag_bad = bad;
-
-    IIV_STAMP(2);
-    // row-major rank of each non-zero entry (its index into the nonce draw, video.py:259-265)
-    int n;
-    const int rank0 = block_scan_excl<kProThreads>(__popc(nzmask), tid, wsum, n);
-
-    // ---- bucket the priorities: 1024 buckets over [0, max].  This is a counting sort
-    // (bucket starts = cumulative counts from the top bucket down) whose tiny buckets
-    // (~7 entries) are finished below by ranking each entry inside its own bucket; it
-    // replaces ~65 dependent bitonic stages by four barriers.
-    // It also yields the optional prefix selection: a generator that will be asked for
-    // at most B opcodes consumes at most 3B list entries (one primary and at most two
-    // secondaries resolved to zero per opcode), so when the host knows B (`need` = 3B)
-    // only the buckets holding the `need` highest priorities are ordered at all (every
-    // entry of the boundary bucket is kept: a superset of the true top-`need`).
-    uint32_t *hist = aux4k;  // the string LUTs are dead by now
-    int sh;
-    {
-        int mx = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) mx = upv[j] > mx ? upv[j] : mx;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            int o = __shfl_xor(mx, d, 64);
-            mx = o > mx ? o : mx;
-        }
-        hist[tid] = 0;
-        __syncthreads();  // (also orders the previous wsum reads before this write)
-        if ((tid & 63) == 0) wsum[tid >> 6] = (uint32_t)mx;
-        __syncthreads();
-        for (int w = 0; w < kProThreads / 64; w++) mx = (int)wsum[w] > mx ? (int)wsum[w] : mx;
-        sh = mx < 1024 ? 0 : (32 - __clz(mx)) - 10;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; j++)
-        if (nzmask & (1u << j)) atomicAdd(&hist[upv[j] >> sh], 1u);
-    __syncthreads();
-    // thread t owns bucket 1023 - t; bstart = number of entries in higher buckets
-    const int bcount = (int)hist[1023 - tid];
-    int total_unused;
-    const int bstart = block_scan_excl<kProThreads>(bcount, tid, wsum, total_unused);
-    if (tid == 0) {
-        sel_bucket = 0;
-        sel_count = n;
-        big_bucket = 0;
-    }
-    __syncthreads();
-    const bool want_prefix = need > 0 && need <= kSelNeedMax && n > need;
-    if (want_prefix && bstart < need && bstart + bcount >= need) {
-        sel_bucket = 1023 - tid;
-        sel_count = bstart + bcount;
-    }
-    __syncthreads();
-    const int n_sel = sel_count;
-    const int first_bucket = sel_bucket;  // buckets >= this are ordered
-    if (bcount > kBucketMax && (1023 - tid) >= first_bucket) big_bucket = 1;
-    uint32_t selmask = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++)
-        if ((nzmask & (1u << j)) && (upv[j] >> sh) >= first_bucket) selmask |= 1u << j;
-    __syncthreads();  // hist is dead from here on; big_bucket is final
-    const bool by_buckets = big_bucket == 0;
-
-    IIV_STAMP(3);
-    // n draws of np.random.randint(0, 256): low byte of the next n MT outputs (video.py:265).
-    // Draw r is output first + r of the block sequence (block 0 = mtb[0], block k = gen[k - 1]);
-    // the stream is left in the block holding the last draw.
-    {
-        const int blk = first + n > 0 ? (first + n - 1) / 624 : 0;
-        const uint32_t *fin = blk ? gen + (blk - 1) * 624 : mtb[0];
-        for (int w = tid; w < 624; w += kProThreads) S.mt_np[w] = fin[w];
-        if (tid == 0) {
-            S.mt_np_idx = first + n - blk * 624;
-            S.draws_np += (unsigned long long)n;
-        }
-    }
-
-    IIV_STAMP(4);
-    // keys (-priority, nonce, page, offset) -> ascending u64 (video.py:259-268); bytes
-    // whose priority is zero (or that were not selected) get the all-ones key and sink
-    unsigned long long kv[8];
-    {
-        int bk = (first + rank0) / 624, bw = first + rank0 - bk * 624;  // block / word of this thread's next draw
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            kv[j] = ~0ull;
-            if (nzmask & (1u << j)) {
-                // the content byte rides in the low bits (offsets are unique, so it never
-                // takes part in the ordering)
-                if (selmask & (1u << j)) {
-                    const uint32_t nonce = mt_temper((bk ? gen + (bk - 1) * 624 : mtb[0])[bw]) & 0xffu;
-                    kv[j] = ((unsigned long long)(0x7fffffffu - (uint32_t)upv[j]) << 29) |
-                            ((unsigned long long)nonce << 21) | ((unsigned long long)(i0 + j) << 8) |
-                            (unsigned long long)((cpk[j >> 2] >> (8 * (j & 3))) & 0xffu);
-                }
-                if (++bw == 624) {
-                    bw = 0;
-                    bk++;
-                }
-            }
-        }
-    }
-    IIV_STAMP(5);
-    if (by_buckets) {
-        // counting sort: scatter every selected key into its bucket's slot range, then
-        // rank it among the (few) keys of the same bucket
-        uint32_t *cursor = aux4k;                                 // histogram is dead
-        uint32_t *start = reinterpret_cast<uint32_t *>(mtb);      // MT state is back in HBM
-        __syncthreads();
-        cursor[1023 - tid] = (uint32_t)bstart;
-        start[1023 - tid] = (uint32_t)bstart;
-        __syncthreads();
-        IIV_STAMP(8);
-        // (the bucket is recovered from the key, so the priorities need not stay in registers)
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            if (kv[j] != ~0ull) {
-                const uint32_t bk = (0x7fffffffu - (uint32_t)(kv[j] >> 29)) >> sh;
-                keys[atomicAdd(&cursor[bk], 1u)] = kv[j];
-            }
-        __syncthreads();
-        IIV_STAMP(9);
-        // rank: the scattered keys lie densely in keys[0, n_sel) grouped by bucket; thread t takes
-        // slot t (not "its own" entries, which in prefix mode occupy ~1 lane in 9) and counts
-        // the smaller keys of that key's bucket, four independent LDS reads per trip
-        for (int t = tid; t < n_sel; t += kProThreads) {
-            const unsigned long long key = keys[t];
-            const int bk = (int)((0x7fffffffu - (uint32_t)(key >> 29)) >> sh);
-            const int s0 = (int)start[bk];
-            const int e0 = bk == 0 ? n : (int)start[bk - 1];
-            const int last = e0 - 1;
-            int below = 0;
-            for (int i = s0; i < e0; i += 4) {
-                const unsigned long long k0 = keys[i];
-                const unsigned long long k1 = keys[i + 1 < e0 ? i + 1 : last];
-                const unsigned long long k2 = keys[i + 2 < e0 ? i + 2 : last];
-                const unsigned long long k3 = keys[i + 3 < e0 ? i + 3 : last];
-                below += (k0 < key ? 1 : 0) + ((i + 1 < e0 && k1 < key) ? 1 : 0) +
-                         ((i + 2 < e0 && k2 < key) ? 1 : 0) + ((i + 3 < e0 && k3 < key) ? 1 : 0);
-            }
-            S.order[s0 + below] = ((uint32_t)(key >> 8) & 0x1fffu) | (((uint32_t)key & 0xffu) << 16);
-        }
-    } else if (n_sel <= 4 * kProThreads && n_sel < n) {
-        // degenerate buckets, prefix selection still small: compact + bitonic
-        __syncthreads();  // every key is built: the MT blocks under keys[] are dead
-        int tot;
-        int nsel_mine = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) nsel_mine += kv[j] != ~0ull ? 1 : 0;
-        int pos = block_scan_excl<kProThreads>(nsel_mine, tid, wsum, tot);
-        const bool small = tot <= 2 * kProThreads;
-        const int n_pad = small ? 2 * kProThreads : 4 * kProThreads;
-        for (int i = tot + tid; i < n_pad; i += kProThreads) keys[i] = ~0ull;
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            if (kv[j] != ~0ull) keys[pos++] = kv[j];
-        __syncthreads();
-        if (small) {
-            unsigned long long v2[2] = {keys[2 * tid], keys[2 * tid + 1]};
-            __syncthreads();
-            bitonic_sort<2, kProThreads>(v2, keys, tid);
-            write_order<2>(S.order, v2, tid);
-        } else {
-            unsigned long long v4[4] = {keys[4 * tid], keys[4 * tid + 1], keys[4 * tid + 2], keys[4 * tid + 3]};
-            __syncthreads();
-            bitonic_sort<4, kProThreads>(v4, keys, tid);
-            write_order<4>(S.order, v4, tid);
-        }
-    } else {
-        // order everything with the bitonic network (keys not selected sink to the end)
-        __syncthreads();  // every key is built: the MT blocks under keys[] are dead
-        bitonic_sort<8, kProThreads>(kv, keys, tid);
-        write_order<8>(S.order, kv, tid);  // entries >= n_sel are never read
-    }
-    IIV_STAMP(6);
-    IIV_STAMP(7);
-    if (tid == 0) {
-        S.n_sorted = n_sel;
-        S.truncated = n_sel < n ? 1 : 0;
-        S.head = 0;
-        S.n_pushed = 0;
-        S.exhausted = 0;
-        S.gen_active = 1;
-        S.gen_is_aux = is_aux;
-        S.gen_frame = frame;
-        S.pad_content = tgt_first;
-        if (flag_bad && S.error == 0) S.error = flag_bad;
-    }
-}
-
-template <int MODE, int DP>
-__global__ __launch_bounds__(kProThreads, 8) void prologue_kernel(StreamState *__restrict__ states,
-                                                               const uint8_t *__restrict__ frames_main,
-                                                               const uint8_t *__restrict__ frames_aux, int n_frames,
-                                                               const LaunchSeg *__restrict__ segs, int seg_stride,
-                                                               const uint16_t *__restrict__ table,
-                                                               const ulonglong2 *__restrict__ strings,
-                                                               const uint16_t *__restrict__ sub,
-                                                               const uint32_t *__restrict__ dwl,
-                                                               const uint32_t *__restrict__ dwr,
-                                                               const uint2 *__restrict__ hgr_slut)
-{
-    const LaunchSeg seg = segs[(size_t)blockIdx.x * seg_stride];
-    prologue_body<MODE, DP>(states, frames_main, frames_aux, n_frames, seg, table, strings, sub, dwl, dwr, hgr_slut);
-}
-
-// ------------------------------------------------------------------------- greedy
-
-constexpr int kChunk = 8;  // initial-list entries whose store-table rows are gathered together
-
-// JOINT (f4, README.md:212-215 "Global optimization"; NOT reference behaviour, IIV_OPT_CONTENT_CHOICE):
-// the content byte of a step is not the primary's target byte but the value c that maximises
-//     R(c) = (dw[primary] - nd_c[primary]) - (d1 + d2),
-// d1, d2 = the two smallest negative deltas nd_c[y] - dw[y] among the page's other bytes with non-zero
-// priority (ties: the target byte, then the smallest c), and the primary keeps nd_c[primary] as its
-// priority.  All else is the reference's step applied to the chosen byte.  Each wave scores a quarter
-// of the byte values over the whole page (4 bytes per lane), two wave minima per value.
-template <int MODE, bool JOINT>
-__global__ __launch_bounds__(256) void greedy_kernel(StreamState *__restrict__ states,
-                                                     const uint8_t *__restrict__ frames_main,
-                                                     const uint8_t *__restrict__ frames_aux, int n_frames,
-                                                     const LaunchSeg *__restrict__ segs, int seg_stride,
-                                                     const uint16_t *__restrict__ store,
-                                                     const uint32_t *__restrict__ left_t,
-                                                     const uint32_t *__restrict__ right_t,
-                                                     uint8_t *__restrict__ ops_out, size_t ops_stride)
-{
-    const LaunchSeg seg = segs[(size_t)blockIdx.x * seg_stride];
-    const int n_ops = __builtin_amdgcn_readfirstlane(seg.n_ops), is_aux = __builtin_amdgcn_readfirstlane(seg.is_aux);
-    const int frame = __builtin_amdgcn_readfirstlane(seg.frame);
-    const size_t ops_base = (size_t)__builtin_amdgcn_readfirstlane(seg.ops_base) * 6;
-    if (n_ops <= 0) return;
-    constexpr int BITS = ModeTraits<MODE>::kBits;
-    constexpr int CB = ModeTraits<MODE>::kContentBits;
-    constexpr int NB = ModeTraits<MODE>::kBanks;
-    constexpr uint32_t INF = 0xffffffffu;
-    __shared__ __attribute__((aligned(16))) uint8_t tgt[NB][8192];  // [0] = bank being encoded, [1] = the other one
-    __shared__ __attribute__((aligned(16))) uint16_t dwf[8192];     // diff_weight | (priority != 0) << 15
-    __shared__ uint32_t mt[2][624];
-    __shared__ uint32_t xw_cnt[4];
-    __shared__ uint32_t xw_key[8];
-    __shared__ unsigned long long xw_pop[4];
-    __shared__ int xw_joint[4];
-    __shared__ uint32_t xw_m12[JOINT ? 4 : 1][JOINT ? (1 << ModeTraits<MODE>::kContentBits) : 1];
-    constexpr int CH = JOINT ? 1 : kChunk;  // (a joint step knows its content only after scoring every value)
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    StreamState &S = states[blockIdx.x];
-    const size_t fbase = ((size_t)blockIdx.x * n_frames + frame) * 8192;
-    uint8_t *out = ops_out + (size_t)blockIdx.x * ops_stride + ops_base;
-
-    if (!S.gen_active || S.error) {
-        if (tid == 0 && !S.error) S.error = kErrNoGenerator;
-        return;
-    }
-
-    // ---- stage target bytes, diff weights + validity flags, sorted order, RNG block
-    for (int i = tid; i < 512 * NB; i += 256) {
-        int b = i >> 9, k = i & 511;
-        const uint8_t *src;
-        if (MODE == kDHGR)
-            src = ((b == 0) == (is_aux != 0) ? frames_aux : frames_main) + fbase;
-        else
-            src = frames_main + fbase;
-        reinterpret_cast<uint4 *>(tgt[b])[k] = reinterpret_cast<const uint4 *>(src)[k];
-    }
-    for (int i = tid; i < 8192; i += 256) {
-        uint32_t bit = (S.nzbits[i >> 5] >> (i & 31)) & 1u;
-        uint32_t dn = (S.pdone[i >> 5] >> (i & 31)) & 1u;
-        dwf[i] = (uint16_t)((dn ? 0u : (S.wd[i] >> kWdDwShift)) | (bit << 15));
-    }
-    for (int i = tid; i < 624; i += 256) mt[0][i] = S.mt_py[i];
-    __syncthreads();
-    int cb = 0;  // mt[cb] = current block, mt[cb^1] = the block after it
-    mt_twist<256>(mt[0], mt[1], tid);
-    int mt_idx = S.mt_py_idx;
-    if (mt_idx >= 624) {
-        mt_twist<256>(mt[1], mt[0], tid);
-        cb = 1;
-        mt_idx -= 624;
-    }
-
-    const int n_sorted = S.n_sorted;
-    int head = S.head, n_pushed = S.n_pushed, exhausted = S.exhausted;
-    int done = 0, err = 0;
-    unsigned long long draws = 0, pad_ops = 0;
-    const int y = tid;
-    const int odd = y & 1;
-    const int o = byte_offset<MODE>(y, is_aux);
-    const uint16_t *store_o = store + ((size_t)o << (CB + BITS));
-
-    // every iteration either emits an opcode, skips >= 1 list entry or pops a pushed
-    // entry, so this bound is never reached; it turns a logic error into an error
-    // code instead of a hung GPU.
-    int guard = n_ops + 8192 + 2 * kPushedCap + 64;
-    while (done < n_ops && !err) {
-        if (--guard < 0) {
-            err = kErrGuard;
-            break;
-        }
-        if (exhausted) {
-            // video.py:249-251: pad forever with (32, target[0,0], [0,0,0,0])
-            uint32_t c0 = tgt[0][0];
-            for (int i = done + tid; i < n_ops; i += 256) {
-                uint8_t *q = out + (size_t)i * 6;
-                q[0] = 32; q[1] = (uint8_t)c0; q[2] = 0; q[3] = 0; q[4] = 0; q[5] = 0;
-            }
-            pad_ops += (unsigned long long)(n_ops - done);
-            done = n_ops;
-            break;
-        }
-
-        // ---- form a chunk of entries (uniform across the workgroup)
-        uint32_t ent[CH];
-        int pos[CH];
-        int cnt = 0, chunk_end = head;
-        bool from_pushed = false;
-        __syncthreads();  // validity flags written by their owner lanes -> visible to the scan
-        if (head < n_sorted) {
-            int idx = head + lane;
-            uint32_t e = idx < n_sorted ? (S.order[idx] & 0x1fffu) : 0u;
-            bool v = idx < n_sorted && (dwf[e] & 0x8000u);
-            unsigned long long mask = __ballot(v);
-            int window_end = head + 64 < n_sorted ? head + 64 : n_sorted;
-            if (mask == 0) {
-                head = window_end;
-                continue;
-            }
-#pragma unroll
-            for (int m = 0; m < CH; m++) {
-                ent[m] = 0;
-                pos[m] = 0;
-                if (mask) {
-                    int l = __builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    ent[m] = __builtin_amdgcn_readlane(e, l);
-                    pos[m] = head + l;
-                    cnt = m + 1;
-                }
-            }
-            chunk_end = mask ? pos[CH - 1] + 1 : window_end;
-        } else {
-            if (S.truncated) {  // more initial entries exist than were ordered: host budget bug
-                err = kErrSortBudget;
-                break;
-            }
-            // pop-min over the pushed bag
-            from_pushed = true;
-            unsigned long long best = ~0ull;
-            for (int i = tid; i < n_pushed; i += 256) {
-                unsigned long long k = ((unsigned long long)S.pushed[i] << 32) | (unsigned)i;
-                best = k < best ? k : best;
-            }
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                unsigned long long other = __shfl_xor(best, d, 64);
-                best = other < best ? other : best;
-            }
-            if (lane == 0) xw_pop[wave] = best;
-            __syncthreads();
-            best = xw_pop[0];
-            for (int w = 1; w < 4; w++) best = xw_pop[w] < best ? xw_pop[w] : best;
-            uint32_t bk = (uint32_t)(best >> 32);
-            if (bk == INF) {
-                exhausted = 1;  // video.py:189
-                continue;
-            }
-            if (tid == 0) S.pushed[(uint32_t)best] = INF;
-#pragma unroll
-            for (int m = 0; m < CH; m++) {
-                ent[m] = 0;
-                pos[m] = 0;
-            }
-            ent[0] = bk & 0x1fff;
-            cnt = 1;
-            if (!(dwf[ent[0]] & 0x8000u)) continue;  // video.py:130
-        }
-
-        // ---- joint mode: choose the entry's content byte.  Lane l holds the byte values l, l + 64, ...
-        // (two per lane DHGR, four HGR); wave w walks the eligible bytes of its quarter of the page: a
-        // byte's row parts are wave-uniform, so the row of every byte value is one (left) or two (right)
-        // cache lines read with lane-consecutive addresses, and each lane keeps the two smallest
-        // deltas of its own byte values -- no reduction until the waves' quarters are merged in LDS.
-        uint32_t joint_c = 0, joint_res = 0;
-        if (JOINT) {
-            using T = SplitTraits<MODE>;
-            constexpr int NS = (1 << CB) / 64;
-            const int p = ent[0] >> 8, x = ent[0] & 255;
-            const uint32_t tc = tgt[0][ent[0]];
-            const uint8_t *own_row = tgt[0] + p * 256;
-            const uint8_t *oth_row = tgt[NB - 1] + p * 256;
-            // content parts of this lane's byte values, for even and odd bytes
-            uint32_t cl[NS][2], cr[NS][2];
-#pragma unroll
-            for (int j = 0; j < NS; j++)
-#pragma unroll
-                for (int od = 0; od < 2; od++) {
-                    cl[j][od] = split_content_left<MODE>((uint32_t)(lane + 64 * j), od);
-                    cr[j][od] = split_content_right<MODE>((uint32_t)(lane + 64 * j), od);
-                }
-            // values of every byte value for the byte with window `win` at parity `od`
-            auto row_values = [&](uint32_t win, int yy, int (&nd)[NS]) {
-                const int od = yy & 1, o = byte_offset<MODE>(yy, is_aux);
-                const uint32_t *lrow = left_t + ((((size_t)o << T::kLeftRowBits) + split_row_left<MODE>(win, od)) << T::kLeftCBits);
-                const uint32_t *rrow =
-                    right_t + ((((size_t)o << T::kRightRowBits) + split_row_right<MODE>(win, od)) << T::kRightCBits);
-#pragma unroll
-                for (int j = 0; j < NS; j++) nd[j] = (int)combine(lrow[cl[j][od]], rrow[cr[j][od]]);
-            };
-            // this lane's byte of the wave's quarter: window, diff weight, eligibility
-            const int ym = 64 * wave + lane;
-            uint32_t pv, nx;
-            neighbours<MODE>(own_row, oth_row, ym, is_aux, pv, nx);
-            const uint32_t win_m = masked_window<MODE>(pv, own_row[ym], nx, ym & 1);
-            const uint32_t wv = dwf[p * 256 + ym];
-            const int dw_m = (int)(wv & 0x7fffu);
-            // (a byte with priority 0, the primary itself, or a zero diff weight can never yield d < 0)
-            unsigned long long todo = __ballot((wv & 0x8000u) && ym != x && dw_m != 0);
-            int m1[NS], m2[NS];  // per byte value: the two smallest negative deltas (m1 <= m2 <= 0)
-#pragma unroll
-            for (int j = 0; j < NS; j++) m1[j] = m2[j] = 0;
-            while (todo) {
-                // four bytes per trip, their rows in flight together (a missing one repeats the first
-                // with diff weight 0: d >= 0 changes nothing)
-                constexpr int U = 4;
-                uint32_t wins[U];
-                int dws[U], ys[U];
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    if (todo) {
-                        const int k = __builtin_ctzll(todo);
-                        todo &= todo - 1;
-                        wins[u] = __builtin_amdgcn_readlane(win_m, k);
-                        dws[u] = __builtin_amdgcn_readlane(dw_m, k);
-                        ys[u] = 64 * wave + k;
-                    } else {
-                        wins[u] = wins[0];
-                        dws[u] = 0;
-                        ys[u] = ys[0];
-                    }
-                }
-                int nd[U][NS];
-#pragma unroll
-                for (int u = 0; u < U; u++) row_values(wins[u], ys[u], nd[u]);
-#pragma unroll
-                for (int u = 0; u < U; u++)
-#pragma unroll
-                    for (int j = 0; j < NS; j++) {
-                        const int d = nd[u][j] - dws[u];
-                        const int lo = d < m1[j] ? d : m1[j], hi = d < m1[j] ? m1[j] : d;
-                        m1[j] = lo;
-                        m2[j] = hi < m2[j] ? hi : m2[j];
-                    }
-            }
-#pragma unroll
-            for (int j = 0; j < NS; j++) xw_m12[wave][lane + 64 * j] = (uint32_t)(uint16_t)m1[j] | ((uint32_t)(uint16_t)m2[j] << 16);
-            // the primary's own byte (uniform)
-            const uint32_t winx = __builtin_amdgcn_readfirstlane(__shfl(win_m, x & 63, 64));  // valid in wave x >> 6 only
-            if (wave == (x >> 6) && lane == 0) xw_joint[0] = (int)winx;
-            __syncthreads();
-            int ndx[NS];
-            row_values((uint32_t)xw_joint[0], x, ndx);
-            const int dwx = (int)(dwf[p * 256 + x] & 0x7fffu);
-            int best = -2147483647 - 1;
-#pragma unroll
-            for (int j = 0; j < NS; j++) {
-                int a1 = 0, a2 = 0;
-#pragma unroll
-                for (int w = 0; w < 4; w++) {
-                    const uint32_t v = xw_m12[w][lane + 64 * j];
-                    const int b1 = (int)(int16_t)(v & 0xffffu), b2 = (int)(int16_t)(v >> 16);
-                    const int lo = b1 < a1 ? b1 : a1, hi = b1 < a1 ? a1 : b1;
-                    a1 = lo;
-                    a2 = hi < a2 ? hi : a2;
-                    a2 = b2 < a2 ? b2 : a2;
-                }
-                const int c = lane + 64 * j;
-                const int key = (dwx - ndx[j] - a1 - a2) * 512 + ((uint32_t)c == tc ? 256 : 0) + (255 - c);
-                best = key > best ? key : best;
-            }
-            best = -wave_min_i32(-best);
-            joint_c = 255u - ((uint32_t)best & 255u);
-            // what the chosen value leaves at the primary: lane joint_c & 63 holds it in slot joint_c >> 6
-            int res = 0;
-#pragma unroll
-            for (int j = 0; j < NS; j++) res = (int)(joint_c >> 6) == j ? ndx[j] : res;
-            joint_res = (uint32_t)__builtin_amdgcn_readlane(res, joint_c & 63);
-            __syncthreads();  // (xw_m12 / xw_joint are rewritten by the next step)
-        }
-
-        // ---- gather the store-table row of every chunk entry (all in flight together)
-        uint32_t ndv[CH];
-#pragma unroll
-        for (int m = 0; m < CH; m++) {
-            {   // branch-free: see greedy_wave_kernel
-                int p = ent[m] >> 8;
-                uint32_t c = JOINT ? joint_c : tgt[0][ent[m]];
-                const uint8_t *own_row = tgt[0] + p * 256;
-                const uint8_t *oth_row = tgt[NB - 1] + p * 256;
-                uint32_t pv, nx;
-                neighbours<MODE>(own_row, oth_row, y, is_aux, pv, nx);
-                uint32_t win = masked_window<MODE>(pv, own_row[y], nx, odd);
-                ndv[m] = store_o[((size_t)(c & ((1u << CB) - 1)) << BITS) + win];
-            }
-        }
-
-        __builtin_amdgcn_sched_barrier(0);  // retire the gathers here: see greedy_wave_kernel
-#pragma unroll
-        for (int m = 0; m < CH; m++) asm volatile("" : "+v"(ndv[m]));
-        __builtin_amdgcn_sched_barrier(0);
-
-        // ---- process the chunk sequentially
-        uint32_t dead = 0;
-#pragma unroll
-        for (int m = 0; m < CH; m++) {
-            if (m >= cnt || done >= n_ops || err) break;
-            if (dead & (1u << m)) {
-                head = pos[m] + 1;
-                continue;
-            }
-            const int p = ent[m] >> 8, x = ent[m] & 255;
-            if (MODE == kDHGR && tgt[0][ent[m]] >= 0x80) {   // video.py:137
-                err = kErrPaletteBit;
-                break;
-            }
-            const uint32_t c = JOINT ? joint_c : tgt[0][ent[m]];  // video.py:134
-            const uint32_t nd = ndv[m];
-            const uint32_t w = dwf[p * 256 + y];
-            const uint32_t dwy = (y == x) ? 0u : (w & 0x7fffu);       // video.py:141
-            const bool nzy = (w & 0x8000u) && (y != x);               // video.py:140
-            const int d = (int)nd - (int)dwy;                         // screen.py:547
-            const bool cand = d < 0;                                  // video.py:283
-            const unsigned long long bal = __ballot(cand);
-            if (lane == 0) xw_cnt[wave] = (uint32_t)__popcll(bal);
-            __syncthreads();
-            const uint32_t c0 = xw_cnt[0], c1 = xw_cnt[1], c2 = xw_cnt[2], c3 = xw_cnt[3];
-            const int C = (int)(c0 + c1 + c2 + c3);
-            const int wbase = (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
-            uint32_t key = INF;
-            if (cand) {
-                // one random.getrandbits(8) per candidate, ascending offset (video.py:290-293)
-                int j = mt_idx + wbase + prefix_popc(bal);
-                uint32_t word = j < 624 ? mt[cb][j] : mt[cb ^ 1][j - 624];
-                uint32_t nonce = mt_temper(word) >> 24;
-                if (nzy)  // video.py:159
-                    key = ((uint32_t)(d + 2048) << 17) | (nonce << 9) | ((uint32_t)y << 1) | (nd != 0 ? 1u : 0u);
-            }
-            uint32_t k1 = key, k2 = INF;
-#pragma unroll
-            for (int s = 1; s < 64; s <<= 1) {
-                uint32_t o1 = __shfl_xor(k1, s, 64), o2 = __shfl_xor(k2, s, 64);
-                uint32_t lo = k1 < o1 ? k1 : o1, hi = k1 < o1 ? o1 : k1;
-                uint32_t m2 = k2 < o2 ? k2 : o2;
-                k1 = lo;
-                k2 = hi < m2 ? hi : m2;
-            }
-            if (lane == 0) {
-                xw_key[2 * wave] = k1;
-                xw_key[2 * wave + 1] = k2;
-            }
-            __syncthreads();
-            uint32_t K1 = INF, K2 = INF;
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                uint32_t k = xw_key[q];
-                if (k < K1) {
-                    K2 = K1;
-                    K1 = k;
-                } else if (k < K2) {
-                    K2 = k;
-                }
-            }
-            const int y1 = K1 != INF ? (int)((K1 >> 1) & 255) : -1;
-            const int f1 = K1 != INF ? (int)(K1 & 1) : 0;
-            const int y2 = K2 != INF ? (int)((K2 >> 1) & 255) : -1;
-            const int f2 = K2 != INF ? (int)(K2 & 1) : 0;
-            if (n_pushed + f1 + f2 > kPushedCap) {
-                err = kErrPushedOverflow;
-                break;
-            }
-
-            // ---- apply (video.py:140-144, 170-178; screen.py:256-293)
-            if (y == x) {
-                dwf[p * 256 + x] = 0;
-                S.up[is_aux][p * 256 + x] = JOINT ? (int32_t)joint_res : 0;
-                S.mem[is_aux][p * 256 + x] = (uint8_t)c;
-            }
-            if (y == y1 || y == y2) {
-                const int second = (y == y2) ? 1 : 0;
-                S.up[is_aux][p * 256 + y] = (int32_t)nd;  // byte_pair_difference == nd[y] (screen.py:383-398)
-                S.mem[is_aux][p * 256 + y] = (uint8_t)c;
-                dwf[p * 256 + y] = (uint16_t)((w & 0x7fffu) | (nd ? 0x8000u : 0u));
-                if (nd) {
-                    int j = mt_idx + C + (second ? f1 : 0);
-                    uint32_t word = j < 624 ? mt[cb][j] : mt[cb ^ 1][j - 624];
-                    uint32_t nonce = mt_temper(word) >> 24;  // video.py:178
-                    S.pushed[n_pushed + (second ? f1 : 0)] =
-                        ((2047u - nd) << 21) | (nonce << 13) | ((uint32_t)p << 8) | (uint32_t)y;
-                }
-            }
-            if (tid == 0) {
-                uint8_t *q = out + (size_t)done * 6;
-                q[0] = (uint8_t)(p + 32);
-                q[1] = (uint8_t)c;
-                q[2] = (uint8_t)x;
-                q[3] = (uint8_t)(y1 >= 0 ? y1 : x);  // video.py:185-186
-                q[4] = (uint8_t)(y2 >= 0 ? y2 : x);
-                q[5] = (uint8_t)x;
-            }
-            // later chunk entries that this step resolved exactly are now dead
-#pragma unroll
-            for (int m2 = 0; m2 < CH; m2++)
-                if (m2 > m && m2 < cnt) {
-                    if (y1 >= 0 && !f1 && ent[m2] == (uint32_t)((p << 8) | y1)) dead |= 1u << m2;
-                    if (y2 >= 0 && !f2 && ent[m2] == (uint32_t)((p << 8) | y2)) dead |= 1u << m2;
-                }
-            mt_idx += C + f1 + f2;
-            draws += (unsigned long long)(C + f1 + f2);
-            n_pushed += f1 + f2;
-            done++;
-            if (!from_pushed) head = pos[m] + 1;
-            if (mt_idx >= 624) {
-                __syncthreads();  // every lane is done with block cb
-                mt_twist<256>(mt[cb ^ 1], mt[cb], tid);
-                cb ^= 1;
-                mt_idx -= 624;
-            }
-        }
-        if (!from_pushed && !err && done < n_ops) head = chunk_end > head ? chunk_end : head;
-    }
-
-    // ---- write the generator back (flags as bitmaps; diff weights themselves are immutable)
-    __syncthreads();
-    for (int wi = tid; wi < 256; wi += 256) {
-        uint32_t nzw = 0, pdw = S.pdone[wi];
-        for (int b = 0; b < 32; b++) {
-            uint32_t v = dwf[wi * 32 + b];
-            nzw |= ((v >> 15) & 1u) << b;
-            // a byte whose diff weight was non-zero at the prologue and is zero now was a primary
-            if ((v & 0x7fffu) == 0 && (S.wd[wi * 32 + b] >> kWdDwShift) != 0) pdw |= 1u << b;
-        }
-        S.nzbits[wi] = nzw;
-        S.pdone[wi] = pdw;
-    }
-    for (int i = tid; i < 624; i += 256) S.mt_py[i] = mt[cb][i];
-    if (tid == 0) {
-        S.mt_py_idx = mt_idx;
-        S.head = head;
-        S.n_pushed = n_pushed;
-        S.exhausted = exhausted;
-        if (exhausted) S.out_of_work[is_aux] = 1;
-        S.draws_py += draws;
-        S.ops += (unsigned long long)done;
-        S.pad_ops += pad_ops;
-        if (err && S.error == 0) S.error = err;
-    }
-}
 
 // ------------------------------------------------------------------------- host object
 
@@ -1775,20 +667,10 @@ static int launch_round(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux,
     size_t slot = 0;
     if (any_prologue) {
         if (e->profiling) { int prc = prof_begin(e, 0, st, slot); if (prc) return prc; }
-#define IIV_PRO(M, D)                                                                                              \
-    hipLaunchKernelGGL((prologue_kernel<M, D>), dim3(e->n_streams), dim3(kProThreads), 0, st, e->d_states, d_main, \
-                       d_aux, n_frames, d_round, seg_stride, e->d_table, e->d_strings, e->d_sub, e->d_dwl, e->d_dwr, e->d_hgr_slut)
-        if (e->mode == kDHGR) {
-            if (e->dw_mode == IIV_DW_SPLIT) IIV_PRO(kDHGR, IIV_DW_SPLIT);
-            else if (e->dw_mode == IIV_DW_RECURRENCE) IIV_PRO(kDHGR, IIV_DW_RECURRENCE);
-            else IIV_PRO(kDHGR, IIV_DW_TABLE);
-        } else {
-            if (e->dw_mode == IIV_DW_SPLIT) IIV_PRO(kHGR, IIV_DW_SPLIT);
-            else if (e->dw_mode == IIV_DW_RECURRENCE) IIV_PRO(kHGR, IIV_DW_RECURRENCE);
-            else IIV_PRO(kHGR, IIV_DW_TABLE);
-        }
-#undef IIV_PRO
-        IIV_HIP(hipGetLastError());
+        const PrologueArgs pa{e->d_states, d_main, d_aux, n_frames, e->n_streams, d_round, seg_stride, e->d_table, e->d_strings,
+                              e->d_sub, e->d_dwl, e->d_dwr, e->d_hgr_slut};
+        int prc2 = launch_prologue(e->mode, e->dw_mode, pa, st);
+        if (prc2) return prc2;
         if (e->profiling) { int prc = prof_end(e, slot, st); if (prc) return prc; }
     }
     if (!any_greedy) return IIV_OK;
@@ -1815,16 +697,10 @@ static int launch_round(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux,
         int rc = use_team ? launch_greedy_team(e->mode, a, st) : launch_greedy_wave(e->mode, a, st);
         if (rc) return rc;
     } else {
-#define IIV_GREEDY(K)                                                                                                  \
-    hipLaunchKernelGGL(K, dim3(e->n_streams), dim3(256), 0, st, e->d_states, d_main, d_aux, n_frames, d_round, seg_stride, \
-                       e->d_store, e->d_left_t, e->d_right_t, d_ops, ops_stride)
-        if (e->content_choice == IIV_CONTENT_JOINT) {
-            if (e->mode == kDHGR) IIV_GREEDY((greedy_kernel<kDHGR, true>)); else IIV_GREEDY((greedy_kernel<kHGR, true>));
-        } else {
-            if (e->mode == kDHGR) IIV_GREEDY((greedy_kernel<kDHGR, false>)); else IIV_GREEDY((greedy_kernel<kHGR, false>));
-        }
-#undef IIV_GREEDY
-        IIV_HIP(hipGetLastError());
+        const WorkgroupArgs wa{e->d_states, d_main, d_aux, n_frames, e->n_streams, d_round, seg_stride, e->d_store, e->d_left_t,
+                               e->d_right_t, d_ops, ops_stride};
+        int wrc = launch_greedy_workgroup(e->mode, e->content_choice == IIV_CONTENT_JOINT, wa, st);
+        if (wrc) return wrc;
     }
     if (e->profiling) { int prc = prof_end(e, slot, st); if (prc) return prc; }
     return IIV_OK;

@@ -1,5 +1,5 @@
 // iiv_stream.h -- per-stream encoder state in HBM and the formats shared by the
-// prologue (iiv_encode.hip), the greedy kernels (iiv_greedy.hip, iiv_encode.hip) and the
+// prologue (iiv_prologue.hip), the greedy kernels (iiv_greedy.hip, iiv_team.hip, iiv_workgroup.hip) and the
 // split-table builder (iiv_tables.hip).
 // Reference: transcoder/video.py:16-301 (Video state), transcoder/screen.py:383-547.
 #pragma once
@@ -279,7 +279,37 @@ struct GreedyArgs {
     int *queue;              // device: this launch's stream counter, zero (the LDS-shared form's persistent workgroups)
 };
 
-int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st);
+int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st);   // iiv_greedy.hip
 int launch_greedy_team(int mode, const GreedyArgs &a, hipStream_t st);   // iiv_team.hip
+
+
+// ---- the prologue (iiv_prologue.hip) and the workgroup greedy kernel (iiv_workgroup.hip)
+constexpr int kSelNeedMax = 2048;  // the prologue's prefix selection is used when 3 * opcode budget <= this
+constexpr int kBucketMax = 96;     // counting-sort buckets larger than this fall back to the bitonic sort
+struct PrologueArgs {
+    StreamState *states;
+    const uint8_t *frames_main, *frames_aux;
+    int n_frames, n_streams;
+    const LaunchSeg *segs;   // device
+    int seg_stride;
+    const uint16_t *table;          // full symmetric table (IIV_DW_TABLE)
+    const ulonglong2 *strings;      // colour-string LUT
+    const uint16_t *sub;            // 16 x 16 substitution costs
+    const uint32_t *dwl, *dwr;      // split diff-weight table (IIV_DW_SPLIT)
+    const uint2 *hgr_slut;          // HGR: three-lookup string table
+};
+int launch_prologue(int mode, int dw_mode, const PrologueArgs &a, hipStream_t st);
+struct WorkgroupArgs {
+    StreamState *states;
+    const uint8_t *frames_main, *frames_aux;
+    int n_frames, n_streams;
+    const LaunchSeg *segs;
+    int seg_stride;
+    const uint16_t *store;                 // dense store table
+    const uint32_t *left_t, *right_t;      // split store table, content-innermost (joint content choice)
+    uint8_t *ops_out;
+    size_t ops_stride;
+};
+int launch_greedy_workgroup(int mode, bool joint, const WorkgroupArgs &a, hipStream_t st);
 
 }  // namespace iiv

@@ -444,7 +444,7 @@ int expand_narrow_tables(int mode, const NarrowTables &nt, uint16_t *d_out, unsi
 }
 
 // The halves with content innermost -- T[o][row][content part] -- for the joint content choice
-// (iiv_encode.hip, greedy_kernel<MODE, true>): one row's values for every byte value are one or
+// (iiv_workgroup.hip, greedy_kernel<MODE, true>): one row's values for every byte value are one or
 // two cache lines.
 template <int MODE>
 __global__ __launch_bounds__(256) void split_transpose_kernel(const uint32_t *__restrict__ left,

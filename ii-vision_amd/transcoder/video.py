@@ -6,7 +6,7 @@ aux_update_priority, out_of_work, frame_number) and methods (tick, encode_frame)
 and `encode_frame` is still a lazy, never-ending generator of
 (page, content, offsets) tuples.  The work -- diff weights, priority ranking, the
 greedy selection loop and both MT19937 nonce streams -- runs in the gfx950 kernels
-of csrc/iiv_encode.hip through iiv_encode() (include/iivision.h).
+of csrc/iiv_prologue.hip / iiv_greedy.hip / iiv_team.hip through iiv_encode() (csrc/iiv_encode.hip, include/iivision.h).
 
 State model: the device holds the live state while a generator runs; the host numpy
 arrays (memory maps, update priorities, pixelmap.packed, out_of_work) and Python's /
