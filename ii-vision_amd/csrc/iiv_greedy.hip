@@ -314,6 +314,9 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? W / 
     // video.py:140-144, 170-187; screen.py:256-293.  Lanes 0..2 carry (x, y1, y2); a
     // missing secondary repeats the primary's stores.
     // (phase B keeps per-lane minima of the re-queued bag up to date: `track` hands it the keys a step pushes)
+#ifdef IIV_STAMPS
+    int n_ties = 0, n_tie_members = 0, n_ties_small = 0;
+#endif
     uint32_t pkey_v = 0;          // lanes 1, 2: the keys pushed by the latest step (track only)
     int push_f1 = 0, push_f2 = 0, push_base = 0;
     auto apply = [&](auto track, int p, int x, uint32_t c, int y1, uint32_t nd1, int y2, uint32_t nd2, int C) {
@@ -448,6 +451,16 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? W / 
                 }
             }
         }
+#ifdef IIV_STAMPS
+        if (tie) {   // diagnostic build: how often the nonces decide, and among how many bytes (those sharing the smallest delta)
+            int n1 = 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) n1 += (int)__popcll(__ballot(ke[r] < 0 && (ke[r] >> kWdDwShift) == (K1 >> kWdDwShift)));
+            n_ties++;
+            n_tie_members += n1;
+            if (n1 <= 2) n_ties_small++;
+        }
+#endif
         if (tie) {
             // the reference's (delta, nonce, offset) heap order with every candidate's nonce
             // materialised: one random.getrandbits(8) per candidate in ascending offset
@@ -743,6 +756,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? W / 
         S.stamps[27] = (unsigned long long)n_steps;   // list entries that went through the pipeline (emitted or found dead)
         S.stamps[29] = wave_r0;   // start / end on the constant 100 MHz counter all XCDs share
         S.stamps[30] = __builtin_amdgcn_s_memrealtime();
+        S.stamps[31] = (unsigned long long)n_ties | ((unsigned long long)n_ties_small << 20) | ((unsigned long long)n_tie_members << 40);
         S.stamps[28] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 /* XCC_ID */) | (0 << 6) | (31 << 11)) << 32) |
                        (unsigned)__builtin_amdgcn_s_getreg((4 /* HW_ID */) | (0 << 6) | (31 << 11));
 #endif

@@ -76,3 +76,7 @@ span_ticks = ev[-1, 0] - ev[0, 0]
 print("        concurrency from s_memrealtime start / end of every wave: peak %.1f waves per CU, time-average %.1f; span %.1f us; "
       "quartiles of the span: %s waves per CU" % (conc.max() / 256.0, (conc[:-1] * dt).sum() / span_ticks / 256.0, span_ticks / 100.0,
           [round(float(conc[np.searchsorted(ev[:, 0], ev[0, 0] + q * span_ticks)]) / 256.0, 1) for q in (0.1, 0.25, 0.5, 0.75, 0.9)]))
+tt = full[:, 31]
+nt, nsmall, nmem = (tt & 0xfffff).sum(), ((tt >> 20) & 0xfffff).sum(), (tt >> 40).sum()
+print("        ties (the nonces decide the two extra offsets): %.1f %% of the opcodes; bytes sharing the smallest delta at a tie: %.1f on average; "
+      "ties with <= 2 such bytes: %.0f %%" % (100.0 * nt / max(full[:, 26].sum(), 1), nmem / max(nt, 1), 100.0 * nsmall / max(nt, 1)))
