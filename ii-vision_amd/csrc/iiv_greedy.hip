@@ -52,6 +52,9 @@ namespace iiv {
 #ifndef IIV_SHARED_W
 #define IIV_SHARED_W 8
 #endif
+#ifndef IIV_SHARED_W_HGR
+#define IIV_SHARED_W_HGR 16
+#endif
 struct WaveLds {                // per stream: 5568 B
     uint32_t nz[256];           // update_priority != 0
     uint32_t pdone[256];        // byte already emitted as a primary (its diff weight counts as 0)
@@ -69,7 +72,7 @@ template <int MODE> struct SharedCfg {
     static constexpr int kL1Bytes = kOffsets * kHalfBytes;
     static constexpr int kZero = kL1Bytes;       // a zero word behind them (excepted bytes, iiv_stream.h)
     static constexpr int kPad = kL1Bytes + 256;
-    static constexpr int kW = MODE == kDHGR ? IIV_SHARED_W : 16;
+    static constexpr int kW = MODE == kDHGR ? IIV_SHARED_W : IIV_SHARED_W_HGR;
     static constexpr int kLds = kPad + kW * (int)sizeof(WaveLds);
 };
 
@@ -80,7 +83,7 @@ __device__ static inline WaveLds *own_wave_lds()
 }
 
 template <int MODE, int W>
-__global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? W / 4 : (2 * W + 3) / 4 + (W % 4 ? 1 : 0)) void greedy_wave_kernel(StreamState *__restrict__ states,
+__global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W + 3) / 4 : (2 * W + 3) / 4 + (W % 4 ? 1 : 0)) void greedy_wave_kernel(StreamState *__restrict__ states,
                                                                    const uint8_t *__restrict__ frames_main,
                                                                    const uint8_t *__restrict__ frames_aux, int n_frames,
                                                                    const LaunchSeg *__restrict__ segs, int seg_stride,
