@@ -554,7 +554,24 @@ def _single_stream(be, args):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     b.close()
-    return {"value": 50 / dt, "unit": "frames/s", "us_per_opcode": 1e6 * dt / (50 * OPS_PER_FRAME)}
+    out = {"value": 50 / dt, "unit": "frames/s", "us_per_opcode": 1e6 * dt / (50 * OPS_PER_FRAME)}
+    # the same on picture-like input (S-img): there the nonces decide nearly every step's extra offsets (96 % of the
+    # opcodes), which used to end the eight-wave kernel's run of concurrent steps at each of them
+    try:
+        fm, fa = be.sb.synth_frames_img(1, 60, be.dhgr, seed=99)
+        b = be.sb.StreamBatch(be.mode, be.table, be.store, 1, seeds=[(1, 1)], dm=be.dm, joint_content=args.joint)
+        b.enc.set_greedy_kernel({"auto": None, "wave": True, "workgroup": False}.get(args.greedy, args.greedy))
+        b.encode_frames(fm, fa, 10)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        b.encode_frames(fm, fa, 50)
+        torch.cuda.synchronize()
+        out["value_img"] = 50 / (time.perf_counter() - t0)
+        b.close()
+    except Exception as e:
+        out["value_img"] = None
+        out["value_img_error"] = repr(e)
+    return out
 
 
 def _make_data_tables_seconds():

@@ -159,6 +159,7 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
         int C, y1, y2;
         uint32_t nd1, nd2;
         bool tie, live;
+        bool tie_soft;   // the nonces decide the winners, but not how many entries the step re-queues: it need not end the run
     };
     auto nd_of = [&](const Scored &sc, int y) -> uint32_t {
         const uint32_t pa = (uint32_t)__builtin_amdgcn_readlane((int)sc.nd01, y >> 2);
@@ -230,6 +231,7 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
         sc.y1 = sc.y2 = -1;
         sc.nd1 = sc.nd2 = 0;
         sc.tie = false;
+        sc.tie_soft = false;
         if (K1 < 0) {
             sc.y1 = K1 & 255;
             sc.nd1 = nd_of(sc, sc.y1);
@@ -245,13 +247,38 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
                         n2 += (int)__popcll(__ballot(((uint32_t)(sc.ke[r] ^ K2) >> kWdDwShift) == 0u));
                     sc.tie = n2 > 1;   // a third eligible byte shares the second delta: the nonces decide
                 }
+                if (sc.tie) {
+                    // The steps behind a tie need only the NUMBER of random words it will draw (one per candidate, known, and
+                    // one per re-queued byte: a winner whose store value is non-zero, video.py:170-178).  If every byte that
+                    // can still win has a non-zero store value, or every one a zero, that number does not depend on the
+                    // nonces: the run goes on, and the tie is resolved by its own wave at commit time, at its own offset of
+                    // the random stream.  (On picture-like input 96 % of the steps tie: ending the run at each would
+                    // leave one step per round.)  Who can still win: the bytes sharing the smallest delta if there are two
+                    // of them, else -- the first winner being fixed -- those sharing the second.
+                    const bool first_fixed = (K1 >> kWdDwShift) != (K2 >> kWdDwShift);
+                    unsigned long long zero = 0, nonzero = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const bool member = ((uint32_t)(sc.ke[r] ^ K2) >> kWdDwShift) == 0u;   // (K2's delta is the deciding class either way)
+                        zero |= __ballot(member && nd[r] == 0u);
+                        nonzero |= __ballot(member && nd[r] != 0u);
+                    }
+                    if (!(zero && nonzero)) {
+                        sc.tie = false;
+                        sc.tie_soft = true;
+                        // what the step will re-queue, whoever wins (published instead of the provisional winners' values)
+                        if (!first_fixed) sc.nd1 = nonzero ? 1u : 0u;
+                        sc.nd2 = nonzero ? 1u : 0u;
+                    }
+                }
             }
         }
     };
     // the reference's (delta, nonce, offset) order with every candidate's nonce materialised; the
     // entry's first nonce is word q0 of the ring (video.py:290-301)
     auto resolve_tie = [&](Scored &sc, int q0) {
-        uint32_t key[4];
+        constexpr int kNone = 0x7fffffff;   // the keys below are < 2^28: signed minima order them
+        int key[4];
         int run = q0;
 #pragma unroll
         for (int q = 0; q < 4; q++) run += prefix_popc(sc.cand[q]);
@@ -260,28 +287,18 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
             const uint32_t nonce = mt_temper(ring_word(run)) >> 24;
             run += (int)((sc.cand[r] >> lane) & 1ull);
             const uint32_t k = ((uint32_t)((sc.ke[r] >> kWdDwShift) + 2048) << 16) | (nonce << 8) | (y0 + r);
-            key[r] = sc.ke[r] < 0 ? k : INF;
+            key[r] = sc.ke[r] < 0 ? (int)k : kNone;
         }
-        uint32_t ta0 = key[0] < key[1] ? key[0] : key[1], tb0 = key[0] < key[1] ? key[1] : key[0];
-        uint32_t ta1 = key[2] < key[3] ? key[2] : key[3], tb1 = key[2] < key[3] ? key[3] : key[2];
-        uint32_t t1 = ta0 < ta1 ? ta0 : ta1;
-        uint32_t thi = ta0 < ta1 ? ta1 : ta0, tmb = tb0 < tb1 ? tb0 : tb1;
-        uint32_t t2 = thi < tmb ? thi : tmb;
-        top2_step<0xB1>(t1, t2);
-        top2_step<0x4E>(t1, t2);
-        top2_step<0x141>(t1, t2);
-        top2_step<0x140>(t1, t2);
-        uint32_t T1 = INF, T2 = INF;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            uint32_t r1 = __builtin_amdgcn_readlane(t1, 16 * q), r2 = __builtin_amdgcn_readlane(t2, 16 * q);
-            uint32_t lo = T1 < r1 ? T1 : r1, hi = T1 < r1 ? r1 : T1;
-            uint32_t m2 = T2 < r2 ? T2 : r2;
-            T1 = lo;
-            T2 = hi < m2 ? hi : m2;
-        }
-        sc.y1 = T1 != INF ? (int)(T1 & 255) : -1;
-        sc.y2 = T2 != INF ? (int)(T2 & 255) : -1;
+        // the two smallest: in the lane, then two fused-DPP wave minima (the keys end in the offset: unique)
+        const int ta0 = key[0] < key[1] ? key[0] : key[1], tb0 = key[0] < key[1] ? key[1] : key[0];
+        const int ta1 = key[2] < key[3] ? key[2] : key[3], tb1 = key[2] < key[3] ? key[3] : key[2];
+        const int t1 = ta0 < ta1 ? ta0 : ta1;
+        const int thi = ta0 < ta1 ? ta1 : ta0, tmb = tb0 < tb1 ? tb0 : tb1;
+        const int t2 = thi < tmb ? thi : tmb;
+        const int T1 = wave_min_i32(t1);
+        const int T2 = wave_min_i32(t1 == T1 ? t2 : t1);
+        sc.y1 = T1 != kNone ? (T1 & 255) : -1;
+        sc.y2 = T2 != kNone ? (T2 & 255) : -1;
         sc.nd1 = sc.y1 >= 0 ? nd_of(sc, sc.y1) : 0u;
         sc.nd2 = sc.y2 >= 0 ? nd_of(sc, sc.y2) : 0u;
     };
@@ -404,6 +421,7 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
         sc.C = 0;
         sc.live = false;
         sc.tie = false;
+        sc.tie_soft = false;
         sc.y1 = sc.y2 = -1;
         sc.nd1 = sc.nd2 = 0;
         if (wave < B) {
@@ -465,6 +483,7 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
         }
 #endif
         if (wave < n_commit && sc.live) {
+            if (sc.tie_soft) resolve_tie(sc, q_mine);   // (its re-queue count was published: nothing to tell the others)
             if (wave == tie_at) {
                 resolve_tie(sc, q_mine);
                 if (lane == 0) {
