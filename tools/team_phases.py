@@ -9,11 +9,13 @@ import _iiv_native as native
 import palette
 import stream_batch
 
+KIND = sys.argv[1] if len(sys.argv) > 1 else "iid"     # iid | img
 for mode in (native.DHGR, native.HGR):
     _, dm = native.cie2000_matrix(palette.NTSCPalette.rgb_array())
     table = native.build_table(mode, dm, True)
     store = native.build_store_table(mode, dm)
-    fm, fa = stream_batch.synth_frames_torch(1, 40, mode == native.DHGR, seed=99)
+    fm, fa = (stream_batch.synth_frames_img(1, 40, mode == native.DHGR, seed=99) if KIND == "img" else
+              stream_batch.synth_frames_torch(1, 40, mode == native.DHGR, seed=99))
     b = stream_batch.StreamBatch(mode, table, store, 1, seeds=[(1, 1)], dm=dm)
     b.enc.set_greedy_kernel("team")
     b.encode_frames(fm, fa, 40)
