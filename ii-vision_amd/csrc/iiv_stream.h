@@ -285,7 +285,7 @@ int launch_greedy_team(int mode, const GreedyArgs &a, hipStream_t st);   // iiv_
 
 // ---- the prologue (iiv_prologue.hip) and the workgroup greedy kernel (iiv_workgroup.hip)
 constexpr int kSelNeedMax = 2048;  // the prologue's prefix selection is used when 3 * opcode budget <= this
-constexpr int kBucketMax = 96;     // counting-sort buckets larger than this fall back to the bitonic sort
+constexpr int kBucketMax = 384;    // counting-sort buckets larger than this fall back to the bitonic sort
 struct PrologueArgs {
     StreamState *states;
     const uint8_t *frames_main, *frames_aux;

@@ -7,8 +7,9 @@ _, dm = native.cie2000_matrix(palette.NTSCPalette.rgb_array())
 mode = native.DHGR
 table = native.build_table(mode, dm, True); store = native.build_store_table(mode, dm)
 S = 8
-for coh in (False, True):
-    fm, fa = stream_batch.synth_frames_torch(S, 60, True, seed=5, coherent=coh)
+for coh in (False, True, "img"):
+    fm, fa = (stream_batch.synth_frames_img(S, 60, True, seed=5) if coh == "img" else
+              stream_batch.synth_frames_torch(S, 60, True, seed=5, coherent=coh))
     b = stream_batch.StreamBatch(mode, table, store, S, seeds=[(i+1,i+1) for i in range(S)], dm=dm)
     b.encode_frames(fm, fa, 60); b.enc.check()
     for i in (0, 3):
@@ -18,7 +19,9 @@ for coh in (False, True):
         bins = np.bincount(nz >> sh, minlength=1024)
         srt = np.sort(nz)[::-1]
         thr = srt[876] if len(srt) > 876 else 0
-        print("coh" if coh else "iid", "stream", i, "n", len(nz), "max", mx, "mean %.0f" % nz.mean(), "p50", int(np.median(nz)),
+        top = np.sort(bins)[::-1][:6]
+        print("   largest buckets:", top.tolist(), " entries in buckets > 96:", int(bins[bins > 96].sum()))
+        print("img" if coh == "img" else "coh" if coh else "iid", "stream", i, "n", len(nz), "max", mx, "mean %.0f" % nz.mean(), "p50", int(np.median(nz)),
               "p88", int(np.percentile(nz, 88)), "sh", sh, "max bucket", bins.max(), "bucket at thr", bins[thr >> sh],
               "nonempty", (bins > 0).sum())
     b.close()

@@ -6,10 +6,12 @@ sys.path.insert(0, os.path.join(os.getcwd(), 'ii-vision_amd', 'transcoder'))
 import numpy as np, torch
 import _iiv_native as native, stream_batch, palette
 _, dm = native.cie2000_matrix(palette.NTSCPalette.rgb_array())
-mode = native.HGR if len(sys.argv) > 1 and sys.argv[1] == "HGR" else native.DHGR
+mode = native.HGR if "HGR" in sys.argv[1:] else native.DHGR
+IMG = "img" in sys.argv[1:]      # picture-like input (S-img) instead of S-iid
 table = native.build_table(mode, dm, True); store = native.build_store_table(mode, dm)
 for S in (1, 512, 4096):
-    fm, fa = stream_batch.synth_frames_torch(S, 4, mode == native.DHGR, seed=5)
+    fm, fa = (stream_batch.synth_frames_img(S, 4, mode == native.DHGR, seed=5) if IMG else
+              stream_batch.synth_frames_torch(S, 4, mode == native.DHGR, seed=5))
     b = stream_batch.StreamBatch(mode, table, store, S, seeds=[(i+1,i+1) for i in range(S)], dm=dm)
     b.encode_frames(fm, fa, 3)
     ops, segs = b.encode_frames(fm, fa, 1)
