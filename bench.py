@@ -101,6 +101,9 @@ def parse_args(argv=None):
     ap.add_argument("--joint", action="store_true",
                     help="SURVEY 8(f4): choose every step's content byte jointly with its extra offsets "
                          "(IIV_CONTENT_JOINT; NOT the reference's output -- not the BASELINE workload)")
+    ap.add_argument("--fourth", action="store_true",
+                    help="SURVEY 8(f4): up to three extra offsets per opcode instead of two and a copy of the first "
+                         "(IIV_OPT_FOURTH_OFFSET; NOT the reference's output -- not the BASELINE workload)")
     ap.add_argument("--greedy", choices=["auto", "wave", "workgroup", "shared", "plain"], default="auto",
                     help="greedy kernel shape: one wave per stream, one 256-thread workgroup per stream, or auto")
     ap.add_argument("--full-sort", action="store_true", help="disable the prologue's prefix sort")
@@ -162,7 +165,7 @@ class GpuBackend:
 
     def make_batch(self, S, seeds):
         a = self.args
-        b = self.sb.StreamBatch(self.mode, self.table, self.store, S, seeds=seeds, dm=self.dm, joint_content=a.joint)
+        b = self.sb.StreamBatch(self.mode, self.table, self.store, S, seeds=seeds, dm=self.dm, joint_content=a.joint, fourth_offset=a.fourth)
         b.enc.set_diff_weights_mode("table" if a.dw_table else a.dw)
         b.enc.set_greedy_kernel({"auto": None, "wave": True, "workgroup": False}.get(a.greedy, a.greedy))
         if a.full_sort:
@@ -269,7 +272,8 @@ def main(argv=None, backend_cls=GpuBackend):
                             args.mode, "//gs RGB (IIGS)" if args.palette == "IIGS" else "NTSC", 560 if dhgr else 280,
                             "img" if args.img else ("static (2 %% redrawn per frame, x%d)" % args.repeat) if args.static else "coh" if args.coherent else "iid",
                             args.steps * F, S, ", bank flip per 2 KiB" if dhgr else "",
-                            "; JOINT content choice (f4, not the reference's output)" if args.joint else ""),
+                            "; JOINT content choice (f4, not the reference's output)" if args.joint else
+                            "; FOURTH offset per opcode (f4, not the reference's output)" if args.fourth else ""),
             "palette": args.palette,
             "streams_per_gpu": S,
             "frames_per_step": F,
@@ -304,7 +308,7 @@ def main(argv=None, backend_cls=GpuBackend):
                                                 "per GPU only with many independent clips (see value / vs_reference_python)")
         if n_gpus == 1 and not args.no_extras and be.is_gpu:
             out["dropin"] = _dropin_video(args)
-            if dhgr and not args.joint:   # SURVEY 8(d) M1 "plus HGR frames/s": a short HGR leg with its own tables and clips
+            if dhgr and not args.joint and not args.fourth:   # SURVEY 8(d) M1 "plus HGR frames/s": a short HGR leg with its own tables and clips
                 out["hgr"] = _hgr_leg(be, args, local_rank, world)
 
         print(json.dumps(out))
@@ -545,7 +549,7 @@ def _single_stream(be, args):
     """One clip alone (a video is a sequential chain: latency-bound)."""
     import torch
     fm, fa = be.sb.synth_frames_torch(1, 60, be.dhgr, seed=99, coherent=args.coherent)
-    b = be.sb.StreamBatch(be.mode, be.table, be.store, 1, seeds=[(1, 1)], dm=be.dm, joint_content=args.joint)
+    b = be.sb.StreamBatch(be.mode, be.table, be.store, 1, seeds=[(1, 1)], dm=be.dm, joint_content=args.joint, fourth_offset=args.fourth)
     b.enc.set_greedy_kernel({"auto": None, "wave": True, "workgroup": False}.get(args.greedy, args.greedy))
     b.encode_frames(fm, fa, 10)
     torch.cuda.synchronize()
@@ -559,7 +563,7 @@ def _single_stream(be, args):
     # opcodes), which used to end the eight-wave kernel's run of concurrent steps at each of them
     try:
         fm, fa = be.sb.synth_frames_img(1, 60, be.dhgr, seed=99)
-        b = be.sb.StreamBatch(be.mode, be.table, be.store, 1, seeds=[(1, 1)], dm=be.dm, joint_content=args.joint)
+        b = be.sb.StreamBatch(be.mode, be.table, be.store, 1, seeds=[(1, 1)], dm=be.dm, joint_content=args.joint, fourth_offset=args.fourth)
         b.enc.set_greedy_kernel({"auto": None, "wave": True, "workgroup": False}.get(args.greedy, args.greedy))
         b.encode_frames(fm, fa, 10)
         torch.cuda.synchronize()
@@ -672,6 +676,7 @@ def _cpu_baseline(be, seed, args, ops_check):
     tab = O.build_table(be.mode, dm, symmetric=True)   # untimed, like the GPU's table build
     v = O.Video(be.mode, tab, seed_py=seed[0], seed_np=seed[1])
     v.set_joint(args.joint)
+    v.set_fourth_offset(args.fourth)
     segs = stream_batch.MovieClock(be.dhgr).segments(n)
     t0 = time.perf_counter()
     got = []
@@ -716,6 +721,7 @@ def _cpu_baseline_all_cores(be, seeds, args):
     vids = [O.Video(be.mode, tab, seed_py=seeds[i][0], seed_np=seeds[i][1]) for i in range(threads)]
     for v in vids:
         v.set_joint(args.joint)
+        v.set_fourth_offset(args.fourth)
 
     def work(i):
         v = vids[i]

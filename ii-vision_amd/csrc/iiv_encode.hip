@@ -58,6 +58,7 @@ struct Encoder {
     int partial_sort;       // allow the prologue's prefix sort when the budget is known
     int greedy_lds_pad;     // IIV_OPT_GREEDY_LDS_PAD
     int content_choice;     // IIV_OPT_CONTENT_CHOICE
+    int fourth_offset;      // IIV_OPT_FOURTH_OFFSET
     StreamState *d_states;
     StreamState *d_snapshot;  // iiv_encoder_snapshot copy (lazily allocated)
     // generator bookkeeping: one entry while every stream has run the same schedule, else one per stream
@@ -203,6 +204,7 @@ int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, c
     e->partial_sort = 1;
     e->greedy_lds_pad = 0;
     e->content_choice = IIV_CONTENT_TARGET;
+    e->fourth_offset = 0;
     e->gens.assign(1, GenState{0, 0, 0});
     e->h_segs[0] = e->h_segs[1] = nullptr;
     e->seg_ev[0] = e->seg_ev[1] = nullptr;
@@ -327,6 +329,8 @@ int encoder_set_option(Encoder *e, int option, int value)
         if (value == IIV_CONTENT_JOINT && !e->d_left)
             return set_error(IIV_ERR_INVALID, "the joint content choice reads the split store table, which is built "
                                                "from dm (none was given at creation)");
+        if (value == IIV_CONTENT_JOINT && e->fourth_offset)
+            return set_error(IIV_ERR_INVALID, "the joint content choice and the fourth offset are not implemented together");
         if (value == IIV_CONTENT_JOINT && !e->d_left_t) {
             IIV_HIP(hipMalloc(&e->d_left_t, split_entries(e->mode, 0) * 4));
             IIV_HIP(hipMalloc(&e->d_right_t, split_entries(e->mode, 1) * 4));
@@ -335,6 +339,16 @@ int encoder_set_option(Encoder *e, int option, int value)
             IIV_HIP(hipDeviceSynchronize());
         }
         e->content_choice = value;
+        return IIV_OK;
+    }
+    if (option == IIV_OPT_FOURTH_OFFSET) {
+        if (value != 0 && value != 1) return set_error(IIV_ERR_INVALID, "bad value");
+        if (value && !e->d_left)
+            return set_error(IIV_ERR_INVALID, "the fourth offset runs in the one-wave kernel, which reads the split store table "
+                                               "built from dm (none was given at creation)");
+        if (value && e->content_choice == IIV_CONTENT_JOINT)
+            return set_error(IIV_ERR_INVALID, "the joint content choice and the fourth offset are not implemented together");
+        e->fourth_offset = value;
         return IIV_OK;
     }
     return set_error(IIV_ERR_INVALID, "unknown option %d", option);
@@ -605,7 +619,9 @@ static int plan_stream(Encoder *e, int stream, const iiv_segment *segs, int n_se
                     }
                     budget += segs[k].n_ops;
                 }
-                if (closed && 3 * budget <= kSelNeedMax) need = (int)(3 * budget);
+                // (a step consumes at most one primary and two -- with the fourth offset three -- secondaries resolved to zero)
+                const long per_op = e->fourth_offset ? 4 : 3;
+                if (closed && per_op * budget <= kSelNeedMax) need = (int)(per_op * budget);
             }
         }
         gs = GenState{1, g.is_aux, g.frame};
@@ -680,10 +696,11 @@ static int launch_round(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux,
     // the 4-wave workgroup with its two barriers per opcode (tools/single_stream_probe.py); the
     // workgroup kernel remains for encoders created without dm, and as a second implementation
     // (the joint content choice, not a reference behaviour, exists in the workgroup kernel only)
-    const bool use_wave = e->d_left && e->greedy_mode != IIV_GREEDY_WORKGROUP && e->content_choice == IIV_CONTENT_TARGET;
+    // (f4's fourth offset: in the plain one-wave kernel only, whatever the kernel option says)
+    const bool use_wave = e->fourth_offset || (e->d_left && e->greedy_mode != IIV_GREEDY_WORKGROUP && e->content_choice == IIV_CONTENT_TARGET);
     // few streams: a team of eight waves per stream scores the next entries of the list
     // concurrently (iiv_team.hip); from ~900 streams on, one wave per stream fills the GPU
-    const bool use_team = use_wave && (e->greedy_mode == IIV_GREEDY_TEAM ||
+    const bool use_team = use_wave && !e->fourth_offset && (e->greedy_mode == IIV_GREEDY_TEAM ||
                                        (e->greedy_mode == IIV_GREEDY_AUTO && e->n_streams <= kTeamMaxStreams));
     if (use_wave) {
         GreedyArgs a{e->d_states, d_main, d_aux, n_frames, e->n_streams, d_round, seg_stride, e->d_left, e->d_right, e->nt, d_ops,
@@ -693,7 +710,7 @@ static int launch_round(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux,
                      // table loads: +5.5 % at 14336 clips) once there is a full workgroup of sixteen streams for every CU
                      e->greedy_mode == IIV_GREEDY_WAVE_SHARED ||
                          (e->mode == kHGR && e->greedy_mode != IIV_GREEDY_WAVE_PLAIN && e->n_streams >= kSharedHgrMinStreams),
-                     d_queue};
+                     d_queue, e->fourth_offset != 0};
         int rc = use_team ? launch_greedy_team(e->mode, a, st) : launch_greedy_wave(e->mode, a, st);
         if (rc) return rc;
     } else {

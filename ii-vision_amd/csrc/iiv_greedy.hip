@@ -82,7 +82,11 @@ __device__ static inline WaveLds *own_wave_lds()
     return &w;
 }
 
-template <int MODE, int W>
+// FOUR (f4, IIV_OPT_FOURTH_OFFSET; NOT the reference's behaviour): up to three extra offsets per opcode instead of two
+// and a copy of the first -- the reference's exit test `len(offsets) == 3` (video.py:180-181) read as the 4 that
+// video.py:146 announces; defined by oracle/iiv_oracle.c: orc_video_set_fourth_offset, pinned against the reference
+// run with that literal changed (tests/golden/g8_fourth_offset.npz).  W == 1 only.
+template <int MODE, int W, bool FOUR = false>
 __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W + 3) / 4 : (2 * W + 3) / 4 + (W % 4 ? 1 : 0)) void greedy_wave_kernel(StreamState *__restrict__ states,
                                                                    const uint8_t *__restrict__ frames_main,
                                                                    const uint8_t *__restrict__ frames_aux, int n_frames,
@@ -321,17 +325,17 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
     int n_ties = 0, n_tie_members = 0, n_ties_small = 0;
 #endif
     bool prev_tie = false;        // the previous step's two winners shared their delta: expect the same of this one
-    uint32_t pkey_v = 0;          // lanes 1, 2: the keys pushed by the latest step (track only)
-    int push_f1 = 0, push_f2 = 0, push_base = 0;
-    auto apply = [&](auto track, int p, int x, uint32_t c, int y1, uint32_t nd1, int y2, uint32_t nd2, int C) {
-        const uint32_t v1 = y1 >= 0 ? nd1 : 0u, v2 = y2 >= 0 ? nd2 : 0u;
-        const int y1e = y1 >= 0 ? y1 : x, y2e = y2 >= 0 ? y2 : x;   // video.py:185-186
-        const int f1 = v1 ? 1 : 0, f2 = v2 ? 1 : 0;
-        if (n_pushed + f1 + f2 > kPushedCap) {
+    uint32_t pkey_v = 0;          // lanes 1, 2 (FOUR: and 3): the keys pushed by the latest step (track only)
+    int push_f1 = 0, push_f2 = 0, push_f3 = 0, push_base = 0;
+    auto apply = [&](auto track, int p, int x, uint32_t c, int y1, uint32_t nd1, int y2, uint32_t nd2, int y3, uint32_t nd3, int C) {
+        const uint32_t v1 = y1 >= 0 ? nd1 : 0u, v2 = y2 >= 0 ? nd2 : 0u, v3 = (FOUR && y3 >= 0) ? nd3 : 0u;
+        const int y1e = y1 >= 0 ? y1 : x, y2e = y2 >= 0 ? y2 : x, y3e = (FOUR && y3 >= 0) ? y3 : x;   // video.py:185-186
+        const int f1 = v1 ? 1 : 0, f2 = v2 ? 1 : 0, f3 = v3 ? 1 : 0;
+        if (n_pushed + f1 + f2 + f3 > kPushedCap) {
             err = kErrPushedOverflow;
             return;
         }
-        if (mt_idx + C + 2 >= 256) twist_now();
+        if (mt_idx + C + (FOUR ? 3 : 2) >= 256) twist_now();
         // lanes 0..2 = (x, 0), (y1e, v1), (y2e, v2): three scalars written into lanes of one register each
         // (a `lane == k ? a : b` chain compiles to selects on loop-invariant lane masks, which the
         // allocator then spills and reloads on every step)
@@ -341,9 +345,13 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
             "v_writelane_b32 %2, %7, 2"
             : "+v"(off_v), "+v"(val_v), "+v"(k_v)
             : "s"(IIV_SGPR(y1e)), "s"(IIV_SGPR(y2e)), "s"(IIV_SGPR(v1)), "s"(IIV_SGPR(v2)), "s"(IIV_SGPR(f1)));
+        if (FOUR)   // lane 3 = (y3e, v3), its re-queued entry behind those of lanes 1 and 2
+            asm("v_writelane_b32 %0, %3, 3\n\tv_writelane_b32 %1, %4, 3\n\tv_writelane_b32 %2, %5, 3"
+                : "+v"(off_v), "+v"(val_v), "+v"(k_v)
+                : "s"(IIV_SGPR(y3e)), "s"(IIV_SGPR(v3)), "s"(IIV_SGPR(f1 + f2)));
         int ln = lane;
         asm volatile("" : "+v"(ln));   // (keeps `lane < 3` from becoming one more hoisted, spilled mask)
-        if (ln < 3) {
+        if (ln < (FOUR ? 4 : 3)) {
             const int off = (int)off_v;
             const uint32_t val = val_v;
             // (buffer stores into this stream's state: field offsets in scalar registers instead of
@@ -360,21 +368,21 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
                 __builtin_amdgcn_raw_buffer_store_b32(pkey, rsrc_s, (n_pushed + k) * 4, (int)offsetof(StreamState, pushed), 0);
                 if (decltype(track)::value) pkey_v = pkey;
             }
-            atomicOr(&pdone[p * 8 + (x >> 5)], 1u << (x & 31));   // (from all three lanes: idempotent)
+            atomicOr(&pdone[p * 8 + (x >> 5)], 1u << (x & 31));   // (from all three / four lanes: idempotent)
         }
         // the opcode (page + 32, content, x, y1, y2, x) goes into lane (done - ob_base) of a
         // register pair; 64 of them leave in two coalesced stores
         const uint32_t w0 = (uint32_t)(p + 32) | (c << 8) | ((uint32_t)x << 16) | ((uint32_t)y1e << 24);
-        const uint32_t w1 = (uint32_t)y2e | ((uint32_t)x << 8);
+        const uint32_t w1 = (uint32_t)y2e | ((uint32_t)(FOUR ? y3e : x) << 8);
         const int ob_lane = IIV_SGPR(done - ob_base);
         // (gfx9 VOP3 reads one SGPR only; v_writelane may take its lane select from m0 besides)
         asm("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
             : "+v"(ob0), "+v"(ob1)
             : "s"(IIV_SGPR(w0)), "s"(ob_lane), "s"(IIV_SGPR(w1)));
-        if (decltype(track)::value) push_f1 = f1, push_f2 = f2, push_base = n_pushed;
-        mt_idx += C + f1 + f2;
-        draws += (uint32_t)(C + f1 + f2);
-        n_pushed += f1 + f2;
+        if (decltype(track)::value) push_f1 = f1, push_f2 = f2, push_f3 = f3, push_base = n_pushed;
+        mt_idx += C + f1 + f2 + f3;
+        draws += (uint32_t)(C + f1 + f2 + f3);
+        n_pushed += f1 + f2 + f3;
         done++;
         if (done - ob_base == 64) flush_ops();
         if (mt_idx >= 624) {
@@ -426,6 +434,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
         const int a1 = ke[2] < ke[3] ? ke[2] : ke[3], b1 = ke[2] < ke[3] ? ke[3] : ke[2];
         const int k1 = a0 < a1 ? a0 : a1, hi01 = a0 < a1 ? a1 : a0, mb = b0 < b1 ? b0 : b1;
         const int k2 = hi01 < mb ? hi01 : mb;
+        const int k3 = hi01 < mb ? mb : hi01;   // (FOUR: the lane's third smallest)
         // store values of byte pairs, for the scalar read-out of the winners' values
         const uint32_t nd01 = nd[0] | (nd[1] << 16), nd23 = nd[2] | (nd[3] << 16);
         auto nd_of = [&](int y) -> uint32_t {   // (scalar from here on: two readlanes, no branch)
@@ -436,25 +445,39 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
         // The exact path below is complete by itself (it orders every eligible byte by (delta, nonce, offset)); the fast
         // path in front of it only pays where ties are rare.  On picture-like input they are the rule (96 % of the
         // steps), so a step that follows a tie goes straight to the exact path.
-        int y1 = -1, y2 = -1;
-        uint32_t nd1 = 0, nd2 = 0;
+        int y1 = -1, y2 = -1, y3 = -1;
+        uint32_t nd1 = 0, nd2 = 0, nd3 = 0;
         bool tie = prev_tie;
         const int K1 = tie ? 0 : wave_min_i32(k1);
+        // does another eligible byte share the delta of the last winner K?  (then the nonces decide)
+        auto shared_delta = [&](int K) -> bool {
+            int n2 = 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                n2 += (int)__popcll(__ballot(((uint32_t)(ke[r] ^ K) >> kWdDwShift) == 0u));
+            return n2 > 1;
+        };
         if (K1 < 0) {
             y1 = K1 & 255;
             nd1 = nd_of(y1);
-            const int K2 = wave_min_i32(k1 == K1 ? k2 : k1);
+            // (the lane that held a winner moves its next key up)
+            const bool hit1 = k1 == K1;
+            const int c1 = hit1 ? k2 : k1;
+            const int K2 = wave_min_i32(c1);
             if (K2 < 0) {
                 y2 = K2 & 255;
                 nd2 = nd_of(y2);
                 tie = (K1 >> kWdDwShift) == (K2 >> kWdDwShift);
-                if (!tie) {
-                    // does a third eligible byte share the second delta?  (then the nonces decide)
-                    int n2 = 0;
-#pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        n2 += (int)__popcll(__ballot(((uint32_t)(ke[r] ^ K2) >> kWdDwShift) == 0u));
-                    tie = n2 > 1;
+                if constexpr (!FOUR) {
+                    if (!tie) tie = shared_delta(K2);
+                } else if (!tie) {
+                    const int n1 = hit1 ? k3 : k2;          // the key behind c1 in its lane
+                    const int K3 = wave_min_i32(c1 == K2 ? n1 : c1);
+                    if (K3 < 0) {
+                        y3 = K3 & 255;
+                        nd3 = nd_of(y3);
+                        tie = (K2 >> kWdDwShift) == (K3 >> kWdDwShift) || shared_delta(K3);
+                    }
                 }
             }
         }
@@ -496,14 +519,23 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
             const int thi = ta0 < ta1 ? ta1 : ta0, tmb = tb0 < tb1 ? tb0 : tb1;
             const int t2 = thi < tmb ? thi : tmb;
             const int T1 = wave_min_i32(t1);
-            const int T2 = wave_min_i32(t1 == T1 ? t2 : t1);
+            const bool thit1 = t1 == T1;
+            const int tc1 = thit1 ? t2 : t1;
+            const int T2 = wave_min_i32(tc1);
             y1 = T1 != kNone ? (T1 & 255) : -1;
             y2 = T2 != kNone ? (T2 & 255) : -1;
             nd1 = y1 >= 0 ? nd_of(y1) : 0u;
             nd2 = y2 >= 0 ? nd_of(y2) : 0u;
             prev_tie = T2 != kNone && (T1 >> 16) == (T2 >> 16);   // (a prediction only: either path is exact)
+            if constexpr (FOUR) {
+                const int t3 = thi < tmb ? tmb : thi;
+                const int T3 = wave_min_i32(tc1 == T2 ? (thit1 ? t3 : t2) : tc1);
+                y3 = T3 != kNone ? (T3 & 255) : -1;
+                nd3 = y3 >= 0 ? nd_of(y3) : 0u;
+                prev_tie = prev_tie || (T3 != kNone && (T2 >> 16) == (T3 >> 16));
+            }
         }
-        apply(track, p, x, c, y1, nd1, y2, nd2, C);
+        apply(track, p, x, c, y1, nd1, y2, nd2, y3, nd3, C);
         return true;
     };
 
@@ -705,7 +737,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
             Loaded L;
             gather8(w, c, L);
             twist_now();
-            push_f1 = push_f2 = 0;
+            push_f1 = push_f2 = push_f3 = 0;
             (void)step(std::true_type{}, e, L);
             // the sub-bag's new minimum, then what this step pushed
             uint32_t mk = rk[0], mi = ridx[0];
@@ -720,6 +752,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
             writelane(ci, ni, wl);
             if (push_f1) cache_merge((uint32_t)__builtin_amdgcn_readlane((int)pkey_v, 1), (uint32_t)push_base);
             if (push_f2) cache_merge((uint32_t)__builtin_amdgcn_readlane((int)pkey_v, 2), (uint32_t)(push_base + push_f1));
+            if (FOUR && push_f3) cache_merge((uint32_t)__builtin_amdgcn_readlane((int)pkey_v, 3), (uint32_t)(push_base + push_f1 + push_f2));
         }
     }
 
@@ -808,9 +841,15 @@ template <int MODE> static int launch_shared(const GreedyArgs &a, hipStream_t st
 int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st)
 {
     // (the shared form needs every stream of the round on one bank -- always so in HGR -- and the host's stream counter)
-    const bool shared = a.shared && a.uniform_bank >= 0 && a.queue && a.lds_pad == 0;
+    const bool shared = a.shared && a.uniform_bank >= 0 && a.queue && a.lds_pad == 0 && !a.fourth;
     int rc = IIV_OK;
-    if (shared)
+    if (a.fourth && mode == kDHGR)   // (f4: a real fourth offset per opcode -- the plain one-wave form only)
+        hipLaunchKernelGGL((greedy_wave_kernel<kDHGR, 1, true>), dim3(a.n_streams), dim3(64), (size_t)a.lds_pad, st, a.states, a.frames_main,
+                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, (int *)nullptr);
+    else if (a.fourth)
+        hipLaunchKernelGGL((greedy_wave_kernel<kHGR, 1, true>), dim3(a.n_streams), dim3(64), (size_t)a.lds_pad, st, a.states, a.frames_main,
+                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, (int *)nullptr);
+    else if (shared)
         rc = mode == kDHGR ? launch_shared<kDHGR>(a, st) : launch_shared<kHGR>(a, st);
     else if (mode == kDHGR)
         hipLaunchKernelGGL((greedy_wave_kernel<kDHGR, 1>), dim3(a.n_streams), dim3(64), (size_t)a.lds_pad, st, a.states, a.frames_main,

@@ -8,7 +8,7 @@
 
 namespace iiv {
 
-constexpr int kPushedCap = 16384;  // >= 2 pushes x 7680 non-hole bytes
+constexpr int kPushedCap = 24576;  // >= 3 pushes (two, or three with the fourth-offset option) x 7680 non-hole bytes
 
 // ---- wd[]: one word per byte of the live generator's bank, written once by the prologue
 // and immutable while the generator lives:
@@ -277,6 +277,7 @@ struct GreedyArgs {
     int uniform_bank;        // 0 / 1: every stream that emits opcodes in this round works on this bank; -1: they differ
     bool shared;             // IIV_GREEDY_WAVE_SHARED: the LDS-shared form wherever it applies (DHGR, one bank per round)
     int *queue;              // device: this launch's stream counter, zero (the LDS-shared form's persistent workgroups)
+    bool fourth;             // IIV_OPT_FOURTH_OFFSET: up to three extra offsets per opcode (the plain one-wave kernel only)
 };
 
 int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st);   // iiv_greedy.hip
@@ -284,7 +285,7 @@ int launch_greedy_team(int mode, const GreedyArgs &a, hipStream_t st);   // iiv_
 
 
 // ---- the prologue (iiv_prologue.hip) and the workgroup greedy kernel (iiv_workgroup.hip)
-constexpr int kSelNeedMax = 2048;  // the prologue's prefix selection is used when 3 * opcode budget <= this
+constexpr int kSelNeedMax = 2048;  // the prologue's prefix selection is used when 3 (fourth offset: 4) * opcode budget <= this
 constexpr int kBucketMax = 384;    // counting-sort buckets larger than this fall back to the bitonic sort
 struct PrologueArgs {
     StreamState *states;

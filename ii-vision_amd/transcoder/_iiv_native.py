@@ -27,6 +27,7 @@ GREEDY_WAVE_SHARED, GREEDY_WAVE_PLAIN = 4, 5
 OPT_PREFIX_SORT = 3
 OPT_GREEDY_LDS_PAD = 5
 OPT_CONTENT_CHOICE, CONTENT_TARGET, CONTENT_JOINT = 6, 0, 1
+OPT_FOURTH_OFFSET = 7
 
 # every symbol include/iivision.h declares
 SYMBOLS = [
@@ -382,6 +383,12 @@ class Encoder:
         chosen jointly with its extra offsets (include/iivision.h: IIV_CONTENT_JOINT) -- the
         reference README's "global optimization" idea, NOT the reference's output."""
         check(lib().iiv_encoder_set_option(self._h, OPT_CONTENT_CHOICE, CONTENT_JOINT if joint else CONTENT_TARGET))
+
+    def set_fourth_offset(self, enable):
+        """f4: up to three extra offsets per opcode instead of two and a copy of the first (the reference's exit test
+        `len(offsets) == 3`, video.py:180-181, read as 4; include/iivision.h IIV_OPT_FOURTH_OFFSET).  NOT the
+        reference's opcode stream."""
+        check(lib().iiv_encoder_set_option(self._h, OPT_FOURTH_OFFSET, 1 if enable else 0))
 
     def set_diff_weights_mode(self, mode):
         """True / "recurrence" (default with dm): the edit-distance recurrence in the kernel;

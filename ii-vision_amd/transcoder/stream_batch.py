@@ -193,15 +193,18 @@ def synth_frames_img(n_streams, n_frames, dhgr, seed, device="cuda"):
 class StreamBatch:
     """S independent video.Video encoders advanced in lock step on one GPU."""
 
-    def __init__(self, mode, table, store_table, n_streams, seeds=None, dm=None, joint_content=False, **clock_kw):
+    def __init__(self, mode, table, store_table, n_streams, seeds=None, dm=None, joint_content=False, fourth_offset=False, **clock_kw):
         """joint_content=True: the content byte of every step is chosen jointly with its extra
         offsets (reference README.md:212-215, include/iivision.h IIV_CONTENT_JOINT) -- better
-        pictures per opcode, NOT the reference's opcode stream."""
+        pictures per opcode, NOT the reference's opcode stream.  fourth_offset=True: every opcode stores at
+        up to four distinct offsets instead of three and a repeat (IIV_OPT_FOURTH_OFFSET) -- likewise."""
         self.mode = mode
         self.n_streams = int(n_streams)
         self.enc = native.Encoder(mode, table, store_table, self.n_streams, dm=dm)
         if joint_content:
             self.enc.set_content_choice(True)
+        if fourth_offset:
+            self.enc.set_fourth_offset(True)
         self.clock = MovieClock(mode == native.DHGR, **clock_kw)
         if seeds is not None:
             self.seed(seeds)

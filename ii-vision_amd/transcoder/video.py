@@ -76,12 +76,16 @@ class Video:
             ticks_per_second: float,
             mode: VideoMode = VideoMode.HGR,
             palette: Palette = Palette.NTSC,
-            joint_content: bool = False
+            joint_content: bool = False,
+            fourth_offset: bool = False
     ):
         """joint_content (not in the reference's signature, default off): choose every opcode's
         content byte jointly with its extra offsets -- the "global optimization" of the reference's
         README.md:212-215 (include/iivision.h: IIV_CONTENT_JOINT).  Less error per opcode, NOT the
-        reference's opcode stream."""
+        reference's opcode stream.
+        fourth_offset (likewise not in the reference's signature, default off): up to three extra offsets per
+        opcode -- the "3 more offsets" of video.py:146 -- instead of the reference's two and a copy of the first
+        (video.py:180-186; IIV_OPT_FOURTH_OFFSET).  NOT the reference's opcode stream."""
         self.mode = mode  # type: VideoMode
         self.frame_grabber = frame_grabber
         self.ticks_per_second = float(ticks_per_second)  # type: float
@@ -118,6 +122,8 @@ class Video:
         self._enc = native.Encoder(self._mode_id, tables.table, tables.store, n_streams=1, dm=tables.dm)
         if joint_content:
             self._enc.set_content_choice(True)
+        if fourth_offset:
+            self._enc.set_fourth_offset(True)
         self._live = None  # the generator whose state the device currently holds
         self._vs = native.VideoState()   # one staging buffer for every state round trip
         self._vb = native.VideoBrief()

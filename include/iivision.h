@@ -218,6 +218,19 @@ void iiv_encoder_destroy(iiv_encoder *enc);
                                   *   removes less by that accounting; measured on the screen itself a single step may, a
                                   *   frame of them does not (tests/test_gpu_joint.py).  128 / 256 times the lookups of a reference step; runs in the
                                   *   workgroup greedy kernel whatever IIV_OPT_GREEDY_KERNEL says. */
+#define IIV_OPT_FOURTH_OFFSET 7  /* 0 (default, the reference) / 1: a real fourth offset per opcode.  NOT reference behaviour.
+                                  * The player stores every opcode's content byte at FOUR offsets, and video.py:146 says
+                                  * "Need to find 3 more offsets to fill this opcode", but the loop's exit test
+                                  * `if len(offsets) == 3: break` (video.py:180-181) counts the primary: it stops after two
+                                  * more, and :184-186 fill the fourth slot with a copy of the first.  With 1 the test reads
+                                  * 4: up to three extra offsets, each handled as the reference handles its two (candidate
+                                  * order (delta, nonce, offset), one nonce per candidate, priority 0 skipped, re-queued with a
+                                  * nonce when the store leaves an error) -- a quarter of the stream's stores is no longer
+                                  * spent on a byte that was just written.  Defined by oracle/iiv_oracle.c
+                                  * (orc_video_set_fourth_offset), which is pinned against the reference run with that one
+                                  * literal changed (tests/golden/g8_fourth_offset.npz).  Runs in the one-wave greedy kernel
+                                  * whatever IIV_OPT_GREEDY_KERNEL says (needs dm at creation); not together with
+                                  * IIV_CONTENT_JOINT. */
 int iiv_encoder_set_option(iiv_encoder *enc, int option, int value);
 
 /* state items, per stream */

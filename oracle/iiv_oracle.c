@@ -698,6 +698,7 @@ struct orc_video {
     orc_mt rng_py, rng_np;
     uint64_t draws_py, draws_np;
     int joint;               /* f4: joint choice of the content byte (not the reference's behaviour) */
+    int fourth;              /* f4: a real fourth offset per opcode (video.py:181 with 4 for 3; not the reference's behaviour) */
     /* generator */
     int gen_active, gen_started, gen_is_aux, gen_exhausted, gen_form;
     uint8_t tgt[2][8192];
@@ -723,7 +724,7 @@ orc_video *orc_video_create(int mode, const uint16_t *table)
     v->heap_cap = 8192 * 3 + 16;
     v->heap = (hent *)malloc(sizeof(hent) * (size_t)v->heap_cap);
     v->sorted = (uint64_t *)malloc(sizeof(uint64_t) * 8192);
-    v->pushed_cap = 8192 * 2 + 16;
+    v->pushed_cap = 8192 * 3 + 16;
     v->pushed = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)v->pushed_cap);
     return v;
 }
@@ -739,6 +740,15 @@ void orc_video_destroy(orc_video *v)
 }
 
 void orc_video_set_joint(orc_video *v, int joint) { v->joint = joint ? 1 : 0; }
+/* f4 -- the opcode's fourth offset.  The player stores every opcode's content byte at FOUR offsets
+ * (opcodes.py: tick opcodes), and video.py:146 says "Need to find 3 more offsets to fill this opcode", but the
+ * loop's exit test `if len(offsets) == 3: break` (video.py:180-181) counts the primary: it stops after TWO more, and
+ * :184-186 pad the fourth slot with a copy of the first.  With the flag set the test reads 4: up to three extra
+ * offsets, each handled by the loop body exactly as the reference's two are (candidate order, one nonce per
+ * candidate, priority 0 skipped, re-queued with a nonce if the store leaves an error).  NOT the reference's opcode
+ * stream -- a quarter of every opcode's stores is no longer wasted.  Pinned against the reference itself with that
+ * one literal changed (tests/golden/make_golden.py --fourth-only -> g8_fourth_offset.npz). */
+void orc_video_set_fourth_offset(orc_video *v, int fourth) { v->fourth = fourth ? 1 : 0; }
 orc_mt *orc_video_rng_py(orc_video *v) { return &v->rng_py; }
 orc_mt *orc_video_rng_np(orc_video *v) { return &v->rng_np; }
 uint8_t *orc_video_memory(orc_video *v, int is_aux) { return v->mem[is_aux ? 1 : 0]; }
@@ -1032,7 +1042,7 @@ static int step_heap(orc_video *v, uint8_t *out)
                 heap_push(v, ne);
             }
             offsets[noffs++] = o;
-            if (noffs == 3)
+            if (noffs == (v->fourth ? 4 : 3))
                 break; /* :181 */
         }
         for (; noffs < 4;)
@@ -1057,8 +1067,8 @@ static int step_heap(orc_video *v, uint8_t *out)
  *  - pushed entries are an unsorted bag popped by arg-min;
  *  - a location whose priority is 0 can never become non-zero again inside one
  *    generator (secondaries require priority != 0), so lazy deletion is permanent;
- *  - the two extra offsets are the two smallest (delta, nonce, offset) among
- *    candidates whose priority is non-zero; every candidate draws a nonce. */
+ *  - the two extra offsets (three with the fourth-offset flag) are the smallest (delta, nonce, offset)
+ *    among candidates whose priority is non-zero; every candidate draws a nonce. */
 static int step_struct(orc_video *v, uint8_t *out)
 {
     int ia = v->gen_is_aux;
@@ -1106,7 +1116,7 @@ static int step_struct(orc_video *v, uint8_t *out)
             uint64_t s = orc_mask_and_shift(v->mode, orc_masked_update(v->mode, bo, row[y / 2], content), bo);
             nd[y] = v->table[((size_t)bo << (2 * bits)) + ((s << bits) + t)];
         }
-        uint32_t k1 = 0xffffffffu, k2 = 0xffffffffu;
+        uint32_t k1 = 0xffffffffu, k2 = 0xffffffffu, k3 = 0xffffffffu;
         for (int y = 0; y < 256; y++) {
             int32_t d = (int32_t)nd[y] - v->dw[page * 256 + y];
             if (d >= 0)
@@ -1116,15 +1126,19 @@ static int step_struct(orc_video *v, uint8_t *out)
                 continue;
             uint32_t key = ((uint32_t)(d + 2048) << 16) | (nonce << 8) | (uint32_t)y;
             if (key < k1) {
+                k3 = k2;
                 k2 = k1;
                 k1 = key;
             } else if (key < k2) {
+                k3 = k2;
                 k2 = key;
+            } else if (key < k3) {
+                k3 = key;
             }
         }
         int offs[4] = {offset, offset, offset, offset};
-        uint32_t ks[2] = {k1, k2};
-        for (int i = 0; i < 2; i++) {
+        uint32_t ks[3] = {k1, k2, k3};
+        for (int i = 0; i < (v->fourth ? 3 : 2); i++) {
             if (ks[i] == 0xffffffffu)
                 break;
             int y = (int)(ks[i] & 255);

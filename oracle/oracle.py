@@ -136,6 +136,7 @@ def _declare(L):
     L.orc_video_out_of_work.argtypes = [C.c_void_p, C.c_int]
     L.orc_video_reset_out_of_work.argtypes = [C.c_void_p]
     L.orc_video_set_joint.argtypes = [C.c_void_p, C.c_int]
+    L.orc_video_set_fourth_offset.argtypes = [C.c_void_p, C.c_int]
     L.orc_video_encode_frame.argtypes = [C.c_void_p, u8p, u8p, C.c_int]
     L.orc_video_next.restype = C.c_int
     L.orc_video_next.argtypes = [C.c_void_p, C.c_int, u8p]
@@ -368,6 +369,10 @@ class Video:
     def set_joint(self, joint):
         """f4: joint choice of the content byte (README.md:212-215); not reference behaviour."""
         self._L.orc_video_set_joint(self._h, 1 if joint else 0)
+
+    def set_fourth_offset(self, fourth):
+        """f4: up to three extra offsets per opcode (video.py:181 with 4 for 3); not reference behaviour."""
+        self._L.orc_video_set_fourth_offset(self._h, 1 if fourth else 0)
 
     def reset_out_of_work(self):
         self._L.orc_video_reset_out_of_work(self._h)

@@ -56,8 +56,11 @@ for rnd in range(rounds):
         n = 3
         fm, fa = fm[:n], (fa[:n] if fa is not None else None)
         sched = [(f_, a_, r_, min(k_, 90)) for (f_, a_, r_, k_) in sched[:5]]
+    # one round in five of the others: a real fourth offset per opcode (IIV_OPT_FOURTH_OFFSET), against the oracle's flag
+    fourth = bool(not joint and rng.random() < 0.2)
     enc = native.Encoder(mode, dtab[key][0], dtab[key][1], n, dm=dms[pal])
     enc.set_content_choice(joint)
+    enc.set_fourth_offset(fourth)
     enc.set_diff_weights_mode(recurrence)
     enc.set_greedy_kernel(wave)
     enc.set_prefix_sort(prefix)
@@ -70,6 +73,7 @@ for rnd in range(rounds):
     for i in range(n):
         v = O.Video(mode, otab[key], seed_py=seeds[i][0], seed_np=seeds[i][1])
         v.set_joint(joint)
+        v.set_fourth_offset(fourth)
         exp = []
         for (fr, a, restart, k) in sched:
             if restart:
@@ -86,6 +90,6 @@ for rnd in range(rounds):
         assert (int(cnt[0]), int(cnt[1])) == v.draws(), ("draws", rnd, i)
         total_ops += exp.shape[0]
     enc.close()
-    print("round %2d ok: mode=%s pal=%d %s wave=%s rec=%s prefix=%d joint=%d segs=%s" % (
-        rnd, "DHGR" if mode else "HGR", pal, kind, wave, recurrence, prefix, joint, [s[3] for s in sched]), flush=True)
+    print("round %2d ok: mode=%s pal=%d %s wave=%s rec=%s prefix=%d joint=%d fourth=%d segs=%s" % (
+        rnd, "DHGR" if mode else "HGR", pal, kind, wave, recurrence, prefix, joint, fourth, [s[3] for s in sched]), flush=True)
 print("fuzz parity: %d rounds, %d opcodes compared, all equal (%.0f s)" % (rounds, total_ops, time.time() - t_start))

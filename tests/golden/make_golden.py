@@ -205,6 +205,7 @@ def main():
     ap.add_argument("--scratch", default="/tmp/iiv_ref")
     ap.add_argument("--a2m-only", action="store_true")
     ap.add_argument("--movie-only", action="store_true")
+    ap.add_argument("--fourth-only", action="store_true")
     args = ap.parse_args()
 
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -351,9 +352,10 @@ def main():
     print("g5 written")
     make_a2m_golden(args.scratch)
     make_movie_golden(args.scratch)
+    make_fourth_offset_golden(args.scratch)
 
 
-if __name__ == "__main__" and "--a2m-only" not in sys.argv and "--movie-only" not in sys.argv:
+if __name__ == "__main__" and not {"--a2m-only", "--movie-only", "--fourth-only"} & set(sys.argv):
     main()
 
 
@@ -513,3 +515,52 @@ if __name__ == "__main__" and "--movie-only" in sys.argv:
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     setup_reference("/tmp/iiv_ref")
     make_movie_golden("/tmp/iiv_ref")
+
+
+def make_fourth_offset_golden(scratch):
+    """g8: the reference's own encode loop with ONE literal changed -- the exit test of the extra-offset loop,
+    `if len(offsets) == 3: break` (video.py:180-181), reads 4 -- i.e. what video.py:146 ("Need to find 3 more
+    offsets to fill this opcode") announces.  The changed method is built here, at generation time, from the
+    imported reference's source (inspect.getsource + one str.replace) and bound to the imported class; only inputs
+    and outputs go into the fixture.  This is what pins the oracle's orc_video_set_fourth_offset()."""
+    import inspect
+    import textwrap
+    import video
+    src = textwrap.dedent(inspect.getsource(video.Video._index_changes))
+    old = "if len(offsets) == 3:"
+    assert src.count(old) == 1, "the reference's exit test moved"
+    ns = dict(vars(video))
+    exec(compile(src.replace(old, "if len(offsets) == 4:"), "<_index_changes, exit test at 4>", "exec"), ns)
+    original = video.Video._index_changes
+    video.Video._index_changes = ns["_index_changes"]
+    try:
+        g8 = {}
+        cases = [("DHGR_iid_s1", "DHGR", 5, 3, 7, False, 1, None), ("HGR_iid_s2", "HGR", 5, 3, 7, False, 2, None),
+                 ("DHGR_coh_s3", "DHGR", 5, 5, 7, True, 3, None), ("HGR_coh_s1", "HGR", 0, 4, 11, True, 1, None),
+                 ("HGR_exhaust", "HGR", 5, 2, 21, False, 5, [(0, 0, 5200), (1, 0, 300), (1, 0, 5600)]),
+                 ("DHGR_exhaust", "DHGR", 5, 2, 22, False, 5,
+                  [(0, 0, 4200), (0, 1, 4300), (0, 0, 900), (1, 1, 2500), (1, 0, 2500), (1, 1, 3000)])]
+        for (tag, mode_name, pal, nf, dseed, coh, rseed, sched) in cases:
+            t = time.time()
+            frames = synth_frames(mode_name, nf, dseed, coherent=coh)
+            if sched is None:
+                sched = movie_schedule(mode_name, nf)
+            st = run_reference(mode_name, pal, frames, sched, rseed, rseed)
+            g8[tag + "/frames"] = frames
+            g8[tag + "/schedule"] = np.array(sched, dtype=np.int32)
+            g8[tag + "/meta"] = np.array([0 if mode_name == "HGR" else 1, pal, rseed, rseed], dtype=np.int32)
+            for k, val in st.items():
+                g8[tag + "/" + k] = val
+            distinct = np.mean([len(set(r[2:6])) for r in st["ops"].tolist()])
+            print("%s: %d ops, %.2f distinct offsets per opcode, sha %s (%.1fs)" % (
+                tag, len(st["ops"]), distinct, sha(st["ops"])[:16], time.time() - t))
+        np.savez_compressed(os.path.join(HERE, "g8_fourth_offset.npz"), **g8)
+        print("g8 written")
+    finally:
+        video.Video._index_changes = original
+
+
+if __name__ == "__main__" and "--fourth-only" in sys.argv:
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    setup_reference("/tmp/iiv_ref")
+    make_fourth_offset_golden("/tmp/iiv_ref")

@@ -91,6 +91,39 @@ def test_encode_runs(O, golden, oracle_tables, structured):
         assert [L.orc_np_randint256(C.byref(rn)) for _ in range(4)] == g3[tag + "/np_next"].tolist(), tag
 
 
+@pytest.mark.parametrize("structured", [False, True])
+def test_fourth_offset_runs(O, golden, oracle_tables, structured):
+    """f4, the opcode's fourth offset: the oracle with orc_video_set_fourth_offset against the imported reference run
+    with its exit test `len(offsets) == 3` reading 4 (tests/golden/make_golden.py --fourth-only): opcodes, state,
+    both RNG positions -- heap form and the restructured form the kernel implements."""
+    g8 = golden.g8_fourth_offset
+    L = O.lib()
+    for tag in _tags(g8):
+        mode, pal, sp, sn = (int(x) for x in g8[tag + "/meta"])
+        frames, sched, ops = g8[tag + "/frames"], g8[tag + "/schedule"], g8[tag + "/ops"]
+        v = O.Video(mode, oracle_tables.get(mode, pal), seed_py=sp, seed_np=sn)
+        v.set_fourth_offset(True)
+        out = []
+        for fi, ia, n in sched:
+            v.encode_frame(frames[fi, 0], frames[fi, 1] if mode == 1 else None, ia)
+            out.append(v.next(int(n), structured=structured))
+        out = np.concatenate(out)
+        assert (out == ops).all(), tag
+        assert (v.memory(0) == g8[tag + "/mem_main"]).all(), tag
+        assert (v.update_priority(0) == g8[tag + "/up_main"]).all(), tag
+        assert (v.packed == g8[tag + "/packed"]).all(), tag
+        if mode == 1:
+            assert (v.memory(1) == g8[tag + "/mem_aux"]).all(), tag
+            assert (v.update_priority(1) == g8[tag + "/up_aux"]).all(), tag
+        assert [int(v.out_of_work(0)), int(v.out_of_work(1))] == g8[tag + "/out_of_work"].tolist(), tag
+        rp, rn = v.rng_py(), v.rng_np()
+        assert [L.orc_py_getrandbits8(C.byref(rp)) for _ in range(4)] == g8[tag + "/py_next"].tolist(), tag
+        assert [L.orc_np_randint256(C.byref(rn)) for _ in range(4)] == g8[tag + "/np_next"].tolist(), tag
+    # and the flag does change the stream: the same inputs without it give the reference's opcodes (g3), whose
+    # fourth offset is a copy of the first
+    assert (ops[:, 5] != ops[:, 2]).any()
+
+
 def test_rng_matches_python_and_numpy(O):
     """MT19937 seeding + draw conventions (video.py:178,265,291) against the real generators."""
     import random
