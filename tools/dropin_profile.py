@@ -1,28 +1,48 @@
-"""Diagnostic: cProfile of the drop-in Video path (no budget hint), DHGR, 20 frames."""
-import os, sys, time, random, io, contextlib, cProfile, pstats
-sys.path.insert(0, os.path.join(os.getcwd(), 'ii-vision_amd', 'transcoder'))
+"""Where the drop-in video.Video path (one next() per opcode from Python) spends its time: cProfile of 20 Movie-paced
+frames, with and without encode_frame(budget=K).   python tools/dropin_profile.py [DHGR|HGR]"""
+import contextlib, cProfile, io, os, pstats, random, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ii-vision_amd", "transcoder"))
 import numpy as np
-import screen, video, video_mode, palette, stream_batch
-class FG: input_frame_rate = 30
-fm, fa = stream_batch.synth_frames_torch(1, 20, True, seed=3, device="cpu")
-def run(spec, budget):
-    random.seed(1); np.random.seed(1)
-    v = video.Video(FG(), ticks_per_second=14700., mode=video_mode.VideoMode.DHGR, palette=palette.Palette.NTSC)
-    v.SPECULATE = spec
-    segs = stream_batch.MovieClock(True).segments(20)
+import palette, screen, stream_batch, video, video_mode
+
+dhgr = (sys.argv[1] if len(sys.argv) > 1 else "DHGR") == "DHGR"
+n_frames = 20
+pal = palette.Palette.NTSC
+fm, fa = stream_batch.synth_frames_torch(1, n_frames, dhgr, seed=3, device="cpu")
+
+
+class FrameGrabber:
+    input_frame_rate = 30
+
+
+def run(budget):
+    random.seed(1)
+    np.random.seed(1)
+    v = video.Video(FrameGrabber(), ticks_per_second=14700., palette=pal,
+                    mode=video_mode.VideoMode.DHGR if dhgr else video_mode.VideoMode.HGR)
+    segs = stream_batch.MovieClock(dhgr).segments(n_frames)
     tgts = {}
-    t0 = time.perf_counter(); n = 0
+    t0 = time.perf_counter()
     with contextlib.redirect_stdout(io.StringIO()):
         for (fr, ia, _, k) in segs:
             if fr not in tgts:
-                tgts[fr] = screen.DHGRBitmap(main_memory=screen.MemoryMap(1, fm[0, fr].numpy().copy()),
-                                             aux_memory=screen.MemoryMap(1, fa[0, fr].numpy().copy()), palette=palette.Palette.NTSC)
-            gen = v.encode_frame(tgts[fr], is_aux=bool(ia), budget=k if budget else None)
+                main = screen.MemoryMap(1, fm[0, fr].numpy().copy())
+                tgts[fr] = (screen.DHGRBitmap(main_memory=main, aux_memory=screen.MemoryMap(1, fa[0, fr].numpy().copy()), palette=pal)
+                            if dhgr else screen.HGRBitmap(main_memory=main, palette=pal))
+            gen = v.encode_frame(tgts[fr], is_aux=bool(ia), **({"budget": k} if budget else {}))
             for _ in range(k):
-                next(gen); n += 1
-    return 20 / (time.perf_counter() - t0)
-run(64, False)
-for spec, budget in ((64, False), (256, False), (512, False), (0, True)):
-    print("SPECULATE=%d budget=%s: %.1f frames/s" % (spec, budget, run(spec, budget)), flush=True)
-pr = cProfile.Profile(); pr.enable(); run(64, False); pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(28); print(s.getvalue()[:5000])
+                next(gen)
+    return n_frames / (time.perf_counter() - t0)
+
+
+run(False)
+for budget in (False, True):
+    print("budget=%s: %.0f frames/s" % (budget, run(budget)))
+    pr = cProfile.Profile()
+    pr.enable()
+    run(budget)
+    pr.disable()
+    s = io.StringIO()
+    pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(22)
+    print("\n".join(l for l in s.getvalue().splitlines() if l.strip())[:6000])
