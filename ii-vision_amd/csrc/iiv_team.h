@@ -349,7 +349,7 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
     // diagnostic build: shader-clock time of wave 0 per phase of a round, rounds, entries, real time
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memtime();
     const unsigned long long t_start = ph_t, rt_start = __builtin_amdgcn_s_memrealtime();
-    unsigned long long n_rounds = 0, n_entries = 0;
+    unsigned long long n_rounds = 0, n_entries = 0, n_end_avail = 0, n_end_room = 0, n_end_page = 0, n_dead = 0, n_end_tie = 0;
 #define IIV_PHASE(i)                                                  \
     do {                                                              \
         const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
@@ -405,6 +405,13 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
             const unsigned long long stop = __ballot(lane >= room || (before & pbit) != 0u);   // first lane that ends the run
             B = (int)__builtin_ctzll(stop | (1ull << W));
             my_e = (uint32_t)__builtin_amdgcn_readlane((int)ev, wave < W ? wave : 0) & 0x00ffffffu;
+#ifdef IIV_STAMPS
+            if (B < W) {   // why the run is shorter than W: the window, the launch's budget, or a page already in the run
+                if (B >= avail) n_end_avail++;
+                else if (B >= room) n_end_room++;
+                else n_end_page++;
+            }
+#endif
         }
         IIV_PHASE(0);   // loop top: window, run formation
         // the MT19937 wave extends the stream meanwhile: one block while the others score, a second one
@@ -522,6 +529,8 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
 #ifdef IIV_STAMPS
         n_rounds++;
         n_entries += (unsigned long long)n_commit;
+        n_dead += (unsigned long long)__popcll(__ballot(lane < n_commit && r_dead));
+        if (tie_at >= 0 && tie_at + 1 < B) n_end_tie++;
 #endif
     }
 #ifdef IIV_STAMPS
@@ -532,6 +541,10 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
         S.stamps[26] += __builtin_amdgcn_s_memtime() - t_start;
         S.stamps[27] += __builtin_amdgcn_s_memrealtime() - rt_start;
         S.stamps[28] += 1;
+        S.stamps[13] += n_end_avail;
+        S.stamps[14] += n_end_room;
+        S.stamps[15] += n_end_page;
+        S.stamps[31] += n_dead | (n_end_tie << 32);
     }
 #endif
 #undef IIV_PHASE

@@ -28,6 +28,9 @@ for mode in (native.DHGR, native.HGR):
     print("mode %d: %d launches, %d rounds, %d entries (%.2f per round); %.0f shader clocks per round; "
           "shader clock / 100 MHz real-time clock = %.2f" % (mode, launches, rounds, entries, entries / max(rounds, 1),
                                                             total / max(rounds, 1), total / max(real, 1)))
+    print("   runs shorter than 7: ended by the window's edge %d, by the launch's budget %d, by a page already in the run %d; "
+          "runs cut short behind a tie the nonces decide: %d; entries found dead: %d" % (
+              int(st[13]), int(st[14]), int(st[15]), int(st[31]) >> 32, int(st[31]) & 0xffffffff))
     for i, n in enumerate(names[:7]):
         print("   %-26s %8.0f clocks per round" % (n, int(st[16 + i]) / max(rounds, 1)))
     print("   MT wave: %.0f clocks per round, %.2f blocks per round -> %.0f clocks per block" % (
