@@ -546,32 +546,34 @@ def _vs_reference(mode, gpu_fps, port_fps_here):
 
 
 def _single_stream(be, args):
-    """One clip alone (a video is a sequential chain: latency-bound)."""
+    """One clip alone (a video is a sequential chain: latency-bound).  A 50-frame step of one clip is 16 ms of GPU time
+    behind 268 launches: one host hiccup moves it by 10 %, so three such steps are timed and the median is reported."""
     import torch
-    fm, fa = be.sb.synth_frames_torch(1, 60, be.dhgr, seed=99, coherent=args.coherent)
-    b = be.sb.StreamBatch(be.mode, be.table, be.store, 1, seeds=[(1, 1)], dm=be.dm, joint_content=args.joint, fourth_offset=args.fourth)
-    b.enc.set_greedy_kernel({"auto": None, "wave": True, "workgroup": False}.get(args.greedy, args.greedy))
-    b.encode_frames(fm, fa, 10)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    b.encode_frames(fm, fa, 50)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    b.close()
-    out = {"value": 50 / dt, "unit": "frames/s", "us_per_opcode": 1e6 * dt / (50 * OPS_PER_FRAME)}
-    # the same on picture-like input (S-img): there the nonces decide nearly every step's extra offsets (96 % of the
-    # opcodes), which used to end the eight-wave kernel's run of concurrent steps at each of them
-    try:
-        fm, fa = be.sb.synth_frames_img(1, 60, be.dhgr, seed=99)
+
+    def rate(fm, fa):
         b = be.sb.StreamBatch(be.mode, be.table, be.store, 1, seeds=[(1, 1)], dm=be.dm, joint_content=args.joint, fourth_offset=args.fourth)
         b.enc.set_greedy_kernel({"auto": None, "wave": True, "workgroup": False}.get(args.greedy, args.greedy))
         b.encode_frames(fm, fa, 10)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        b.encode_frames(fm, fa, 50)
-        torch.cuda.synchronize()
-        out["value_img"] = 50 / (time.perf_counter() - t0)
+        dts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            b.encode_frames(fm, fa, 50)
+            torch.cuda.synchronize()
+            dts.append(time.perf_counter() - t0)
+        b.enc.check()
         b.close()
+        return sorted(dts)[1]
+
+    fm, fa = be.sb.synth_frames_torch(1, 160, be.dhgr, seed=99, coherent=args.coherent)
+    dt = rate(fm, fa)
+    out = {"value": 50 / dt, "unit": "frames/s", "us_per_opcode": 1e6 * dt / (50 * OPS_PER_FRAME),
+           "sample": "median of three consecutive 50-frame steps of one 160-frame clip (after 10 warm-up frames)"}
+    # the same on picture-like input (S-img): there the nonces decide nearly every step's extra offsets (96 % of the
+    # opcodes), which used to end the eight-wave kernel's run of concurrent steps at each of them
+    try:
+        fm, fa = be.sb.synth_frames_img(1, 160, be.dhgr, seed=99)
+        out["value_img"] = 50 / rate(fm, fa)
     except Exception as e:
         out["value_img"] = None
         out["value_img_error"] = repr(e)
