@@ -328,7 +328,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
     uint32_t pkey_v = 0;          // lanes 1, 2 (FOUR: and 3): the keys pushed by the latest step (track only)
     int push_f1 = 0, push_f2 = 0, push_f3 = 0, push_base = 0;
     auto apply = [&](auto track, int p, int x, uint32_t c, int y1, uint32_t nd1, int y2, uint32_t nd2, int y3, uint32_t nd3, int C) {
-        const uint32_t v1 = y1 >= 0 ? nd1 : 0u, v2 = y2 >= 0 ? nd2 : 0u, v3 = (FOUR && y3 >= 0) ? nd3 : 0u;
+        const uint32_t v1 = nd1, v2 = nd2, v3 = FOUR ? nd3 : 0u;   // (a missing winner's value is 0: step() leaves it so)
         const int y1e = y1 >= 0 ? y1 : x, y2e = y2 >= 0 ? y2 : x, y3e = (FOUR && y3 >= 0) ? y3 : x;   // video.py:185-186
         const int f1 = v1 ? 1 : 0, f2 = v2 ? 1 : 0, f3 = v3 ? 1 : 0;
         if (n_pushed + f1 + f2 + f3 > kPushedCap) {
@@ -422,7 +422,9 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             nd[r] = L.gl[r] + L.gr[r];   // l1 + r1, or 0 + the dense value (iiv_stream.h: narrow form)
-            const int d = (int)((nd[r] << kWdDwShift) | (y0 + r)) - (int)L.dwm[r];
+            // delta << 20 | store value << 8 | offset: the value (11 bits) rides in the key's spare bits, so a winner's key
+            // brings it along (one multiply-add: nd * (2^20 + 2^8) + y; the subtraction touches bits >= 20 only)
+            const int d = (int)(__umul24(nd[r], (1u << kWdDwShift) | (1u << 8)) + (y0 + r)) - (int)L.dwm[r];
             const int gone = __builtin_amdgcn_sbfe((int)pdw, sh0 + r, 1);
             const int live = __builtin_amdgcn_sbfe((int)nzw, sh0 + r, 1);
             ke[r] = d & live;
@@ -435,9 +437,10 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
         const int k1 = a0 < a1 ? a0 : a1, hi01 = a0 < a1 ? a1 : a0, mb = b0 < b1 ? b0 : b1;
         const int k2 = hi01 < mb ? hi01 : mb;
         const int k3 = hi01 < mb ? mb : hi01;   // (FOUR: the lane's third smallest)
-        // store values of byte pairs, for the scalar read-out of the winners' values
-        const uint32_t nd01 = nd[0] | (nd[1] << 16), nd23 = nd[2] | (nd[3] << 16);
-        auto nd_of = [&](int y) -> uint32_t {   // (scalar from here on: two readlanes, no branch)
+        auto nd_in = [](int K) -> uint32_t { return ((uint32_t)K >> 8) & 0x7ffu; };   // the store value inside a fast-path key
+        // (the exact path's keys have no room for it: there it is read out of the lanes, packed in pairs)
+        auto nd_of = [&](int y) -> uint32_t {
+            const uint32_t nd01 = nd[0] | (nd[1] << 16), nd23 = nd[2] | (nd[3] << 16);
             const uint32_t pa = (uint32_t)__builtin_amdgcn_readlane((int)nd01, y >> 2);
             const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane((int)nd23, y >> 2);
             return (((y & 2) ? pb : pa) >> ((y & 1) * 16)) & 0xffffu;
@@ -459,14 +462,14 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
         };
         if (K1 < 0) {
             y1 = K1 & 255;
-            nd1 = nd_of(y1);
+            nd1 = nd_in(K1);
             // (the lane that held a winner moves its next key up)
             const bool hit1 = k1 == K1;
             const int c1 = hit1 ? k2 : k1;
             const int K2 = wave_min_i32(c1);
             if (K2 < 0) {
                 y2 = K2 & 255;
-                nd2 = nd_of(y2);
+                nd2 = nd_in(K2);
                 tie = (K1 >> kWdDwShift) == (K2 >> kWdDwShift);
                 if constexpr (!FOUR) {
                     if (!tie) tie = shared_delta(K2);
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
                     const int K3 = wave_min_i32(c1 == K2 ? n1 : c1);
                     if (K3 < 0) {
                         y3 = K3 & 255;
-                        nd3 = nd_of(y3);
+                        nd3 = nd_in(K3);
                         tie = (K2 >> kWdDwShift) == (K3 >> kWdDwShift) || shared_delta(K3);
                     }
                 }

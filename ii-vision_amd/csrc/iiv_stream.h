@@ -222,9 +222,11 @@ __device__ static inline void narrow_offsets(uint32_t wd, M xm, uint32_t zrel, u
     if (MODE == kDHGR) dl = (rr << 5) + ((lr2 & 30u) + drel);
     else if (!ODD) dl = (rr << 6) + ((lr2 & 62u) + drel);
     else dl = ((rr >> 1) << 7) + ((lr2 & 126u) + drel);
-    const bool x = t != 0;
-    off_l = x ? zrel : lr2;
-    off_r = x ? dl : rr << 1;
+    // (bit selects on the exception bit spread over the word: one v_bfe_i32 and two v_bfi_b32 instead of a compare and
+    // two conditional moves)
+    const uint32_t m = 0u - t;
+    off_l = (zrel & m) | (lr2 & ~m);
+    off_r = (dl & m) | ((rr << 1) & ~m);
 }
 
 // LDS accesses of one wave execute in order: making one lane's LDS writes visible to the
