@@ -4,7 +4,7 @@ set -e
 name="$1"; flags="$2"; src="${3:-iiv_greedy}"
 cd "$(dirname "$0")/../ii-vision_amd/csrc"
 mkdir -p ../../ab
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $flags -c $src.hip -o /tmp/${src}_$name.o
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -mllvm -amdgpu-atomic-optimizer-strategy=None $flags -c $src.hip -o /tmp/${src}_$name.o
 objs=""
 for o in iiv_api iiv_tables iiv_bitmap iiv_encode iiv_prologue iiv_workgroup iiv_greedy iiv_team iiv_a2m iiv_ingest; do
   if [ "$o" = "$src" ]; then objs="$objs /tmp/${src}_$name.o"; else objs="$objs $o.o"; fi
