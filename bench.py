@@ -310,6 +310,7 @@ def main(argv=None, backend_cls=GpuBackend):
             out["dropin"] = _dropin_video(args)
             if dhgr and not args.joint and not args.fourth:   # SURVEY 8(d) M1 "plus HGR frames/s": a short HGR leg with its own tables and clips
                 out["hgr"] = _hgr_leg(be, args, local_rank, world)
+                out["fourth_offset"] = _hgr_leg(be, args, local_rank, world, steps=4, mode="DHGR", fourth=True)
 
         print(json.dumps(out))
     if use_dist:
@@ -447,9 +448,10 @@ def _roofline_objects(be, args, prof, op_count, seg_count, S, elapsed, live_ceil
     return out
 
 
-def _hgr_leg(be, args, local_rank, world, steps=6, warmup=1):
+def _hgr_leg(be, args, local_rank, world, steps=6, warmup=1, mode="HGR", fourth=False):
     """HGR frames/s (BASELINE config 3's workload) in the default line: the DHGR leg's clips and tables are
-    released, HGR tables are built and `steps` x 50 frames of as many HGR S-iid clips are encoded the same way."""
+    released, HGR tables are built and `steps` x 50 frames of as many HGR S-iid clips are encoded the same way.
+    (mode="DHGR", fourth=True: the same short leg for f4's fourth offset per opcode -- not the reference's stream.)"""
     import copy
     import gc
     S = be.S
@@ -460,7 +462,7 @@ def _hgr_leg(be, args, local_rank, world, steps=6, warmup=1):
     gc.collect()
     be.torch.cuda.empty_cache()
     a2 = copy.copy(args)
-    a2.mode, a2.steps, a2.warmup = "HGR", steps, warmup
+    a2.mode, a2.steps, a2.warmup, a2.fourth = mode, steps, warmup, fourth
     h = GpuBackend(a2, local_rank, world)
     h.build_tables()
     n_frames = steps * a2.frames_per_step
@@ -468,11 +470,19 @@ def _hgr_leg(be, args, local_rank, world, steps=6, warmup=1):
     h.make_batch(S, rank_seeds(0, S))
     leg = timed_leg(h, steps, warmup)
     fps = steps * a2.frames_per_step * S / leg["elapsed"]
-    out = {"metric": "HGR frames transcoded/sec", "value": fps, "unit": "frames/s", "steps": steps, "warmup": warmup,
+    out = {"metric": "%s frames transcoded/sec" % mode, "value": fps, "unit": "frames/s", "steps": steps, "warmup": warmup,
            "ms_per_step": 1000.0 * leg["elapsed"] / steps,
-           "workload": "HGR NTSC palette 280x192 S-iid synthetic clips, %d independent clips x %d frames, Movie.encode "
-                       "control flow (490 opcodes/frame)" % (S, n_frames)}
-    out.update(_roofline_objects(h, a2, leg["prof"], leg["op_count"], leg["seg_count"], S, leg["elapsed"], live_ceiling=True))
+           "workload": "%s NTSC palette S-iid synthetic clips, %d independent clips x %d frames, Movie.encode "
+                       "control flow (490 opcodes/frame)" % (mode, S, n_frames)}
+    if fourth:
+        o = leg["first_ops"].cpu().numpy().reshape(-1, 6)[:, 2:6]
+        o.sort(axis=1)
+        out["distinct_offsets_per_opcode"] = float(((o[:, 1:] != o[:, :-1]).sum(axis=1) + 1).mean())
+        out["note"] = ("IIV_OPT_FOURTH_OFFSET: up to three extra offsets per opcode instead of the reference's two and a copy of "
+                       "the first (video.py:146,180-186) -- NOT the reference's stream, off by default; what it buys in picture "
+                       "error per frame: profiles/r03_fourth_offset.txt")
+    else:
+        out.update(_roofline_objects(h, a2, leg["prof"], leg["op_count"], leg["seg_count"], S, leg["elapsed"], live_ceiling=True))
     h.batch.close()
     return out
 
