@@ -700,7 +700,7 @@ static int launch_round(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux,
     const bool use_wave = e->fourth_offset || (e->d_left && e->greedy_mode != IIV_GREEDY_WORKGROUP && e->content_choice == IIV_CONTENT_TARGET);
     // few streams: a team of eight waves per stream scores the next entries of the list
     // concurrently (iiv_team.hip); from ~900 streams on, one wave per stream fills the GPU
-    const bool use_team = use_wave && !e->fourth_offset && (e->greedy_mode == IIV_GREEDY_TEAM ||
+    const bool use_team = use_wave && (e->greedy_mode == IIV_GREEDY_TEAM ||
                                        (e->greedy_mode == IIV_GREEDY_AUTO && e->n_streams <= kTeamMaxStreams));
     if (use_wave) {
         GreedyArgs a{e->d_states, d_main, d_aux, n_frames, e->n_streams, d_round, seg_stride, e->d_left, e->d_right, e->nt, d_ops,

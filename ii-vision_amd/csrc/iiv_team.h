@@ -46,7 +46,9 @@ constexpr int kRing = kRingNeed + 6;       // MT19937 blocks kept in LDS
 static_assert(623 + kScorers * 258 + 2 <= 4991, "ring_word divides by 624 exactly only below 4991");
 
 // TW = waves in the workgroup (greedy_team_kernel: 8; waves beyond the eighth would only follow the rounds)
-template <int MODE, int TW>
+// FOUR (f4, IIV_OPT_FOURTH_OFFSET; not the reference's behaviour): up to three extra offsets per opcode, as in
+// greedy_wave_kernel<MODE, 1, true> (iiv_greedy.hip) and oracle/iiv_oracle.c: orc_video_set_fourth_offset.
+template <int MODE, int TW, bool FOUR = false>
 __device__ __forceinline__ void team_body(StreamState *__restrict__ states, const uint8_t *__restrict__ frames_main,
                                           const uint8_t *__restrict__ frames_aux, int n_frames, const LaunchSeg &g,
                                           const NarrowTables &nt,
@@ -156,11 +158,13 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
         uint32_t nd01, nd23;            // store values of the lane's four bytes, packed in pairs
         int ke[4];                      // eligible keys delta << 20 | offset (>= 0: not eligible)
         unsigned long long cand[4];     // candidate masks (delta < 0, diff weight still counts), per byte column
-        int C, y1, y2;
-        uint32_t nd1, nd2;
+        int C, y1, y2, y3;
+        uint32_t nd1, nd2, nd3;
         bool tie, live;
         bool tie_soft;   // the nonces decide the winners, but not how many entries the step re-queues: it need not end the run
+        int fcount;      // how many entries the step re-queues (the winners with a non-zero store value), if that is known
     };
+    constexpr int kSlots = FOUR ? 3 : 2;   // extra offsets per opcode
     auto nd_of = [&](const Scored &sc, int y) -> uint32_t {
         const uint32_t pa = (uint32_t)__builtin_amdgcn_readlane((int)sc.nd01, y >> 2);
         const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane((int)sc.nd23, y >> 2);
@@ -227,48 +231,79 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
         const int a1 = sc.ke[2] < sc.ke[3] ? sc.ke[2] : sc.ke[3], b1 = sc.ke[2] < sc.ke[3] ? sc.ke[3] : sc.ke[2];
         const int k1 = a0 < a1 ? a0 : a1, hi01 = a0 < a1 ? a1 : a0, mb = b0 < b1 ? b0 : b1;
         const int k2 = hi01 < mb ? hi01 : mb;
+        const int k3 = hi01 < mb ? mb : hi01;   // (FOUR: the lane's third smallest)
         const int K1 = wave_min_i32(k1);
-        sc.y1 = sc.y2 = -1;
-        sc.nd1 = sc.nd2 = 0;
+        sc.y1 = sc.y2 = sc.y3 = -1;
+        sc.nd1 = sc.nd2 = sc.nd3 = 0;
         sc.tie = false;
         sc.tie_soft = false;
+        sc.fcount = 0;
+        // the delta class of key K (eligible bytes with K's delta): its size; whether it holds zero / non-zero store values
+        auto class_size = [&](int K) -> int {
+            int n = 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) n += (int)__popcll(__ballot(((uint32_t)(sc.ke[r] ^ K) >> kWdDwShift) == 0u));
+            return n;
+        };
+        auto class_values = [&](int K, unsigned long long &zero, unsigned long long &nonzero) {
+            zero = nonzero = 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const bool member = ((uint32_t)(sc.ke[r] ^ K) >> kWdDwShift) == 0u;
+                zero |= __ballot(member && nd[r] == 0u);
+                nonzero |= __ballot(member && nd[r] != 0u);
+            }
+        };
         if (K1 < 0) {
             sc.y1 = K1 & 255;
             sc.nd1 = nd_of(sc, sc.y1);
-            const int K2 = wave_min_i32(k1 == K1 ? k2 : k1);
+            const bool hit1 = k1 == K1;
+            const int c1 = hit1 ? k2 : k1;
+            const int K2 = wave_min_i32(c1);
+            int K3 = 0;
             if (K2 < 0) {
                 sc.y2 = K2 & 255;
                 sc.nd2 = nd_of(sc, sc.y2);
-                sc.tie = (K1 >> kWdDwShift) == (K2 >> kWdDwShift);
-                if (!sc.tie) {
-                    int n2 = 0;
-#pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        n2 += (int)__popcll(__ballot(((uint32_t)(sc.ke[r] ^ K2) >> kWdDwShift) == 0u));
-                    sc.tie = n2 > 1;   // a third eligible byte shares the second delta: the nonces decide
-                }
-                if (sc.tie) {
-                    // The steps behind a tie need only the NUMBER of random words it will draw (one per candidate, known, and
-                    // one per re-queued byte: a winner whose store value is non-zero, video.py:170-178).  If every byte that
-                    // can still win has a non-zero store value, or every one a zero, that number does not depend on the
-                    // nonces: the run goes on, and the tie is resolved by its own wave at commit time, at its own offset of
-                    // the random stream.  (On picture-like input 96 % of the steps tie: ending the run at each would
-                    // leave one step per round.)  Who can still win: the bytes sharing the smallest delta if there are two
-                    // of them, else -- the first winner being fixed -- those sharing the second.
-                    const bool first_fixed = (K1 >> kWdDwShift) != (K2 >> kWdDwShift);
-                    unsigned long long zero = 0, nonzero = 0;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const bool member = ((uint32_t)(sc.ke[r] ^ K2) >> kWdDwShift) == 0u;   // (K2's delta is the deciding class either way)
-                        zero |= __ballot(member && nd[r] == 0u);
-                        nonzero |= __ballot(member && nd[r] != 0u);
+                if constexpr (FOUR) {
+                    K3 = wave_min_i32(c1 == K2 ? (hit1 ? k3 : k2) : c1);
+                    if (K3 < 0) {
+                        sc.y3 = K3 & 255;
+                        sc.nd3 = nd_of(sc, sc.y3);
                     }
-                    if (!(zero && nonzero)) {
-                        sc.tie = false;
+                }
+            }
+            // the winners as found (no tie): what they re-queue
+            sc.fcount = (sc.nd1 ? 1 : 0) + (sc.nd2 ? 1 : 0) + (sc.nd3 ? 1 : 0);
+            // Do the nonces decide?  KL = the last winner found.  They do if two winners share a delta, or -- with every
+            // slot filled -- a further eligible byte shares KL's.
+            const int n_won = K2 >= 0 ? 1 : (FOUR && K3 < 0) ? 3 : 2;
+            if (n_won >= 2) {
+                const int KL = n_won == 3 ? K3 : K2;
+                const int dL = KL >> kWdDwShift;
+                const bool eq12 = (K1 >> kWdDwShift) == (K2 >> kWdDwShift);
+                const bool eq23 = n_won == 3 && (K2 >> kWdDwShift) == dL;
+                const bool full = n_won == kSlots;
+                // winners with a smaller delta than the last one's: they win whatever the nonces say
+                const int lt = ((K1 >> kWdDwShift) < dL ? 1 : 0) + ((n_won == 3 && (K2 >> kWdDwShift) < dL) ? 1 : 0);
+                const int r = n_won - lt;                          // slots that go to the last winner's class
+                // more members than slots: the nonces choose among them.  (With two slots and two winners sharing a delta
+                // the class is counted only to tell a soft tie from a softer one: not worth it -- taken as shared.)
+                const bool shared = full && ((!FOUR && eq12) || class_size(KL) > r);
+                if (eq12 || eq23 || shared) {
+                    // The steps behind a tie need only the NUMBER of random words it will draw (one per candidate, known, and
+                    // one per re-queued byte: a winner whose store value is non-zero, video.py:170-178).  That number does not
+                    // depend on the nonces if the class the nonces choose from goes in whole (as many members as slots), or
+                    // if its members' store values are all zero or all non-zero: the run goes on, and the tie is resolved
+                    // by its own wave at commit time, at its own offset of the random stream.  (On picture-like input 96 % of
+                    // the steps tie: ending the run at each would leave one step per round.)
+                    if (!shared) {
+                        sc.tie_soft = true;        // (the winners are the ones found, in an order the nonces decide: fcount stands)
+                    } else if (unsigned long long zero = 0, nonzero = 0; class_values(KL, zero, nonzero), !(zero && nonzero)) {
                         sc.tie_soft = true;
-                        // what the step will re-queue, whoever wins (published instead of the provisional winners' values)
-                        if (!first_fixed) sc.nd1 = nonzero ? 1u : 0u;
-                        sc.nd2 = nonzero ? 1u : 0u;
+                        const int f_lt = ((K1 >> kWdDwShift) < dL && sc.nd1 ? 1 : 0) + ((n_won == 3 && (K2 >> kWdDwShift) < dL && sc.nd2) ? 1 : 0);
+                        sc.fcount = f_lt + (nonzero ? r : 0);
+                    } else {
+                        sc.tie = true;
                     }
                 }
             }
@@ -296,29 +331,38 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
         const int thi = ta0 < ta1 ? ta1 : ta0, tmb = tb0 < tb1 ? tb0 : tb1;
         const int t2 = thi < tmb ? thi : tmb;
         const int T1 = wave_min_i32(t1);
-        const int T2 = wave_min_i32(t1 == T1 ? t2 : t1);
+        const bool thit1 = t1 == T1;
+        const int tc1 = thit1 ? t2 : t1;
+        const int T2 = wave_min_i32(tc1);
         sc.y1 = T1 != kNone ? (T1 & 255) : -1;
         sc.y2 = T2 != kNone ? (T2 & 255) : -1;
         sc.nd1 = sc.y1 >= 0 ? nd_of(sc, sc.y1) : 0u;
         sc.nd2 = sc.y2 >= 0 ? nd_of(sc, sc.y2) : 0u;
+        if constexpr (FOUR) {
+            const int t3 = thi < tmb ? tmb : thi;
+            const int T3 = wave_min_i32(tc1 == T2 ? (thit1 ? t3 : t2) : tc1);
+            sc.y3 = T3 != kNone ? (T3 & 255) : -1;
+            sc.nd3 = sc.y3 >= 0 ? nd_of(sc, sc.y3) : 0u;
+        }
+        sc.fcount = (sc.nd1 ? 1 : 0) + (sc.nd2 ? 1 : 0) + (sc.nd3 ? 1 : 0);
     };
     // video.py:140-144, 170-187; screen.py:256-293: the stores of one step.  q_push = ring position of
     // the first re-queue nonce, push_at / op_at = where its pushed entries / its opcode go.
     auto commit = [&](uint32_t e, const Scored &sc, int q_push, int push_at, int op_at) {
         const int p = (e >> 8) & 31, x = e & 255;
         const uint32_t c = (e >> 16) & 0xffu;
-        const uint32_t v1 = sc.y1 >= 0 ? sc.nd1 : 0u, v2 = sc.y2 >= 0 ? sc.nd2 : 0u;
-        const int y1e = sc.y1 >= 0 ? sc.y1 : x, y2e = sc.y2 >= 0 ? sc.y2 : x;   // video.py:185-186
-        const int f1 = v1 ? 1 : 0;
-        if (lane < 3) {
-            const int off = lane == 0 ? x : lane == 1 ? y1e : y2e;
-            const uint32_t val = lane == 0 ? 0u : lane == 1 ? v1 : v2;
+        const uint32_t v1 = sc.y1 >= 0 ? sc.nd1 : 0u, v2 = sc.y2 >= 0 ? sc.nd2 : 0u, v3 = (FOUR && sc.y3 >= 0) ? sc.nd3 : 0u;
+        const int y1e = sc.y1 >= 0 ? sc.y1 : x, y2e = sc.y2 >= 0 ? sc.y2 : x, y3e = (FOUR && sc.y3 >= 0) ? sc.y3 : x;   // video.py:185-186
+        const int f1 = v1 ? 1 : 0, f2 = v2 ? 1 : 0;
+        if (lane < 1 + kSlots) {
+            const int off = lane == 0 ? x : lane == 1 ? y1e : lane == 2 ? y2e : y3e;
+            const uint32_t val = lane == 0 ? 0u : lane == 1 ? v1 : lane == 2 ? v2 : v3;
             up[p * 256 + off] = (int32_t)val;
             mem[p * 256 + off] = (uint8_t)c;
             if (val == 0) {
                 atomicAnd(&nz[p * 8 + (off >> 5)], ~(1u << (off & 31)));
             } else {
-                const int k = lane == 2 ? f1 : 0;
+                const int k = lane == 2 ? f1 : lane == 3 ? f1 + f2 : 0;
                 const uint32_t nonce = mt_temper(ring_word(q_push + k)) >> 24;   // video.py:178
                 S.pushed[push_at + k] = ((2047u - val) << 21) | (nonce << 13) | ((uint32_t)p << 8) | (uint32_t)off;
             }
@@ -330,7 +374,7 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
                 q[2] = (uint8_t)x;
                 q[3] = (uint8_t)y1e;
                 q[4] = (uint8_t)y2e;
-                q[5] = (uint8_t)x;
+                q[5] = (uint8_t)(FOUR ? y3e : x);
             }
         }
     };
@@ -429,16 +473,16 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
         sc.live = false;
         sc.tie = false;
         sc.tie_soft = false;
-        sc.y1 = sc.y2 = -1;
-        sc.nd1 = sc.nd2 = 0;
+        sc.y1 = sc.y2 = sc.y3 = -1;
+        sc.nd1 = sc.nd2 = sc.nd3 = 0;
+        sc.fcount = 0;
         if (wave < B) {
             if (cur.e != (my_e | 0x80000000u)) load(my_e, cur);   // (not the entry that was requested ahead)
             score(cur, sc);
             if (MODE == kDHGR && sc.live && ((my_e >> 16) & 0xffu) >= 0x80) sc.C |= 1 << 29;   // video.py:137
             if (lane == 0) {
-                const int f1 = (sc.y1 >= 0 && sc.nd1) ? 1 : 0, f2 = (sc.y2 >= 0 && sc.nd2) ? 1 : 0;
                 res[wave][0] = (uint32_t)sc.C | (sc.live ? 0u : 1u << 31) | (sc.tie ? 1u << 30 : 0u);
-                res[wave][1] = (uint32_t)f1 | ((uint32_t)f2 << 1);
+                res[wave][1] = (uint32_t)sc.fcount;   // entries the step re-queues (a tie the nonces decide: rewritten after its resolution)
             }
         }
         IIV_PHASE(1);   // load (if not requested ahead) + score
@@ -456,7 +500,7 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
         // entries that take effect this round: up to and including a tie (it is resolved with the nonces
         // at its own offset; what was scored behind it is redone), up to but excluding a bad content byte
         int n_commit = first_stop < 0 ? B : bad_palette ? first_stop : first_stop + 1;
-        const uint32_t f12 = (rv.y & 1u) + ((rv.y >> 1) & 1u);
+        const uint32_t f12 = rv.y;
         const bool counts = lane < n_commit && !r_dead && lane != tie_at;   // (the tie's own numbers are added after its resolution)
         const uint32_t item = counts ? ((rv.x & 0x1fffu) + f12) | (f12 << 12) | (1u << 17) : 0u;
         uint32_t scan = item;
@@ -470,7 +514,7 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
                   op_mine = done + (int)(mine >> 17);
         int q = mt_idx + (int)(all & 0xfffu), pu = n_pushed + (int)((all >> 12) & 0x1fu), op = done + (int)(all >> 17);
         if (bad_palette) err = kErrPaletteBit;
-        if (pu + 2 > kPushedCap) {   // (+2: the tie entry, whose pushes are not known yet)
+        if (pu + kSlots > kPushedCap) {   // (+ the tie entry, whose pushes are not known yet)
             err = kErrPushedOverflow;
             n_commit = 0;
         }
@@ -493,10 +537,7 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
             if (sc.tie_soft) resolve_tie(sc, q_mine);   // (its re-queue count was published: nothing to tell the others)
             if (wave == tie_at) {
                 resolve_tie(sc, q_mine);
-                if (lane == 0) {
-                    const int f1 = (sc.y1 >= 0 && sc.nd1) ? 1 : 0, f2 = (sc.y2 >= 0 && sc.nd2) ? 1 : 0;
-                    res[wave][1] = (uint32_t)f1 | ((uint32_t)f2 << 1);
-                }
+                if (lane == 0) res[wave][1] = (uint32_t)sc.fcount;
             }
             commit(my_e, sc, q_mine + sc.C, push_mine, op_mine);
         }
@@ -506,8 +547,8 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
         valid += grow1 + grow2;
         if (tie_at >= 0 && !err) {
             const uint32_t r0 = res[tie_at][0], r1 = res[tie_at][1];
-            q += (int)(r0 & 0x1fffu) + (int)(r1 & 1u) + (int)((r1 >> 1) & 1u);
-            pu += (int)(r1 & 1u) + (int)((r1 >> 1) & 1u);
+            q += (int)(r0 & 0x1fffu) + (int)r1;
+            pu += (int)r1;
             op += 1;
         }
         draws += (uint32_t)(q - mt_idx);
@@ -592,17 +633,17 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
             err = kErrPaletteBit;
             break;
         }
-        if (n_pushed + 2 > kPushedCap) {
+        if (n_pushed + kSlots > kPushedCap) {
             err = kErrPushedOverflow;
             break;
         }
-        if (sc.tie) resolve_tie(sc, mt_idx);
-        const int f1 = (sc.y1 >= 0 && sc.nd1) ? 1 : 0, f2 = (sc.y2 >= 0 && sc.nd2) ? 1 : 0;
+        if (sc.tie || sc.tie_soft) resolve_tie(sc, mt_idx);
+        const int fq = sc.fcount;
         commit(e, sc, mt_idx + sc.C, n_pushed, done);
         wave_lds_sync();
-        mt_idx += sc.C + f1 + f2;
-        draws += (uint32_t)(sc.C + f1 + f2);
-        n_pushed += f1 + f2;
+        mt_idx += sc.C + fq;
+        draws += (uint32_t)(sc.C + fq);
+        n_pushed += fq;
         done++;
         while (mt_idx >= 624) {
             ring_drop();

@@ -4,7 +4,7 @@
 
 namespace iiv {
 
-template <int MODE>
+template <int MODE, bool FOUR>
 __global__ __launch_bounds__(64 * kScoringWaves) void greedy_team_kernel(StreamState *__restrict__ states,
                                                                          const uint8_t *__restrict__ frames_main,
                                                                          const uint8_t *__restrict__ frames_aux, int n_frames,
@@ -13,17 +13,22 @@ __global__ __launch_bounds__(64 * kScoringWaves) void greedy_team_kernel(StreamS
                                                                          uint8_t *__restrict__ ops_out, size_t ops_stride)
 {
     const LaunchSeg g = segs[(size_t)blockIdx.x * seg_stride];
-    team_body<MODE, kScoringWaves>(states, frames_main, frames_aux, n_frames, g, nt, ops_out, ops_stride);
+    team_body<MODE, kScoringWaves, FOUR>(states, frames_main, frames_aux, n_frames, g, nt, ops_out, ops_stride);
 }
 
 int launch_greedy_team(int mode, const GreedyArgs &a, hipStream_t st)
 {
-    if (mode == kDHGR)
-        hipLaunchKernelGGL(greedy_team_kernel<kDHGR>, dim3(a.n_streams), dim3(64 * kScoringWaves), 0, st, a.states, a.frames_main,
-                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride);
-    else
-        hipLaunchKernelGGL(greedy_team_kernel<kHGR>, dim3(a.n_streams), dim3(64 * kScoringWaves), 0, st, a.states, a.frames_main,
-                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride);
+#define IIV_TEAM(M, F)                                                                                                        \
+    hipLaunchKernelGGL((greedy_team_kernel<M, F>), dim3(a.n_streams), dim3(64 * kScoringWaves), 0, st, a.states, a.frames_main, \
+                       a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride)
+    if (mode == kDHGR) {
+        if (a.fourth) IIV_TEAM(kDHGR, true);
+        else IIV_TEAM(kDHGR, false);
+    } else {
+        if (a.fourth) IIV_TEAM(kHGR, true);
+        else IIV_TEAM(kHGR, false);
+    }
+#undef IIV_TEAM
     return hip_check(hipGetLastError(), "greedy_team_kernel launch");
 }
 

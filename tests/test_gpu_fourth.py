@@ -23,7 +23,7 @@ def _encoder(native, device_tables, mode, pal, n, recurrence=True, prefix=True, 
     enc = native.Encoder(mode, t, s, n, dm=device_tables.dm[(mode, pal)])
     enc.set_diff_weights_mode(recurrence)
     enc.set_prefix_sort(prefix)
-    enc.set_greedy_kernel(kernel)      # (whatever is asked for: the option runs in the one-wave kernel)
+    enc.set_greedy_kernel(kernel)      # (the option runs in the one-wave and the eight-wave kernel; others fall back to the one-wave)
     enc.set_fourth_offset(True)
     return enc
 
@@ -129,6 +129,40 @@ def test_fourth_offset_leaves_less_error_per_opcode(native, O, device_tables, mo
     assert (res[True] < res[False]).all(), (res[True], res[False])
     gain = 1.0 - res[True].sum() / res[False].sum()
     assert 0.005 < gain < 0.3, gain
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("fourth", [False, True])
+def test_team_kernel_to_exhaustion_on_picture_like_input(native, O, oracle_tables, device_tables, mode, fourth):
+    """The eight-wave kernel (one clip alone: what a single video.Video uses), with and without the option, on
+    picture-like input (nearly every step is decided by the nonces) through the list, the re-queued bag -- wave 0 alone,
+    ties resolved there too -- and out of work: every opcode equals the oracle's."""
+    import stream_batch
+    n, nf = 4, 2
+    fm, fa = stream_batch.synth_frames_img(n, nf, mode == 1, seed=31, device="cpu")
+    sched = [(0, 0, 1, 2500), (0, 0, 0, 2500), (1, 0, 1, 3000), (1, 0, 0, 3000)]
+    enc = _encoder(native, device_tables, mode, 5, n, kernel="team")
+    enc.set_fourth_offset(fourth)
+    seeds = [(i + 3, i + 9) for i in range(n)]
+    for i, (sp, sn) in enumerate(seeds):
+        enc.set_state(native.STATE_RNG_PY, O.mt_seed_py(sp).state_words(), i)
+        enc.set_state(native.STATE_RNG_NP, O.mt_seed_np(sn).state_words(), i)
+    got = enc.encode(fm.cuda(), fa.cuda() if fa is not None else None, sched).cpu().numpy()
+    enc.check()
+    for i in range(n):
+        v = O.Video(mode, oracle_tables.get(mode, 5), seed_py=seeds[i][0], seed_np=seeds[i][1])
+        v.set_fourth_offset(fourth)
+        exp = []
+        for (fr, a, restart, k) in sched:
+            if restart:
+                v.encode_frame(fm[i, fr].numpy(), fa[i, fr].numpy() if fa is not None else None, a)
+            exp.append(v.next(k))
+        exp = np.concatenate(exp)
+        bad = np.nonzero((got[i] != exp).any(axis=1))[0]
+        assert len(bad) == 0, "stream %d: first mismatch at op %d: got %s want %s" % (i, bad[0], got[i][bad[0]], exp[bad[0]])
+        assert v.out_of_work(0) and enc.get_state(native.STATE_OUT_OF_WORK, i)[0] == 1
+        assert (enc.get_state(native.STATE_UP_MAIN, i) == v.update_priority(0)).all()
+    enc.close()
 
 
 def test_option_rules(native, device_tables):
