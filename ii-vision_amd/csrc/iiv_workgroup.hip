@@ -387,7 +387,10 @@ __global__ __launch_bounds__(256) void greedy_kernel(StreamState *__restrict__ s
 
             // ---- apply (video.py:140-144, 170-178; screen.py:256-293)
             if (y == x) {
-                dwf[p * 256 + x] = 0;
+                // (its diff weight counts as 0 from here on, video.py:141; its priority is 0 -- or, with the joint choice, the
+                // error the chosen byte leaves: then the location stays live for a later pop of a stale bag entry, as in the
+                // oracle's definition, video.py:130)
+                dwf[p * 256 + x] = (JOINT && joint_res) ? (uint16_t)0x8000u : (uint16_t)0;
                 S.up[is_aux][p * 256 + x] = JOINT ? (int32_t)joint_res : 0;
                 S.mem[is_aux][p * 256 + x] = (uint8_t)c;
             }

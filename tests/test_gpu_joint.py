@@ -105,6 +105,28 @@ def test_joint_leaves_less_error_per_opcode(native, O, device_tables, mode):
     assert 0.01 < gain < 0.2, gain
 
 
+@pytest.mark.parametrize("mode,ops", [(1, 6000), (0, 4500)])
+def test_joint_runs_past_the_list_into_the_bag(native, O, oracle_tables, device_tables, mode, ops):
+    """A generator pulled far past its sorted list: the joint choice leaves a primary with a residual priority (it is not
+    re-queued, video.py:140 with IIV_CONTENT_JOINT), so a stale bag entry of that location, pushed when it was an extra
+    offset, finds it live when it is popped and the location is encoded again -- as the oracle's definition does.  (Until
+    round 3 the kernel dropped such pops: every joint test stopped short of the bag.)"""
+    import stream_batch
+    n = 2
+    fm, fa = stream_batch.synth_frames_torch(n, 2, mode == 1, seed=5, coherent=True, device="cpu", keep=0.97)
+    frames = [np.stack([fm[i].numpy(), fa[i].numpy() if fa is not None else np.zeros_like(fm[i].numpy())], axis=1) for i in range(n)]
+    sched = [(0, 0, ops), (1, 0, 1500)]
+    seeds = [(i + 3, i + 9) for i in range(n)]
+    enc, got = _device(native, device_tables, mode, frames, sched, seeds, O, True)
+    for i in range(n):
+        v, exp = _oracle(O, oracle_tables, mode, frames[i], sched, *seeds[i], True)
+        bad = np.nonzero((got[i] != exp).any(axis=1))[0]
+        assert len(bad) == 0, "stream %d: first mismatch at op %d: got %s want %s" % (i, bad[0], got[i][bad[0]], exp[bad[0]])
+        assert (enc.get_state(native.STATE_UP_MAIN, i) == v.update_priority(0)).all()
+        assert (enc.get_state(native.STATE_MEM_MAIN, i) == v.memory(0)).all()
+    enc.close()
+
+
 def test_default_is_the_reference_step(native, O, oracle_tables, device_tables):
     """The flag is off unless asked for, and switching it off again restores the reference's stream."""
     mode = 1
