@@ -46,6 +46,11 @@ for rnd in range(rounds):
             f = int(rng.integers(0, nf))
             ia = int(rng.integers(0, 2)) if mode == 1 else 0
         sched.append((f, ia, restart, k))
+    # one round in seven: a marathon -- one generator pulled far past its sorted list, through the re-queued bag and
+    # (usually) out of work, then another one on top of what it left
+    marathon = bool(rng.random() < 1 / 7)
+    if marathon:
+        sched = [(int(rng.integers(0, nf)), 0, 1, int(rng.integers(5000, 9500))), (int(rng.integers(0, nf)), int(rng.integers(0, 2)) if mode == 1 else 0, 1, 1200)]
     wave = (True, "shared", "shared", "team", "team", False)[int(rng.integers(0, 6))]
     recurrence = ("split", "split", True, True, False)[int(rng.integers(0, 5))]
     prefix = bool(rng.random() < 0.7)
@@ -53,9 +58,9 @@ for rnd in range(rounds):
     # (128 / 256 times the lookups per step on the CPU: shorter schedules, fewer streams)
     joint = bool(rng.random() < 1 / 6)
     if joint:
-        n = 3
+        n = 2 if marathon else 3
         fm, fa = fm[:n], (fa[:n] if fa is not None else None)
-        sched = [(f_, a_, r_, min(k_, 90)) for (f_, a_, r_, k_) in sched[:5]]
+        sched = [(f_, a_, r_, min(k_, 4200 if marathon else 90)) for (f_, a_, r_, k_) in sched[:5]]
     # one round in five of the others: a real fourth offset per opcode (IIV_OPT_FOURTH_OFFSET), against the oracle's flag
     fourth = bool(not joint and rng.random() < 0.2)
     enc = native.Encoder(mode, dtab[key][0], dtab[key][1], n, dm=dms[pal])
@@ -90,6 +95,6 @@ for rnd in range(rounds):
         assert (int(cnt[0]), int(cnt[1])) == v.draws(), ("draws", rnd, i)
         total_ops += exp.shape[0]
     enc.close()
-    print("round %2d ok: mode=%s pal=%d %s wave=%s rec=%s prefix=%d joint=%d fourth=%d segs=%s" % (
-        rnd, "DHGR" if mode else "HGR", pal, kind, wave, recurrence, prefix, joint, fourth, [s[3] for s in sched]), flush=True)
+    print("round %2d ok: mode=%s pal=%d %s wave=%s rec=%s prefix=%d joint=%d fourth=%d%s segs=%s" % (
+        rnd, "DHGR" if mode else "HGR", pal, kind, wave, recurrence, prefix, joint, fourth, " marathon" if marathon else "", [s[3] for s in sched]), flush=True)
 print("fuzz parity: %d rounds, %d opcodes compared, all equal (%.0f s)" % (rounds, total_ops, time.time() - t_start))
