@@ -222,7 +222,11 @@ class Video:
             self._aux_memory_map.page_offset[...] = st.array("mem_aux", np.uint8, (32, 256))
             self._aux_update_priority[...] = st.array("up_aux", np.int32, (32, 256))
         self._pixelmap.packed[...] = st.array("packed", np.uint64, (32, 128))
-        self._set_global_rng(st)
+        # the device's RNG positions become the process's -- unless the caller has drawn from / reseeded random or
+        # np.random since this object last synchronised them: then the caller's state stands (it is what the reference's
+        # next generator would read, video.py:178,265,291) and travels to the device with the next launch
+        if not self._global_rng_moved():
+            self._set_global_rng(st)
         self._out_of_work[False] = bool(st.out_of_work[0])  # video.py:189
         self._out_of_work[True] = bool(st.out_of_work[1])
         self._host_current = True

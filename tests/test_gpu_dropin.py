@@ -294,3 +294,81 @@ def test_reseeding_between_generators_is_carried_to_the_device(O, oracle_tables)
             want.append(ov.next(n))
     assert (np.array(got, dtype=np.uint8) == np.concatenate(want)).all()
     assert (v.update_priority == ov.update_priority(0)).all() and (v.aux_update_priority == ov.update_priority(1)).all()
+
+
+@pytest.mark.parametrize("mode,seed", [(1, 1), (1, 2), (0, 3), (0, 4), (1, 5), (0, 6), (1, 7), (0, 8)])
+def test_video_random_interleavings(O, oracle_tables, mode, seed):
+    """What a caller of the reference's Video may do between and inside generators, in random order and with random
+    Video.SPECULATE: start a generator, pull a few or many opcodes, abandon it, look at a state attribute in the middle
+    (which must be exactly the state of the opcodes consumed), draw from or reseed the global generators between two
+    generators, reset out_of_work as movie.py:96 does.  Every opcode, every observed array and the final global RNG
+    positions equal the oracle driven the same way."""
+    import ctypes as C
+    import palette
+    import screen
+    import video
+    import video_mode
+    from test_gpu_encode import _synth
+    rng = np.random.default_rng(1000 + seed)
+    frames = _synth(mode, 4, 4242 + seed, coherent=True)
+    random.seed(seed)
+    np.random.seed(seed + 50)
+    v = video.Video(_FG(), ticks_per_second=14700., mode=video_mode.VideoMode.DHGR if mode else video_mode.VideoMode.HGR,
+                    palette=palette.Palette.NTSC)
+    ov = O.Video(mode, oracle_tables.get(mode, 5), seed_py=seed, seed_np=seed + 50)
+    L = O.lib()
+    with contextlib.redirect_stdout(io.StringIO()):
+        for step in range(40):
+            v.SPECULATE = int(rng.choice([0, 1, 7, 64, 256, 256]))
+            # between generators: sometimes draw, sometimes reseed, sometimes reset the flags
+            act = rng.random()
+            if act < 0.15:
+                assert random.getrandbits(8) == L.orc_py_getrandbits8(C.byref(ov.rng_py()))
+            elif act < 0.3:
+                assert int(np.random.randint(0, 256)) == L.orc_np_randint256(C.byref(ov.rng_np()))
+            elif act < 0.4:
+                s1, s2 = int(rng.integers(1 << 16)), int(rng.integers(1 << 16))
+                random.seed(s1)
+                np.random.seed(s2)
+                L.orc_mt_seed_py(L.orc_video_rng_py(ov._h), s1)
+                L.orc_mt_seed_np(L.orc_video_rng_np(ov._h), s2)
+            elif act < 0.5:
+                v.out_of_work = {True: False, False: False}
+                ov.reset_out_of_work()
+            fi, ia = int(rng.integers(0, 4)), bool(rng.integers(0, 2)) if mode else False
+            k = int(rng.choice([0, 1, 2, 5, 40, 183, 292, 490, 900]))
+            if mode:
+                tgt = screen.DHGRBitmap(main_memory=screen.MemoryMap(1, frames[fi, 0].copy()),
+                                        aux_memory=screen.MemoryMap(1, frames[fi, 1].copy()), palette=palette.Palette.NTSC)
+            else:
+                tgt = screen.HGRBitmap(main_memory=screen.MemoryMap(1, frames[fi, 0].copy()), palette=palette.Palette.NTSC)
+            promised = bool(k and rng.random() < 0.2)    # encode_frame(budget=k): k opcodes WILL be pulled, one launch makes them
+            gen = v.encode_frame(tgt, is_aux=ia, **({"budget": k} if promised else {}))
+            ov.encode_frame(frames[fi, 0], frames[fi, 1] if mode else None, int(ia))
+            # (no look at the state inside a promised budget: the promise is what allows the state to run ahead)
+            peek_at = int(rng.integers(0, k)) if k and not promised and rng.random() < 0.35 else -1
+            got = []
+            for j in range(k):
+                page, content, offsets = next(gen)
+                got.append([page, content] + list(offsets))
+                if j == peek_at:   # a look at the state in the middle of a generator: exactly j + 1 opcodes in
+                    want = ov.next(j + 1)
+                    assert (np.array(got, np.uint8) == want).all(), (step, "ops before the peek")
+                    up = v.aux_update_priority if ia else v.update_priority
+                    assert (up == ov.update_priority(int(ia))).all(), (step, "priorities at the peek")
+                    mm = v.aux_memory_map if ia else v.memory_map
+                    assert (mm.page_offset == ov.memory(int(ia))).all(), (step, "memory map at the peek")
+                    got = []
+            rest = k - (peek_at + 1 if peek_at >= 0 else 0)
+            if rest:
+                assert (np.array(got, np.uint8) == ov.next(rest)).all(), (step, fi, ia, k)
+            gen = None    # (abandoned: movie.py:94-101 rebinds op_seq)
+            if rng.random() < 0.2:
+                assert v.out_of_work[ia] == ov.out_of_work(int(ia)), step
+    assert (v.update_priority == ov.update_priority(0)).all() and (v.memory_map.page_offset == ov.memory(0)).all()
+    if mode:
+        assert (v.aux_update_priority == ov.update_priority(1)).all() and (v.aux_memory_map.page_offset == ov.memory(1)).all()
+    assert (v.pixelmap.packed == ov.packed).all()
+    rp, rn = ov.rng_py(), ov.rng_np()
+    assert [random.getrandbits(8) for _ in range(4)] == [L.orc_py_getrandbits8(C.byref(rp)) for _ in range(4)]
+    assert np.random.randint(0, 256, size=4).tolist() == [L.orc_np_randint256(C.byref(rn)) for _ in range(4)]

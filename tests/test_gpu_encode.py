@@ -278,3 +278,29 @@ def test_per_stream_schedules(native, O, oracle_tables, device_tables, mode, wav
     with pytest.raises(native.IIVError):
         enc.encode(fm, fa, [(0, 0, 1, 5)])                   # the streams no longer share a schedule
     enc.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("kernel", ["team", True, False])
+def test_generator_advanced_a_few_opcodes_per_launch(native, O, oracle_tables, device_tables, mode, kernel):
+    """What video.Video does without a budget: hundreds of launches of one, two or three opcodes continuing the same
+    generator (state, bitmaps, MT19937 block and window position saved and restored every time) equal one run of the oracle."""
+    import torch
+    t, s = device_tables.get(mode, 5)
+    frames = _synth(mode, 2, 4246, coherent=True)
+    fm = torch.from_numpy(frames[None, :, 0].copy()).cuda()
+    fa = torch.from_numpy(frames[None, :, 1].copy()).cuda() if mode == 1 else None
+    n = 420
+    for chunk in (1, 2, 3):
+        enc = native.Encoder(mode, t, s, 1, dm=device_tables.dm[(mode, 5)])
+        enc.set_greedy_kernel(kernel)
+        py, npw = _seed_states(O, 11, 12)
+        enc.set_state(native.STATE_RNG_PY, py)
+        enc.set_state(native.STATE_RNG_NP, npw)
+        v = O.Video(mode, oracle_tables.get(mode, 5), seed_py=11, seed_np=12)
+        v.encode_frame(frames[0, 0], frames[0, 1] if mode else None, 0)
+        exp = v.next(n)
+        got = np.concatenate([enc.encode(fm, fa, [(0, 0, 1 if i == 0 else 0, chunk)]).cpu().numpy()[0] for i in range(0, n, chunk)])
+        enc.check()
+        assert (got[:n] == exp).all(), (mode, kernel, chunk)
+        enc.close()
