@@ -173,3 +173,64 @@ def test_movie_clock_split_calls_equal_one_call(dhgr, every_n):
         c = stream_batch.MovieClock(False, every_n_video_frames=2)
         a, b = c.segments(3), c.segments(3)
         assert a[-1] == (2, 0, 1, 490) and b[0] == (2, 0, 0, 490)
+
+
+def _movie_tick_by_tick(dhgr, ticks_per_second, frame_rate, every_n, n_frames, n_audio):
+    """movie.Movie.encode + emit_stream (movie.py:56-150) and video.Video.tick (video.py:64-70) walked one audio sample
+    at a time, as the reference does: the (target frame, bank, opcodes pulled) of every generator that yielded something."""
+    ticks = frame_number = 0
+    tpf = float(ticks_per_second) / float(frame_rate)
+    stream_pos, aux, last_bank = 7, False, False
+    target, gens = None, []
+    for _ in range(n_audio):
+        ticks += 1
+        if ticks >= tpf * frame_number:                       # Video.tick
+            frame_number += 1
+            if frame_number - 1 >= n_frames:                  # next(video_frames) raises StopIteration (movie.py:71-74)
+                break
+            if (frame_number - 1) % every_n == 0:             # movie.py:76-80
+                target = frame_number - 1
+                gens.append([target, int(aux), 0])            # movie.py:94
+        if aux != last_bank:                                  # movie.py:98-102
+            last_bank = aux
+            gens.append([target, int(aux), 0])
+        gens[-1][2] += 1                                      # next(op_seq), movie.py:109
+        stream_pos += 7                                       # emit_stream, movie.py:113-150
+        if stream_pos % 2048 >= 2044:
+            if dhgr:
+                aux = not aux
+            stream_pos += 4
+    return [tuple(g) for g in gens if g[2] > 0]
+
+
+def test_movie_clock_against_a_tick_by_tick_walk():
+    """MovieClock jumps from event to event (new frame, end of a 2 KiB socket frame, end of the call); the reference walks
+    every audio sample.  Random sample rates, frame rates, every_n, clip lengths and audio lengths, the clip cut into
+    random calls (by frames and by ticks): the generators are the same."""
+    rng = np.random.default_rng(2027)
+    for trial in range(300):
+        dhgr = bool(rng.integers(0, 2))
+        tps = float(rng.choice([14340.0, 14700.0, 11025.0, 22050.0, 7350.0, 14699.5]))
+        fps = float(rng.choice([30.0, 29.97, 24.0, 25.0, 15.0, 60.0, 23.976, 12.5]))
+        every_n = int(rng.choice([1, 1, 2, 3]))
+        n_frames = int(rng.integers(1, 40))
+        n_audio = int(rng.integers(1, int(n_frames * tps / fps * 1.3) + 2))
+        want = _movie_tick_by_tick(dhgr, tps, fps, every_n, n_frames, n_audio)
+        clock = stream_batch.MovieClock(dhgr, ticks_per_second=tps, input_frame_rate=fps, every_n_video_frames=every_n)
+        whole = stream_batch.merge_generators(clock.segments(n_frames, max_ticks=n_audio))
+        assert whole == want, (trial, dhgr, tps, fps, every_n, n_frames, n_audio)
+        # the same clip in random slices
+        clock = stream_batch.MovieClock(dhgr, ticks_per_second=tps, input_frame_rate=fps, every_n_video_frames=every_n)
+        parts, left_ticks = [], n_audio
+        while clock.frame_number < n_frames + 1 and left_ticks > 0:
+            by_frames = rng.random() < 0.5
+            nf = int(rng.integers(1, 6)) if by_frames else n_frames - clock.frame_number
+            mt = left_ticks if by_frames else min(left_ticks, int(rng.integers(1, 3000)))
+            nf = min(nf, n_frames - clock.frame_number)
+            before = clock.ticks
+            part = clock.segments(nf, max_ticks=mt)
+            left_ticks -= clock.ticks - before
+            parts += part
+            if clock.ticks == before:     # nothing left to do: the clip has ended
+                break
+        assert stream_batch.merge_generators(parts) == want, (trial, "sliced", dhgr, tps, fps, every_n, n_frames, n_audio)
