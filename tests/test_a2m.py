@@ -110,3 +110,27 @@ def test_encode_then_emit_end_to_end(native, O, oracle_tables, device_tables, go
         want = O.emit_stream(1, np.concatenate(exp), np.full(n, 34, np.uint8), addr.tick, addr.ack, addr.terminate)
         assert np.array_equal(stream[i], want)
     b.close()
+
+
+@pytest.mark.gpu
+def test_emit_kernel_random_sizes_and_cuts(native, O, golden):
+    """Random opcode counts around the 2 KiB socket-frame boundaries, random ticks, random max_bytes_out cuts
+    (movie.py:132-134), several streams at once, both modes: the kernel's bytes equal the oracle's restatement of
+    Movie.emit_stream (which test_oracle_emit_stream_matches_reference pins to the reference's own output)."""
+    import torch
+    import a2m
+    g = golden.g6_a2m
+    addr = a2m.OpcodeAddresses(g["tick_addr"], g["special_addr"][0], g["special_addr"][1], g["special_addr"][2])
+    rng = np.random.default_rng(77)
+    for trial in range(60):
+        mode = int(rng.integers(0, 2))
+        n = int(rng.choice([0, 1, 2, 290, 291, 292, 293, 582, 583, 584, int(rng.integers(1, 4000))]))
+        S = int(rng.integers(1, 5))
+        ops = rng.integers(0, 256, (S, n, 6), dtype=np.uint8)
+        ops[:, :, 0] = rng.integers(32, 64, (S, n))
+        ticks = (rng.integers(2, 34, (S, n)) * 2).astype(np.uint8)
+        mx = None if rng.random() < 0.5 else int(rng.choice([1, 7, 8, 14, 2043, 2044, 2048, 2049, int(rng.integers(1, 7 * n + 64))]))
+        got = a2m.emit_stream(mode, torch.from_numpy(ops).cuda(), torch.from_numpy(ticks).cuda(), addr, mx).cpu().numpy()
+        for s in range(S):
+            want = O.emit_stream(mode, ops[s], ticks[s], g["tick_addr"], addr.ack, addr.terminate, mx)
+            assert got.shape[1] == len(want) and (got[s] == want).all(), (trial, mode, n, S, mx, s)
