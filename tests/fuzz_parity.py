@@ -38,14 +38,17 @@ for rnd in range(rounds):
         fm, fa = stream_batch.synth_frames_torch(n, nf, mode == 1, seed=int(rng.integers(1 << 30)),
                                                  coherent=kind != "iid", device="cpu", keep=0.98 if kind == "static" else 0.9)
     # schedule: (frame, is_aux, restart, n_ops) with ragged lengths, continued generators, zero-length creations
-    sched, f, ia = [], 0, 0
-    for _ in range(int(rng.integers(4, 10))):
-        k = int(rng.choice([0, 1, 2, 63, 64, 65, 127, 200, 292, 490, 700, 1500]))
-        restart = 1 if not sched or rng.random() < 0.7 else 0
-        if restart:
-            f = int(rng.integers(0, nf))
-            ia = int(rng.integers(0, 2)) if mode == 1 else 0
-        sched.append((f, ia, restart, k))
+    def random_schedule(lo=4, hi=10):
+        sched, f, ia = [], 0, 0
+        for _ in range(int(rng.integers(lo, hi))):
+            k = int(rng.choice([0, 1, 2, 63, 64, 65, 127, 200, 292, 490, 700, 1500]))
+            restart = 1 if not sched or rng.random() < 0.7 else 0
+            if restart:
+                f = int(rng.integers(0, nf))
+                ia = int(rng.integers(0, 2)) if mode == 1 else 0
+            sched.append((f, ia, restart, k))
+        return sched
+    sched = random_schedule()
     # one round in seven: a marathon -- one generator pulled far past its sorted list, through the re-queued bag and
     # (usually) out of work, then another one on top of what it left
     marathon = bool(rng.random() < 1 / 7)
@@ -73,14 +76,25 @@ for rnd in range(rounds):
     for i, (sp, sn) in enumerate(seeds):
         enc.set_state(native.STATE_RNG_PY, O.mt_seed_py(sp).state_words(), i)
         enc.set_state(native.STATE_RNG_NP, O.mt_seed_np(sn).state_words(), i)
-    got = enc.encode(fm.cuda(), fa.cuda() if fa is not None else None, sched).cpu().numpy()
+    # one round in four (of the short ones): every stream its own schedule (iiv_encode_streams: streams on different banks
+    # in the same launch round, streams that idle while others still work, a stream with nothing to do at all)
+    per_stream = bool(not marathon and not joint and rng.random() < 0.25)
+    if per_stream:
+        scheds = [random_schedule(1, 8) if i else [] for i in range(n)]
+        scheds[int(rng.integers(1, n))] = sched
+        ops_all, totals = enc.encode_streams(fm.cuda(), fa.cuda() if fa is not None else None, scheds)
+        ops_all = ops_all.cpu().numpy()
+        got = [ops_all[i, :totals[i]] for i in range(n)]
+    else:
+        scheds = [sched] * n
+        got = enc.encode(fm.cuda(), fa.cuda() if fa is not None else None, sched).cpu().numpy()
     enc.check()
     for i in range(n):
         v = O.Video(mode, otab[key], seed_py=seeds[i][0], seed_np=seeds[i][1])
         v.set_joint(joint)
         v.set_fourth_offset(fourth)
         exp = []
-        for (fr, a, restart, k) in sched:
+        for (fr, a, restart, k) in scheds[i]:
             if restart:
                 v.encode_frame(fm[i, fr].numpy(), fa[i, fr].numpy() if fa is not None else None, a)
             if k:
@@ -96,5 +110,5 @@ for rnd in range(rounds):
         total_ops += exp.shape[0]
     enc.close()
     print("round %2d ok: mode=%s pal=%d %s wave=%s rec=%s prefix=%d joint=%d fourth=%d%s segs=%s" % (
-        rnd, "DHGR" if mode else "HGR", pal, kind, wave, recurrence, prefix, joint, fourth, " marathon" if marathon else "", [s[3] for s in sched]), flush=True)
+        rnd, "DHGR" if mode else "HGR", pal, kind, wave, recurrence, prefix, joint, fourth, " marathon" if marathon else " per-stream schedules" if per_stream else "", [s[3] for s in sched]), flush=True)
 print("fuzz parity: %d rounds, %d opcodes compared, all equal (%.0f s)" % (rounds, total_ops, time.time() - t_start))
