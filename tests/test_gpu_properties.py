@@ -178,3 +178,34 @@ def test_full_size_batch_properties(native, O, oracle_tables, device_tables):
     for i in (0, 1500, 4095):
         v, exp = _oracle(O, oracle_tables, 1, np.stack([tm[i], ta[i]], axis=1), segs, seeds[i])
         assert np.array_equal(ops[i], exp), i
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_kernel_forms_agree_at_batch_sizes(native, O, oracle_tables, device_tables, mode):
+    """The kernel forms against each other at the sizes they are dispatched for, on picture-like input (ties on nearly
+    every step): 600 clips through the eight-wave kernel and 4608 clips through the LDS-shared form (persistent
+    workgroups taking streams off a queue, a partly filled last workgroup) both equal the plain one-wave kernel, opcode for
+    opcode and in the final state; three sampled clips equal the oracle."""
+    import stream_batch
+    F = 3
+    t, s = device_tables.get(mode)
+    for S, other in ((600, "team"), (4608 + 5, "shared")):
+        fm, fa = stream_batch.synth_frames_img(S, F, mode == 1, seed=900 + S)
+        seeds = [(i + 1, i + 7) for i in range(S)]
+        res = {}
+        for kern in ("plain", other):
+            b = stream_batch.StreamBatch(mode, t, s, S, seeds=seeds, dm=device_tables.dm[(mode, 5)])
+            b.enc.set_greedy_kernel(kern)
+            ops, segs = b.encode_frames(fm, fa, F)
+            b.enc.check()
+            up = np.stack([b.enc.get_state(native.STATE_UP_MAIN, i) for i in range(0, S, 151)])
+            res[kern] = (ops.cpu().numpy(), up)
+            b.close()
+        assert np.array_equal(res["plain"][0], res[other][0]), (S, other)
+        assert np.array_equal(res["plain"][1], res[other][1]), (S, other)
+        tm = fm.cpu().numpy()
+        ta = fa.cpu().numpy() if fa is not None else None
+        for i in (0, S // 2, S - 1):
+            fr = np.stack([tm[i], ta[i] if ta is not None else np.zeros_like(tm[i])], axis=1)
+            v, exp = _oracle(O, oracle_tables, mode, fr, segs, seeds[i])
+            assert np.array_equal(res[other][0][i], exp), (S, other, i)
