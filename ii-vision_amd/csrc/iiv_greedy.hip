@@ -42,6 +42,9 @@ namespace iiv {
 #ifndef IIV_WAVE_OCC
 #define IIV_WAVE_OCC 6     // waves per SIMD the register allocation is held to
 #endif
+#ifndef IIV_STEP_PRIO
+#define IIV_STEP_PRIO 1    // s_setprio of a wave while it scores and applies an entry (0 elsewhere)
+#endif
 
 // W = streams (waves) per workgroup.  W == 1: every table load goes to the L1/TA (both modes).
 // W > 1 (DHGR): the workgroup's streams all work on the same bank and share that bank's whole L1 half
@@ -657,7 +660,13 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
 #ifdef IIV_STAMPS
             n_steps++;
 #endif
+            // A wave that has its table words scores and applies at raised priority: its step is a chain of dependent
+            // reductions and scalar bookkeeping, and every cycle it waits for an issue slot behind waves that are only
+            // issuing loads is a cycle its own next loads start later (+1 % DHGR, +1.2 % HGR; raising the load issue
+            // instead costs HGR 5 %).
+            __builtin_amdgcn_s_setprio(IIV_STEP_PRIO);
             (void)step(std::false_type{}, eA, cur);
+            __builtin_amdgcn_s_setprio(0);
             IIV_PHASE(2);   // wait for the table words, score, apply
             head = hA;
             eA = eB;
