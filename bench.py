@@ -198,6 +198,11 @@ class GpuBackend:
     def profile_read(self):
         return self.batch.enc.profile_read()
 
+    def input_stats(self):
+        """(share of the steps the nonces decided, form of the one-wave kernel the encoder has settled on) -- the encoder
+        picks the form by what its kernels report about the input (include/iivision.h: iiv_encoder_input_stats)"""
+        return self.batch.enc.input_stats()
+
     def uses_wave_kernel(self):
         return self.args.greedy != "workgroup" and not self.args.joint
 
@@ -276,6 +281,8 @@ def main(argv=None, backend_cls=GpuBackend):
                             "; FOURTH offset per opcode (f4, not the reference's output)" if args.fourth else ""),
             "palette": args.palette,
             "streams_per_gpu": S,
+            **({"greedy_form": be.input_stats()[1], "nonce_decided_share_of_steps": round(be.input_stats()[0], 4)}
+               if hasattr(be, "input_stats") and be.uses_wave_kernel() else {}),
             "frames_per_step": F,
             "opcodes_per_frame": OPS_PER_FRAME,
             "parallelism": "%d GPU x %d independent streams, no collective" % (n_gpus, S),

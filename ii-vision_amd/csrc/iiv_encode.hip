@@ -30,6 +30,14 @@
 namespace iiv {
 
 constexpr int kSharedHgrMinStreams = 4096;   // 16 streams per workgroup x 256 CUs
+constexpr int kSharedDhgrMinStreams = 2048;  // (at 1024 clips the LDS-shared form is 3 % behind the plain one)
+// The LDS-shared form of the one-wave kernel keeps 16 waves per CU busy, the plain form 28.  On input whose steps are
+// rarely decided by the nonces the shared form wins (DHGR +1-7 %, HGR +3-12 %); on picture-like input, where nearly every
+// step takes the exact-nonce path with its extra wave reductions and LDS reads, 16 waves hide that latency worse than 28
+// and it loses 5 %.  Both forms produce the same bytes, so the encoder picks by what its own kernels saw: they count the
+// steps the nonces decided and the opcodes emitted, the counters come back with an asynchronous copy (never waited for:
+// a call uses what an earlier call's copy has delivered), and a batch above this share runs the plain form.
+constexpr unsigned kTieHeavyPercent = 30;
 constexpr int kTeamMaxStreams = 768;   // IIV_GREEDY_AUTO: at most this many streams run the team kernel
 
 
@@ -71,6 +79,12 @@ struct Encoder {
     LaunchSeg *d_segs;
     int *d_queue;           // one stream counter per launch round of a call (persistent greedy workgroups), zeroed per call
     size_t queue_cap;
+    // what the one-wave kernels saw (kTieHeavyPercent): device counters, their pinned host copy, the event behind the copy
+    unsigned long long *d_tie_stats, *h_tie_stats, tie_seen[2];
+    hipEvent_t tie_ev;
+    bool tie_copy_pending;
+    int tie_heavy;          // -1: not known yet, 0 / 1
+    double tie_rate;        // of the latest interval looked at
     size_t d_cap;
     // scratch for encoder_check / IIV_STATE_PACKED
     int *d_result;
@@ -146,6 +160,9 @@ void encoder_destroy(Encoder *e)
     }
     if (e->d_segs) (void)hipFree(e->d_segs);
     if (e->d_queue) (void)hipFree(e->d_queue);
+    if (e->d_tie_stats) (void)hipFree(e->d_tie_stats);
+    if (e->h_tie_stats) (void)hipHostFree(e->h_tie_stats);
+    if (e->tie_ev) (void)hipEventDestroy(e->tie_ev);
     if (e->d_result) (void)hipFree(e->d_result);
     if (e->d_packed) (void)hipFree(e->d_packed);
     if (e->d_states) (void)hipFree(e->d_states);
@@ -213,6 +230,12 @@ int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, c
     e->d_segs = nullptr;
     e->d_queue = nullptr;
     e->queue_cap = 0;
+    e->d_tie_stats = e->h_tie_stats = nullptr;
+    e->tie_seen[0] = e->tie_seen[1] = 0;
+    e->tie_ev = nullptr;
+    e->tie_copy_pending = false;
+    e->tie_heavy = -1;
+    e->tie_rate = 0.0;
     e->d_cap = 0;
     e->d_result = nullptr;
     e->d_packed = nullptr;
@@ -227,6 +250,11 @@ int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, c
         if ((rc = hip_check(hipMalloc(&e->d_packed, 4096 * 8), "hipMalloc(packed)"))) break;
         if ((rc = hip_check(hipEventCreateWithFlags(&e->seg_ev[0], hipEventDisableTiming), "event"))) break;
         if ((rc = hip_check(hipEventCreateWithFlags(&e->seg_ev[1], hipEventDisableTiming), "event"))) break;
+        if ((rc = hip_check(hipMalloc(&e->d_tie_stats, 2 * sizeof(unsigned long long)), "hipMalloc(tie statistics)"))) break;
+        if ((rc = hip_check(hipMemset(e->d_tie_stats, 0, 2 * sizeof(unsigned long long)), "memset"))) break;
+        if ((rc = hip_check(hipHostMalloc(&e->h_tie_stats, 2 * sizeof(unsigned long long)), "hipHostMalloc(tie statistics)"))) break;
+        e->h_tie_stats[0] = e->h_tie_stats[1] = 0;
+        if ((rc = hip_check(hipEventCreateWithFlags(&e->tie_ev, hipEventDisableTiming), "event"))) break;
         // the table values must fit the 11-bit fields too (a caller-made table may not come from dm)
         uint32_t h_max = 0;
         if ((rc = hip_check(hipMemset(e->d_result, 0, 8), "memset"))) break;
@@ -564,6 +592,23 @@ int encoder_profile(Encoder *e, int enable)
     return IIV_OK;
 }
 
+// the form of the one-wave kernel the next launch of a full batch runs (launch_round)
+static bool shared_form_now(const Encoder *e)
+{
+    return e->greedy_mode == IIV_GREEDY_WAVE_SHARED ||
+           (e->greedy_mode != IIV_GREEDY_WAVE_PLAIN &&
+            e->n_streams >= (e->mode == kHGR ? kSharedHgrMinStreams : kSharedDhgrMinStreams) &&
+            (e->tie_heavy < 0 ? e->mode == kHGR : e->tie_heavy == 0));
+}
+
+int encoder_input_stats(Encoder *e, double *tie_share, int *form)
+{
+    if (!e) return set_error(IIV_ERR_INVALID, "input_stats: null encoder");
+    if (tie_share) *tie_share = e->tie_rate;
+    if (form) *form = shared_form_now(e) && !e->fourth_offset ? IIV_GREEDY_WAVE_SHARED : IIV_GREEDY_WAVE_PLAIN;
+    return IIV_OK;
+}
+
 int encoder_profile_read(Encoder *e, double ms[2], int64_t launches[2])
 {
     if (!e) return set_error(IIV_ERR_INVALID, "profile_read: null encoder");
@@ -675,6 +720,29 @@ static int reset_queues(Encoder *e, size_t n_rounds, hipStream_t st)
     return IIV_OK;
 }
 
+// tie statistics (kTieHeavyPercent): take in what an earlier call's copy has delivered, if it has
+static void tie_stats_poll(Encoder *e)
+{
+    if (!e->tie_copy_pending || hipEventQuery(e->tie_ev) != hipSuccess) return;
+    e->tie_copy_pending = false;
+    const unsigned long long ties = e->h_tie_stats[0] - e->tie_seen[0], ops = e->h_tie_stats[1] - e->tie_seen[1];
+    if (ops < 32ull * (unsigned long long)e->n_streams) return;   // (too little to judge by: keep counting)
+    e->tie_seen[0] = e->h_tie_stats[0];
+    e->tie_seen[1] = e->h_tie_stats[1];
+    e->tie_rate = (double)ties / (double)ops;
+    e->tie_heavy = ties * 100ull > (unsigned long long)kTieHeavyPercent * ops ? 1 : 0;
+}
+
+// ... and ask for the counters as this call leaves them (asynchronous; one copy in flight at a time)
+static int tie_stats_request(Encoder *e, hipStream_t st)
+{
+    if (!e->d_tie_stats || e->tie_copy_pending) return IIV_OK;
+    IIV_HIP(hipMemcpyAsync(e->h_tie_stats, e->d_tie_stats, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    IIV_HIP(hipEventRecord(e->tie_ev, st));
+    e->tie_copy_pending = true;
+    return IIV_OK;
+}
+
 // launch round r: descriptors at d + r * round_stride, stream i reads entry i * seg_stride
 static int launch_round(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux, int n_frames, const LaunchSeg *d_round,
                         int seg_stride, bool any_prologue, bool any_greedy, int uniform_bank, int *d_queue, uint8_t *d_ops,
@@ -706,11 +774,11 @@ static int launch_round(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux,
         GreedyArgs a{e->d_states, d_main, d_aux, n_frames, e->n_streams, d_round, seg_stride, e->d_left, e->d_right, e->nt, d_ops,
                      ops_stride, e->greedy_lds_pad,
                      e->greedy_mode == IIV_GREEDY_WAVE_PLAIN ? -1 : uniform_bank,
-                     // the LDS-shared form: on request, and by default where it is the faster one -- HGR (its step is bound by its
-                     // table loads: +5.5 % at 14336 clips) once there is a full workgroup of sixteen streams for every CU
-                     e->greedy_mode == IIV_GREEDY_WAVE_SHARED ||
-                         (e->mode == kHGR && e->greedy_mode != IIV_GREEDY_WAVE_PLAIN && e->n_streams >= kSharedHgrMinStreams),
-                     d_queue, e->fourth_offset != 0};
+                     // the LDS-shared form: on request; otherwise for batches that fill the GPU with its workgroups, unless the
+                     // kernels have reported input on which the plain form is the faster one (kTieHeavyPercent; until they
+                     // have reported: HGR shared, DHGR plain -- the better guess for each)
+                     shared_form_now(e),
+                     d_queue, e->fourth_offset != 0, e->d_tie_stats};
         int rc = use_team ? launch_greedy_team(e->mode, a, st) : launch_greedy_wave(e->mode, a, st);
         if (rc) return rc;
     } else {
@@ -742,11 +810,12 @@ int encode(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux, int n_frames
     if (rounds.empty()) return IIV_OK;
     if ((rc = upload_segs(e, rounds, st))) return rc;
     if ((rc = reset_queues(e, rounds.size(), st))) return rc;
+    tie_stats_poll(e);
     for (size_t r = 0; r < rounds.size(); r++)
         if ((rc = launch_round(e, d_main, d_aux, n_frames, e->d_segs + r, 0, rounds[r].need >= 0, true, rounds[r].is_aux, e->d_queue + r, d_ops,
                                total * 6, st)))
             return rc;
-    return IIV_OK;
+    return tie_stats_request(e, st);
 }
 
 // stream s runs segs[seg_begin[s] .. seg_begin[s + 1])
@@ -787,12 +856,13 @@ int encode_streams(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux, int 
     int rc = upload_segs(e, table, st);
     if (rc) return rc;
     if ((rc = reset_queues(e, n_rounds, st))) return rc;
+    tie_stats_poll(e);
     for (size_t r = 0; r < n_rounds; r++)
         if ((rc = launch_round(e, d_main, d_aux, n_frames, e->d_segs + r * (size_t)S, 1, any_pro[r] != 0, true, bank[r] < 0 ? -1 : bank[r],
                                e->d_queue + r, d_ops,
                                ops_stride, st)))
             return rc;
-    return IIV_OK;
+    return tie_stats_request(e, st);
 }
 
 __global__ void error_scan_kernel(const StreamState *states, int n, int *result)
@@ -953,6 +1023,12 @@ int iiv_encoder_profile_read(iiv_encoder *enc, double ms[2], int64_t launches[2]
 {
     if (!enc) return iiv::set_error(IIV_ERR_INVALID, "null encoder");
     return iiv::encoder_profile_read(enc->impl, ms, launches);
+}
+
+int iiv_encoder_input_stats(iiv_encoder *enc, double *tie_share, int *form)
+{
+    if (!enc) return iiv::set_error(IIV_ERR_INVALID, "null encoder");
+    return iiv::encoder_input_stats(enc->impl, tie_share, form);
 }
 
 int iiv_check_split_diff_table(int mode, const int32_t dm[256], const uint16_t *d_table, unsigned long long *mismatches,

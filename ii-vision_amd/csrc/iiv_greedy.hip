@@ -95,7 +95,8 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
                                                                    const uint8_t *__restrict__ frames_aux, int n_frames,
                                                                    const LaunchSeg *__restrict__ segs, int seg_stride,
                                                                    const NarrowTables nt,
-                                                                   uint8_t *__restrict__ ops_out, size_t ops_stride, int n_streams, int bank, int *__restrict__ queue)
+                                                                   uint8_t *__restrict__ ops_out, size_t ops_stride, int n_streams, int bank, int *__restrict__ queue,
+                                                                   unsigned long long *__restrict__ tie_stats)
 {
     using T = SplitTraits<MODE>;
     constexpr uint32_t INF = 0xffffffffu;
@@ -328,6 +329,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
     int n_ties = 0, n_tie_members = 0, n_ties_small = 0;
 #endif
     bool prev_tie = false;        // the previous step's two winners shared their delta: expect the same of this one
+    int n_exact = 0;              // steps of this launch that took the exact-nonce path (tie_stats: what the host picks the kernel form by)
     uint32_t pkey_v = 0;          // lanes 1, 2 (FOUR: and 3): the keys pushed by the latest step (track only)
     int push_f1 = 0, push_f2 = 0, push_f3 = 0, push_base = 0;
     auto apply = [&](auto track, int p, int x, uint32_t c, int y1, uint32_t nd1, int y2, uint32_t nd2, int y3, uint32_t nd3, int C) {
@@ -502,6 +504,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
             // materialised: one random.getrandbits(8) per candidate in ascending offset
             // (video.py:290-293)
             twist_now();
+            n_exact++;
             // (on picture-like input this is the normal path: 96 % of the opcodes of S-img tie, with 11 bytes sharing the
             // smallest delta; on random input 2.5 %)
             constexpr int kNone = 0x7fffffff;   // the keys below are < 2^28: signed minima order them
@@ -794,6 +797,10 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
         S.ops += (unsigned long long)done;
         S.pad_ops += pad_ops;
         if (err && S.error == 0) S.error = err;
+        if (tie_stats) {   // (two atomics per stream and launch)
+            atomicAdd(&tie_stats[0], (unsigned long long)n_exact);
+            atomicAdd(&tie_stats[1], (unsigned long long)(done - (int)pad_ops));
+        }
 #ifdef IIV_STAMPS
         for (int i = 0; i < 4; i++) S.stamps[16 + i] = ph[i];
         S.stamps[24] = wave_t0;
@@ -846,7 +853,7 @@ template <int MODE> static int launch_shared(const GreedyArgs &a, hipStream_t st
     }
     const int wgs = (a.n_streams + SC::kW - 1) / SC::kW;
     hipLaunchKernelGGL((greedy_wave_kernel<MODE, SC::kW>), dim3(wgs < resident ? wgs : resident), dim3(64 * SC::kW), (size_t)SC::kLds, st, a.states,
-                       a.frames_main, a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, a.queue);
+                       a.frames_main, a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, a.queue, a.tie_stats);
     return IIV_OK;
 }
 
@@ -857,18 +864,18 @@ int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st)
     int rc = IIV_OK;
     if (a.fourth && mode == kDHGR)   // (f4: a real fourth offset per opcode -- the plain one-wave form only)
         hipLaunchKernelGGL((greedy_wave_kernel<kDHGR, 1, true>), dim3(a.n_streams), dim3(64), (size_t)a.lds_pad, st, a.states, a.frames_main,
-                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, (int *)nullptr);
+                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, (int *)nullptr, a.tie_stats);
     else if (a.fourth)
         hipLaunchKernelGGL((greedy_wave_kernel<kHGR, 1, true>), dim3(a.n_streams), dim3(64), (size_t)a.lds_pad, st, a.states, a.frames_main,
-                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, (int *)nullptr);
+                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, (int *)nullptr, a.tie_stats);
     else if (shared)
         rc = mode == kDHGR ? launch_shared<kDHGR>(a, st) : launch_shared<kHGR>(a, st);
     else if (mode == kDHGR)
         hipLaunchKernelGGL((greedy_wave_kernel<kDHGR, 1>), dim3(a.n_streams), dim3(64), (size_t)a.lds_pad, st, a.states, a.frames_main,
-                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, (int *)nullptr);
+                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, (int *)nullptr, a.tie_stats);
     else
         hipLaunchKernelGGL((greedy_wave_kernel<kHGR, 1>), dim3(a.n_streams), dim3(64), (size_t)a.lds_pad, st, a.states, a.frames_main,
-                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, (int *)nullptr);
+                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, (int *)nullptr, a.tie_stats);
     if (rc) return rc;
     return hip_check(hipGetLastError(), "greedy_wave_kernel launch");
 }

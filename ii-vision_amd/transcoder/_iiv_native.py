@@ -42,7 +42,7 @@ SYMBOLS = [
     "iiv_encoder_set_state_range", "iiv_encoder_get_video_state", "iiv_encoder_set_video_state",
     "iiv_encoder_get_video_brief",
     "iiv_encode", "iiv_encode_streams",
-    "iiv_encoder_check", "iiv_encoder_profile", "iiv_encoder_profile_read",
+    "iiv_encoder_check", "iiv_encoder_profile", "iiv_encoder_profile_read", "iiv_encoder_input_stats",
     "iiv_build_split_store_table", "iiv_split_table_entries", "iiv_check_split_diff_table",
     "iiv_build_narrow_store_table",
     "iiv_emit_stream", "iiv_emit_chunk", "iiv_frames_to_memory_maps",
@@ -139,6 +139,7 @@ def lib():
     L.iiv_encoder_check.argtypes = [vp, C.POINTER(i32), vp]
     L.iiv_encoder_profile.argtypes = [vp, i32]
     L.iiv_encoder_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.iiv_encoder_input_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.iiv_emit_stream.argtypes = [i32, i32, C.c_long, vp, vp, vp, C.c_uint16, C.c_uint16, C.c_long, vp, sz,
                                   C.POINTER(sz), vp]
     L.iiv_emit_chunk.argtypes = [i32, i32, C.c_long, C.c_long, vp, sz, vp, sz, i32, vp, C.c_uint16, vp, sz,
@@ -517,6 +518,13 @@ class Encoder:
         n = (C.c_int64 * 2)()
         check(lib().iiv_encoder_profile_read(self._h, ms, n))
         return {"prologue_ms": ms[0], "greedy_ms": ms[1], "prologue_launches": n[0], "greedy_launches": n[1]}
+
+    def input_stats(self):
+        """(share of the steps the nonces decided, as the kernels reported it for an earlier call; the form of the one-wave
+        kernel the next full-batch launch runs: "shared" / "plain") -- include/iivision.h: iiv_encoder_input_stats"""
+        share, form = C.c_double(0.0), C.c_int(0)
+        check(lib().iiv_encoder_input_stats(self._h, C.byref(share), C.byref(form)))
+        return share.value, "shared" if form.value == GREEDY_WAVE_SHARED else "plain"
 
 
 # ---- f2: byte emission -------------------------------------------------------------

@@ -329,6 +329,16 @@ int iiv_encoder_check(iiv_encoder *enc, int *bad_stream, void *stream);
 int iiv_encoder_profile(iiv_encoder *enc, int enable);
 int iiv_encoder_profile_read(iiv_encoder *enc, double ms[2], int64_t launches[2]);
 
+/* What the encoder's kernels have reported about the input so far, and which form of the one-wave greedy kernel
+ * the next call will run because of it.  (Diagnostic; nothing in the output depends on it.)  The one-wave kernel
+ * counts the steps whose extra offsets the nonces decided (video.py:290-301: candidates sharing a delta) and the
+ * opcodes it emitted; the counters reach the host by an asynchronous copy that is never waited for, so the figures
+ * are those of an earlier call.  *tie_share = that share over the latest interval looked at (0 before any);
+ * *form = IIV_GREEDY_WAVE_SHARED or IIV_GREEDY_WAVE_PLAIN: batches that fill the GPU run the LDS-shared form unless
+ * the share is above 30 % (picture-like input), where the plain form's 28 waves per CU hide the exact-nonce path's
+ * latency better than the shared form's 16 (IIV_OPT_GREEDY_KERNEL = WAVE_SHARED / WAVE_PLAIN overrule it). */
+int iiv_encoder_input_stats(iiv_encoder *enc, double *tie_share, int *form);
+
 /* ==== f2: byte emission of the opcode stream (".a2m") ====================== */
 
 /* movie.Movie.emit_stream + done (transcoder/movie.py:113-161) with

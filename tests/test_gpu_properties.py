@@ -209,3 +209,33 @@ def test_kernel_forms_agree_at_batch_sizes(native, O, oracle_tables, device_tabl
             fr = np.stack([tm[i], ta[i] if ta is not None else np.zeros_like(tm[i])], axis=1)
             v, exp = _oracle(O, oracle_tables, mode, fr, segs, seeds[i])
             assert np.array_equal(res[other][0][i], exp), (S, other, i)
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_encoder_picks_the_kernel_form_by_what_its_kernels_report(native, device_tables, mode):
+    """A batch that fills the GPU runs the LDS-shared form of the one-wave kernel unless the kernels report input whose
+    steps are mostly decided by the nonces (picture-like: ~96 %), where the plain form is the faster one.  The report
+    travels by an asynchronous copy, so the choice follows a call or two behind; the bytes are the same either way
+    (test_kernel_forms_agree_at_batch_sizes), only the rate differs."""
+    import torch
+    import stream_batch
+    S, F = 4608, 4
+    t, s = device_tables.get(mode)
+    for kind, want_form, lo, hi in (("iid", "shared", 0.0, 0.15), ("img", "plain", 0.6, 1.0)):
+        fm, fa = (stream_batch.synth_frames_img(S, F, mode == 1, seed=5) if kind == "img" else
+                  stream_batch.synth_frames_torch(S, F, mode == 1, seed=5))
+        b = stream_batch.StreamBatch(mode, t, s, S, seeds=[(i + 1, i + 1) for i in range(S)], dm=device_tables.dm[(mode, 5)])
+        assert b.enc.input_stats()[0] == 0.0                    # nothing reported yet
+        for f in range(F):
+            b.encode_frames(fm, fa, 1)
+            torch.cuda.synchronize()                            # (lets the copy behind each call land before the next looks)
+        b.enc.check()
+        share, form = b.enc.input_stats()
+        assert lo <= share <= hi, (kind, share)
+        assert form == want_form, (kind, share, form)
+        # an explicit choice overrules the report
+        b.enc.set_greedy_kernel("plain")
+        assert b.enc.input_stats()[1] == "plain"
+        b.enc.set_greedy_kernel("shared")
+        assert b.enc.input_stats()[1] == "shared"
+        b.close()
