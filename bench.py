@@ -281,7 +281,8 @@ def main(argv=None, backend_cls=GpuBackend):
                             "; FOURTH offset per opcode (f4, not the reference's output)" if args.fourth else ""),
             "palette": args.palette,
             "streams_per_gpu": S,
-            **({"greedy_form": be.input_stats()[1], "nonce_decided_share_of_steps": round(be.input_stats()[0], 4)}
+            **({"greedy_form": be.input_stats()[1], "nonce_decided_share_of_steps": round(be.input_stats()[0], 4),
+                "real_opcodes_per_stream_and_launch": round(be.batch.enc.real_opcodes_per_launch, 1)}
                if hasattr(be, "input_stats") and be.uses_wave_kernel() else {}),
             "frames_per_step": F,
             "opcodes_per_frame": OPS_PER_FRAME,
@@ -430,7 +431,8 @@ def _roofline_objects(be, args, prof, op_count, seg_count, S, elapsed, live_ceil
         # kernel's access pattern (a streamed 1 KiB row + 8 divergent table loads per opcode, narrow
         # form: 2-byte slices + 1 lane in 64 into the dense table) with no arithmetic at all.
         loads = float(op_count) * S * 512 / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
-        hgr_shared = args.mode == "HGR" and S >= 4096 and args.greedy in ("auto", "wave", "shared")
+        form = be.input_stats()[1] if hasattr(be, "input_stats") else "plain"   # what the encoder settled on for this input
+        hgr_shared = args.mode == "HGR" and form == "shared"
         peak, src = _gather_ceiling_live(S, args.mode, hgr_shared) if live_ceiling else (None, None)
         if peak is None and args.mode == "HGR":
             peak, src = GATHER_CEILING_GLOADS_HGR, "tools/gather_ceiling D 14336 HGR, a run on an MI355X committed as a constant, not this run"
@@ -440,7 +442,12 @@ def _roofline_objects(be, args, prof, op_count, seg_count, S, elapsed, live_ceil
         out["roofline_access_pattern"] = {
             "kernel": "greedy_wave_kernel", "bound": "l1 divergent loads",
             "achieved": loads, "peak": peak, "unit": "G table loads/s", "frac": loads / peak, "peak_source": src,
+            "kernel_form": form,
         }
+        if form == "shared" and args.mode != "HGR":
+            out["roofline_access_pattern"]["note"] = ("the kernel ran its LDS-shared form (four of the eight table loads per opcode come from "
+                                                      "LDS); the ceiling quoted is that of the plain form's pattern (variant D: all eight from "
+                                                      "the L1), measured in this run -- variant E's is ~25 % higher (profiles/r03_gather_ceiling.txt)")
     pro_bytes = float(seg_count) * S * BYTES_PER_PROLOGUE
     out["roofline_prologue"] = {
         "kernel": "prologue_kernel",

@@ -38,6 +38,10 @@ constexpr int kSharedDhgrMinStreams = 2048;  // (at 1024 clips the LDS-shared fo
 // steps the nonces decided and the opcodes emitted, the counters come back with an asynchronous copy (never waited for:
 // a call uses what an earlier call's copy has delivered), and a batch above this share runs the plain form.
 constexpr unsigned kTieHeavyPercent = 30;
+// ... and so does a batch whose streams have little left to do per launch (converging content that is mostly out of work:
+// a frame shown four times runs 5.7 M frames/s plain, 4.6 M shared -- the workgroups' table copy and stream queue are
+// overhead that a launch of a few dozen real opcodes per stream does not repay)
+constexpr unsigned kSharedMinOpsPerLaunch = 96;
 constexpr int kTeamMaxStreams = 768;   // IIV_GREEDY_AUTO: at most this many streams run the team kernel
 
 
@@ -80,11 +84,12 @@ struct Encoder {
     int *d_queue;           // one stream counter per launch round of a call (persistent greedy workgroups), zeroed per call
     size_t queue_cap;
     // what the one-wave kernels saw (kTieHeavyPercent): device counters, their pinned host copy, the event behind the copy
-    unsigned long long *d_tie_stats, *h_tie_stats, tie_seen[2];
+    unsigned long long *d_tie_stats, *h_tie_stats, tie_seen[3];
     hipEvent_t tie_ev;
     bool tie_copy_pending;
     int tie_heavy;          // -1: not known yet, 0 / 1
     double tie_rate;        // of the latest interval looked at
+    double ops_per_launch;  // real (not padding) opcodes per stream and launch, likewise
     size_t d_cap;
     // scratch for encoder_check / IIV_STATE_PACKED
     int *d_result;
@@ -231,7 +236,8 @@ int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, c
     e->d_queue = nullptr;
     e->queue_cap = 0;
     e->d_tie_stats = e->h_tie_stats = nullptr;
-    e->tie_seen[0] = e->tie_seen[1] = 0;
+    e->tie_seen[0] = e->tie_seen[1] = e->tie_seen[2] = 0;
+    e->ops_per_launch = 0.0;
     e->tie_ev = nullptr;
     e->tie_copy_pending = false;
     e->tie_heavy = -1;
@@ -250,10 +256,10 @@ int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, c
         if ((rc = hip_check(hipMalloc(&e->d_packed, 4096 * 8), "hipMalloc(packed)"))) break;
         if ((rc = hip_check(hipEventCreateWithFlags(&e->seg_ev[0], hipEventDisableTiming), "event"))) break;
         if ((rc = hip_check(hipEventCreateWithFlags(&e->seg_ev[1], hipEventDisableTiming), "event"))) break;
-        if ((rc = hip_check(hipMalloc(&e->d_tie_stats, 2 * sizeof(unsigned long long)), "hipMalloc(tie statistics)"))) break;
-        if ((rc = hip_check(hipMemset(e->d_tie_stats, 0, 2 * sizeof(unsigned long long)), "memset"))) break;
-        if ((rc = hip_check(hipHostMalloc(&e->h_tie_stats, 2 * sizeof(unsigned long long)), "hipHostMalloc(tie statistics)"))) break;
-        e->h_tie_stats[0] = e->h_tie_stats[1] = 0;
+        if ((rc = hip_check(hipMalloc(&e->d_tie_stats, 3 * sizeof(unsigned long long)), "hipMalloc(tie statistics)"))) break;
+        if ((rc = hip_check(hipMemset(e->d_tie_stats, 0, 3 * sizeof(unsigned long long)), "memset"))) break;
+        if ((rc = hip_check(hipHostMalloc(&e->h_tie_stats, 3 * sizeof(unsigned long long)), "hipHostMalloc(tie statistics)"))) break;
+        e->h_tie_stats[0] = e->h_tie_stats[1] = e->h_tie_stats[2] = 0;
         if ((rc = hip_check(hipEventCreateWithFlags(&e->tie_ev, hipEventDisableTiming), "event"))) break;
         // the table values must fit the 11-bit fields too (a caller-made table may not come from dm)
         uint32_t h_max = 0;
@@ -601,10 +607,13 @@ static bool shared_form_now(const Encoder *e)
             (e->tie_heavy < 0 ? e->mode == kHGR : e->tie_heavy == 0));
 }
 
-int encoder_input_stats(Encoder *e, double *tie_share, int *form)
+int encoder_input_stats(Encoder *e, double stats[2], int *form)
 {
     if (!e) return set_error(IIV_ERR_INVALID, "input_stats: null encoder");
-    if (tie_share) *tie_share = e->tie_rate;
+    if (stats) {
+        stats[0] = e->tie_rate;
+        stats[1] = e->ops_per_launch;
+    }
     if (form) *form = shared_form_now(e) && !e->fourth_offset ? IIV_GREEDY_WAVE_SHARED : IIV_GREEDY_WAVE_PLAIN;
     return IIV_OK;
 }
@@ -725,19 +734,21 @@ static void tie_stats_poll(Encoder *e)
 {
     if (!e->tie_copy_pending || hipEventQuery(e->tie_ev) != hipSuccess) return;
     e->tie_copy_pending = false;
-    const unsigned long long ties = e->h_tie_stats[0] - e->tie_seen[0], ops = e->h_tie_stats[1] - e->tie_seen[1];
-    if (ops < 32ull * (unsigned long long)e->n_streams) return;   // (too little to judge by: keep counting)
-    e->tie_seen[0] = e->h_tie_stats[0];
-    e->tie_seen[1] = e->h_tie_stats[1];
-    e->tie_rate = (double)ties / (double)ops;
-    e->tie_heavy = ties * 100ull > (unsigned long long)kTieHeavyPercent * ops ? 1 : 0;
+    const unsigned long long ties = e->h_tie_stats[0] - e->tie_seen[0], ops = e->h_tie_stats[1] - e->tie_seen[1],
+                             runs = e->h_tie_stats[2] - e->tie_seen[2];
+    if (runs < 2ull * (unsigned long long)e->n_streams) return;   // (too little to judge by: keep counting)
+    for (int k = 0; k < 3; k++) e->tie_seen[k] = e->h_tie_stats[k];
+    e->tie_rate = ops ? (double)ties / (double)ops : 0.0;
+    e->ops_per_launch = (double)ops / (double)runs;
+    // (`tie_heavy` = the plain form is the better one for this input)
+    e->tie_heavy = (ties * 100ull > (unsigned long long)kTieHeavyPercent * ops || ops < (unsigned long long)kSharedMinOpsPerLaunch * runs) ? 1 : 0;
 }
 
 // ... and ask for the counters as this call leaves them (asynchronous; one copy in flight at a time)
 static int tie_stats_request(Encoder *e, hipStream_t st)
 {
     if (!e->d_tie_stats || e->tie_copy_pending) return IIV_OK;
-    IIV_HIP(hipMemcpyAsync(e->h_tie_stats, e->d_tie_stats, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    IIV_HIP(hipMemcpyAsync(e->h_tie_stats, e->d_tie_stats, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     IIV_HIP(hipEventRecord(e->tie_ev, st));
     e->tie_copy_pending = true;
     return IIV_OK;
@@ -1025,10 +1036,10 @@ int iiv_encoder_profile_read(iiv_encoder *enc, double ms[2], int64_t launches[2]
     return iiv::encoder_profile_read(enc->impl, ms, launches);
 }
 
-int iiv_encoder_input_stats(iiv_encoder *enc, double *tie_share, int *form)
+int iiv_encoder_input_stats(iiv_encoder *enc, double stats[2], int *form)
 {
     if (!enc) return iiv::set_error(IIV_ERR_INVALID, "null encoder");
-    return iiv::encoder_input_stats(enc->impl, tie_share, form);
+    return iiv::encoder_input_stats(enc->impl, stats, form);
 }
 
 int iiv_check_split_diff_table(int mode, const int32_t dm[256], const uint16_t *d_table, unsigned long long *mismatches,

@@ -797,9 +797,10 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
         S.ops += (unsigned long long)done;
         S.pad_ops += pad_ops;
         if (err && S.error == 0) S.error = err;
-        if (tie_stats) {   // (two atomics per stream and launch)
+        if (tie_stats) {   // (three atomics per stream and launch)
             atomicAdd(&tie_stats[0], (unsigned long long)n_exact);
             atomicAdd(&tie_stats[1], (unsigned long long)(done - (int)pad_ops));
+            atomicAdd(&tie_stats[2], 1ull);
         }
 #ifdef IIV_STAMPS
         for (int i = 0; i < 4; i++) S.stamps[16 + i] = ph[i];

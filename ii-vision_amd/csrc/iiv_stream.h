@@ -280,7 +280,7 @@ struct GreedyArgs {
     bool shared;             // IIV_GREEDY_WAVE_SHARED: the LDS-shared form wherever it applies (DHGR, one bank per round)
     int *queue;              // device: this launch's stream counter, zero (the LDS-shared form's persistent workgroups)
     bool fourth;             // IIV_OPT_FOURTH_OFFSET: up to three extra offsets per opcode (the plain one-wave kernel only)
-    unsigned long long *tie_stats;   // device, or null: [0] += steps decided by the nonces, [1] += opcodes emitted (one-wave kernel)
+    unsigned long long *tie_stats;   // device, or null: [0] += steps decided by the nonces, [1] += opcodes emitted, [2] += 1 per stream and launch (one-wave kernel)
 };
 
 int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st);   // iiv_greedy.hip

@@ -522,9 +522,10 @@ class Encoder:
     def input_stats(self):
         """(share of the steps the nonces decided, as the kernels reported it for an earlier call; the form of the one-wave
         kernel the next full-batch launch runs: "shared" / "plain") -- include/iivision.h: iiv_encoder_input_stats"""
-        share, form = C.c_double(0.0), C.c_int(0)
-        check(lib().iiv_encoder_input_stats(self._h, C.byref(share), C.byref(form)))
-        return share.value, "shared" if form.value == GREEDY_WAVE_SHARED else "plain"
+        st, form = (C.c_double * 2)(), C.c_int(0)
+        check(lib().iiv_encoder_input_stats(self._h, st, C.byref(form)))
+        self.real_opcodes_per_launch = st[1]
+        return st[0], "shared" if form.value == GREEDY_WAVE_SHARED else "plain"
 
 
 # ---- f2: byte emission -------------------------------------------------------------

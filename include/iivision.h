@@ -333,11 +333,14 @@ int iiv_encoder_profile_read(iiv_encoder *enc, double ms[2], int64_t launches[2]
  * the next call will run because of it.  (Diagnostic; nothing in the output depends on it.)  The one-wave kernel
  * counts the steps whose extra offsets the nonces decided (video.py:290-301: candidates sharing a delta) and the
  * opcodes it emitted; the counters reach the host by an asynchronous copy that is never waited for, so the figures
- * are those of an earlier call.  *tie_share = that share over the latest interval looked at (0 before any);
+ * are those of an earlier call.  stats[0] = that share over the latest interval looked at, stats[1] = real (not padding)
+ * opcodes per stream and launch over the same interval (both 0 before any report);
  * *form = IIV_GREEDY_WAVE_SHARED or IIV_GREEDY_WAVE_PLAIN: batches that fill the GPU run the LDS-shared form unless
- * the share is above 30 % (picture-like input), where the plain form's 28 waves per CU hide the exact-nonce path's
- * latency better than the shared form's 16 (IIV_OPT_GREEDY_KERNEL = WAVE_SHARED / WAVE_PLAIN overrule it). */
-int iiv_encoder_input_stats(iiv_encoder *enc, double *tie_share, int *form);
+ * the share is above 30 % (picture-like input: the plain form's 28 waves per CU hide the exact-nonce path's latency
+ * better than the shared form's 16) or the streams emit fewer than 96 real opcodes per launch (converging content that is
+ * mostly out of work: the shared form's per-workgroup table copy is not repaid).  IIV_OPT_GREEDY_KERNEL = WAVE_SHARED /
+ * WAVE_PLAIN overrule it. */
+int iiv_encoder_input_stats(iiv_encoder *enc, double stats[2], int *form);
 
 /* ==== f2: byte emission of the opcode stream (".a2m") ====================== */
 
