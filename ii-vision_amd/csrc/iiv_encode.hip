@@ -729,11 +729,36 @@ static int reset_queues(Encoder *e, size_t n_rounds, hipStream_t st)
     return IIV_OK;
 }
 
+// the streams' stat_* totals summed (one small launch per iiv_encode call, in front of the copy)
+__global__ void tie_stats_kernel(const StreamState *states, int n, unsigned long long *out)
+{
+    unsigned long long a = 0, b = 0, c = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        a += states[i].stat_exact;
+        b += states[i].stat_ops;
+        c += states[i].stat_runs;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        a += __shfl_xor(a, d, 64);
+        b += __shfl_xor(b, d, 64);
+        c += __shfl_xor(c, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out[0], a);
+        atomicAdd(&out[1], b);
+        atomicAdd(&out[2], c);
+    }
+}
+
 // tie statistics (kTieHeavyPercent): take in what an earlier call's copy has delivered, if it has
 static void tie_stats_poll(Encoder *e)
 {
     if (!e->tie_copy_pending || hipEventQuery(e->tie_ev) != hipSuccess) return;
     e->tie_copy_pending = false;
+    if (e->h_tie_stats[2] < e->tie_seen[2] || e->h_tie_stats[1] < e->tie_seen[1] || e->h_tie_stats[0] < e->tie_seen[0]) {
+        for (int k = 0; k < 3; k++) e->tie_seen[k] = e->h_tie_stats[k];   // (a rollback took the streams' totals back)
+        return;
+    }
     const unsigned long long ties = e->h_tie_stats[0] - e->tie_seen[0], ops = e->h_tie_stats[1] - e->tie_seen[1],
                              runs = e->h_tie_stats[2] - e->tie_seen[2];
     if (runs < 2ull * (unsigned long long)e->n_streams) return;   // (too little to judge by: keep counting)
@@ -748,6 +773,10 @@ static void tie_stats_poll(Encoder *e)
 static int tie_stats_request(Encoder *e, hipStream_t st)
 {
     if (!e->d_tie_stats || e->tie_copy_pending) return IIV_OK;
+    IIV_HIP(hipMemsetAsync(e->d_tie_stats, 0, 3 * sizeof(unsigned long long), st));
+    const int blocks = e->n_streams < 64 * 256 ? (e->n_streams + 255) / 256 : 64;
+    hipLaunchKernelGGL(tie_stats_kernel, dim3(blocks), dim3(256), 0, st, e->d_states, e->n_streams, e->d_tie_stats);
+    IIV_HIP(hipGetLastError());
     IIV_HIP(hipMemcpyAsync(e->h_tie_stats, e->d_tie_stats, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     IIV_HIP(hipEventRecord(e->tie_ev, st));
     e->tie_copy_pending = true;
@@ -789,7 +818,7 @@ static int launch_round(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux,
                      // kernels have reported input on which the plain form is the faster one (kTieHeavyPercent; until they
                      // have reported: HGR shared, DHGR plain -- the better guess for each)
                      shared_form_now(e),
-                     d_queue, e->fourth_offset != 0, e->d_tie_stats};
+                     d_queue, e->fourth_offset != 0, e->d_tie_stats != nullptr};
         int rc = use_team ? launch_greedy_team(e->mode, a, st) : launch_greedy_wave(e->mode, a, st);
         if (rc) return rc;
     } else {

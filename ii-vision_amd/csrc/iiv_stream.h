@@ -48,6 +48,9 @@ struct StreamState {
     int32_t pad_content;      // target[0,0] of the live generator's bank (video.py:249)
     int32_t truncated;        // order[] holds only the top of the list (prefix sort)
     unsigned long long draws_py, draws_np, ops, pad_ops;
+    // what the one-wave kernel saw of the input (iiv_encode.hip: kTieHeavyPercent), totals since creation: steps the nonces
+    // decided, real (not padding) opcodes, launches that emitted something
+    unsigned long long stat_exact, stat_ops, stat_runs;
     unsigned long long stamps[32];  // diagnostic builds only (-DIIV_STAMPS): prologue s_memtime stamps [0,16), greedy phase cycles [16,24)
 };
 
@@ -280,7 +283,7 @@ struct GreedyArgs {
     bool shared;             // IIV_GREEDY_WAVE_SHARED: the LDS-shared form wherever it applies (DHGR, one bank per round)
     int *queue;              // device: this launch's stream counter, zero (the LDS-shared form's persistent workgroups)
     bool fourth;             // IIV_OPT_FOURTH_OFFSET: up to three extra offsets per opcode (the plain one-wave kernel only)
-    unsigned long long *tie_stats;   // device, or null: [0] += steps decided by the nonces, [1] += opcodes emitted, [2] += 1 per stream and launch (one-wave kernel)
+    bool count_stats;        // the one-wave kernel adds to the streams' stat_* fields
 };
 
 int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st);   // iiv_greedy.hip
