@@ -87,7 +87,17 @@ for rnd in range(rounds):
         got = [ops_all[i, :totals[i]] for i in range(n)]
     else:
         scheds = [sched] * n
+        # one round in five: the call is made, rolled back to a snapshot (iiv_encoder_snapshot / _rollback: what the drop-in
+        # Video's speculation rests on) and made again -- state, generators and both RNG streams must be back where they were
+        replay = bool(rng.random() < 0.2)
+        if replay:
+            enc.snapshot()
+            first = enc.encode(fm.cuda(), fa.cuda() if fa is not None else None, sched).cpu().numpy()
+            enc.check()
+            enc.rollback()
         got = enc.encode(fm.cuda(), fa.cuda() if fa is not None else None, sched).cpu().numpy()
+        if replay:
+            assert (first == got).all(), ("replay after rollback", rnd)
     enc.check()
     for i in range(n):
         v = O.Video(mode, otab[key], seed_py=seeds[i][0], seed_np=seeds[i][1])

@@ -296,8 +296,9 @@ def test_reseeding_between_generators_is_carried_to_the_device(O, oracle_tables)
     assert (v.update_priority == ov.update_priority(0)).all() and (v.aux_update_priority == ov.update_priority(1)).all()
 
 
-@pytest.mark.parametrize("mode,seed", [(1, 1), (1, 2), (0, 3), (0, 4), (1, 5), (0, 6), (1, 7), (0, 8)])
-def test_video_random_interleavings(O, oracle_tables, mode, seed):
+@pytest.mark.parametrize("mode,seed,fourth", [(1, 1, False), (1, 2, False), (0, 3, False), (0, 4, False), (1, 5, False), (0, 6, False),
+                                              (1, 7, True), (0, 8, True)])
+def test_video_random_interleavings(O, oracle_tables, mode, seed, fourth):
     """What a caller of the reference's Video may do between and inside generators, in random order and with random
     Video.SPECULATE: start a generator, pull a few or many opcodes, abandon it, look at a state attribute in the middle
     (which must be exactly the state of the opcodes consumed), draw from or reseed the global generators between two
@@ -314,8 +315,9 @@ def test_video_random_interleavings(O, oracle_tables, mode, seed):
     random.seed(seed)
     np.random.seed(seed + 50)
     v = video.Video(_FG(), ticks_per_second=14700., mode=video_mode.VideoMode.DHGR if mode else video_mode.VideoMode.HGR,
-                    palette=palette.Palette.NTSC)
+                    palette=palette.Palette.NTSC, fourth_offset=fourth)
     ov = O.Video(mode, oracle_tables.get(mode, 5), seed_py=seed, seed_np=seed + 50)
+    ov.set_fourth_offset(fourth)
     L = O.lib()
     with contextlib.redirect_stdout(io.StringIO()):
         for step in range(40):
