@@ -184,3 +184,32 @@ def test_frame_grabber_feeds_the_encoder(native, O, oracle_tables, device_tables
     b.close()
     with pytest.raises(ValueError):
         frame_grabber.ArrayFrameGrabber(np.zeros((2, 192, 140, 3), np.uint8), video_mode.VideoMode.HGR)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 0])
+def test_ingest_kernel_on_noise_and_extremes(native, O, mode):
+    """Uniform noise, saturated primaries, black, white, a one-pixel checkerboard and steep ramps -- the inputs that push
+    the error-diffusion accumulators and the dither offsets to their clamps -- through every dither kind and both
+    palettes: kernel = definition, byte for byte."""
+    import torch
+    rng = np.random.default_rng(12)
+    y, x = np.mgrid[0:192, 0:280]
+    frames = [rng.integers(0, 256, (192, 280, 3), dtype=np.uint8), np.zeros((192, 280, 3), np.uint8),
+              np.full((192, 280, 3), 255, np.uint8)]
+    for c in ((255, 0, 0), (0, 255, 0), (0, 0, 255), (255, 255, 0)):
+        frames.append(np.broadcast_to(np.array(c, np.uint8), (192, 280, 3)).copy())
+    frames.append((((x + y) & 1) * 255).astype(np.uint8)[..., None].repeat(3, axis=2))
+    frames.append(np.stack([(x * 255 // 279), (y * 255 // 191), ((x * 7 + y * 13) % 256)], axis=2).astype(np.uint8))
+    frames.append(np.where(rng.random((192, 280, 1)) < 0.5, 0, 255).astype(np.uint8).repeat(3, axis=2))
+    rgb = np.ascontiguousarray(np.stack(frames))
+    for pal_id in (5, 0):
+        for dither in (0, 1, 17, 128, 255, native.DITHER_DIFFUSION):
+            main, aux = native.frames_to_memory_maps(mode, O.PALETTE_RGB[pal_id], torch.from_numpy(rgb).cuda(), dither)
+            main = main.cpu().numpy()
+            aux = aux.cpu().numpy() if aux is not None else None
+            for f in range(len(rgb)):
+                em, ea = O.frame_to_memory_map(mode, O.PALETTE_RGB[pal_id], rgb[f], dither)
+                assert (main[f] == em).all(), (mode, pal_id, dither, f)
+                if mode == 1:
+                    assert (aux[f] == ea).all(), (mode, pal_id, dither, f)
