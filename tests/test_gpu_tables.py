@@ -254,3 +254,55 @@ def test_verify_pins_a_users_tables_on_arrival(native, O, dms, tmp_path, capsys)
     assert residual == 0
     known = implied >= 0
     assert known.sum() >= 200 and (implied[known] == np.maximum(dms[0], dms[0].T)[known]).all()
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_arbitrary_diff_matrices(native, O, mode, seed):
+    """Nothing in the table scheme may lean on the two shipped palettes: random symmetric integer diff matrices (a
+    user's own palette, make_data_tables.py:55-87) -- small values, large values up to the key fields' limit, many equal
+    entries, zeros off the diagonal (the NTSC palette has a pair of identical greys) -- go through the device's table
+    build, the split and narrow store tables (exact for every entry, re-read with the kernels' own arithmetic), the
+    split diff-weight table, and a short encode in every kernel form against the oracle built from the same matrix."""
+    import torch
+    from test_gpu_encode import _seed_states, _synth
+    rng = np.random.default_rng(500 + seed)
+    hi = (110, 12, 60)[seed - 1]
+    dm = rng.integers(0, hi, (16, 16), dtype=np.int32)
+    if seed == 3:
+        # NOT symmetric: make_data_tables.py:81-87 writes (c, d) and (d, c) on every iteration of its double loop, so the
+        # lower triangle of the matrix it was given wins (SURVEY A.3); both table builders must do the same
+        np.fill_diagonal(dm, 0)
+    else:
+        dm = np.triu(dm, 1)
+        dm = dm + dm.T                               # symmetric, zero diagonal
+    dm[3, 9] = dm[9, 3] = 0                          # two "identical" colours
+    dm = np.ascontiguousarray(dm.reshape(256).astype(np.int32))
+    otab = O.build_table(mode, dm, symmetric=True)
+    table = native.build_table(mode, dm, True)
+    assert bool((table.cpu().numpy() == otab).all())
+    dense = native.build_store_table(mode, dm)
+    exp, n_exc = native.build_narrow_store_table(mode, dm, dense)
+    assert bool((exp == dense).all())
+    assert native.check_split_diff_table(mode, dm, table) == 0
+    frames = _synth(mode, 2, 77 + seed, coherent=True)
+    fm = torch.from_numpy(frames[None, :, 0].copy()).cuda()
+    fa = torch.from_numpy(frames[None, :, 1].copy()).cuda() if mode == 1 else None
+    sched = [(0, 0, 300), (1, 1 if mode else 0, 250), (1, 0, 2200)]
+    v = O.Video(mode, otab, seed_py=5, seed_np=6)
+    exp_ops = []
+    for (f, ia, k) in sched:
+        v.encode_frame(frames[f, 0], frames[f, 1] if mode else None, ia)
+        exp_ops.append(v.next(k))
+    exp_ops = np.concatenate(exp_ops)
+    for kern, rec in (("team", True), (True, "split"), ("shared", False), (False, True)):
+        enc = native.Encoder(mode, table, dense, 1, dm=dm)
+        enc.set_greedy_kernel(kern)
+        enc.set_diff_weights_mode(rec)
+        py, npw = _seed_states(O, 5, 6)
+        enc.set_state(native.STATE_RNG_PY, py)
+        enc.set_state(native.STATE_RNG_NP, npw)
+        got = enc.encode(fm, fa, [(f, ia, 1, k) for (f, ia, k) in sched]).cpu().numpy()[0]
+        enc.check()
+        assert (got == exp_ops).all(), (mode, seed, kern, rec)
+        enc.close()
