@@ -297,8 +297,8 @@ def test_reseeding_between_generators_is_carried_to_the_device(O, oracle_tables)
 
 
 @pytest.mark.parametrize("mode,seed,fourth", [(1, 1, False), (1, 2, False), (0, 3, False), (0, 4, False), (1, 5, False), (0, 6, False),
-                                              (1, 7, True), (0, 8, True)])
-def test_video_random_interleavings(O, oracle_tables, mode, seed, fourth):
+                                              (1, 7, True), (0, 8, True), (1, 9, "strict"), (0, 10, "strict")])
+def test_video_random_interleavings(O, oracle_tables, mode, seed, fourth, monkeypatch):
     """What a caller of the reference's Video may do between and inside generators, in random order and with random
     Video.SPECULATE: start a generator, pull a few or many opcodes, abandon it, look at a state attribute in the middle
     (which must be exactly the state of the opcodes consumed), draw from or reseed the global generators between two
@@ -314,6 +314,9 @@ def test_video_random_interleavings(O, oracle_tables, mode, seed, fourth):
     frames = _synth(mode, 4, 4242 + seed, coherent=True)
     random.seed(seed)
     np.random.seed(seed + 50)
+    if fourth == "strict":      # Video.STRICT_SYNC: the literal behaviour, every next() a full state round trip
+        monkeypatch.setattr(video.Video, "STRICT_SYNC", True)
+        fourth = False
     v = video.Video(_FG(), ticks_per_second=14700., mode=video_mode.VideoMode.DHGR if mode else video_mode.VideoMode.HGR,
                     palette=palette.Palette.NTSC, fourth_offset=fourth)
     ov = O.Video(mode, oracle_tables.get(mode, 5), seed_py=seed, seed_np=seed + 50)
@@ -339,6 +342,8 @@ def test_video_random_interleavings(O, oracle_tables, mode, seed, fourth):
                 ov.reset_out_of_work()
             fi, ia = int(rng.integers(0, 4)), bool(rng.integers(0, 2)) if mode else False
             k = int(rng.choice([0, 1, 2, 5, 40, 183, 292, 490, 900]))
+            if video.Video.STRICT_SYNC:
+                k = min(k, 60)
             if mode:
                 tgt = screen.DHGRBitmap(main_memory=screen.MemoryMap(1, frames[fi, 0].copy()),
                                         aux_memory=screen.MemoryMap(1, frames[fi, 1].copy()), palette=palette.Palette.NTSC)
