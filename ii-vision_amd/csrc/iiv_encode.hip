@@ -614,7 +614,7 @@ int encoder_input_stats(Encoder *e, double stats[2], int *form)
         stats[0] = e->tie_rate;
         stats[1] = e->ops_per_launch;
     }
-    if (form) *form = shared_form_now(e) && !e->fourth_offset ? IIV_GREEDY_WAVE_SHARED : IIV_GREEDY_WAVE_PLAIN;
+    if (form) *form = shared_form_now(e) ? IIV_GREEDY_WAVE_SHARED : IIV_GREEDY_WAVE_PLAIN;
     return IIV_OK;
 }
 

@@ -88,7 +88,7 @@ __device__ static inline WaveLds *own_wave_lds()
 // FOUR (f4, IIV_OPT_FOURTH_OFFSET; NOT the reference's behaviour): up to three extra offsets per opcode instead of two
 // and a copy of the first -- the reference's exit test `len(offsets) == 3` (video.py:180-181) read as the 4 that
 // video.py:146 announces; defined by oracle/iiv_oracle.c: orc_video_set_fourth_offset, pinned against the reference
-// run with that literal changed (tests/golden/g8_fourth_offset.npz).  W == 1 only.
+// run with that literal changed (tests/golden/g8_fourth_offset.npz).
 template <int MODE, int W, bool FOUR = false>
 __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W + 3) / 4 : (2 * W + 3) / 4 + (W % 4 ? 1 : 0)) void greedy_wave_kernel(StreamState *__restrict__ states,
                                                                    const uint8_t *__restrict__ frames_main,
@@ -837,23 +837,23 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
 #undef IIV_PHASE
 
 // the LDS-shared form: persistent workgroups -- as many as are resident at once -- whose waves take streams off a queue
-template <int MODE> static int launch_shared(const GreedyArgs &a, hipStream_t st)
+template <int MODE, bool FOUR> static int launch_shared(const GreedyArgs &a, hipStream_t st)
 {
     using SC = SharedCfg<MODE>;
     static int resident = 0;
     if (!resident) {
         int per_cu = 0, dev = 0;
         hipDeviceProp_t prop;
-        if (hip_check(hipFuncSetAttribute((const void *)greedy_wave_kernel<MODE, SC::kW>, hipFuncAttributeMaxDynamicSharedMemorySize, SC::kLds),
+        if (hip_check(hipFuncSetAttribute((const void *)greedy_wave_kernel<MODE, SC::kW, FOUR>, hipFuncAttributeMaxDynamicSharedMemorySize, SC::kLds),
                       "greedy_wave_kernel LDS attribute") ||
-            hip_check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)greedy_wave_kernel<MODE, SC::kW>, 64 * SC::kW, (size_t)SC::kLds),
+            hip_check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)greedy_wave_kernel<MODE, SC::kW, FOUR>, 64 * SC::kW, (size_t)SC::kLds),
                       "greedy_wave_kernel occupancy") ||
             hip_check(hipGetDevice(&dev), "hipGetDevice") || hip_check(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties"))
             return IIV_ERR_HIP;
         resident = (per_cu > 0 ? per_cu : 1) * prop.multiProcessorCount;
     }
     const int wgs = (a.n_streams + SC::kW - 1) / SC::kW;
-    hipLaunchKernelGGL((greedy_wave_kernel<MODE, SC::kW>), dim3(wgs < resident ? wgs : resident), dim3(64 * SC::kW), (size_t)SC::kLds, st, a.states,
+    hipLaunchKernelGGL((greedy_wave_kernel<MODE, SC::kW, FOUR>), dim3(wgs < resident ? wgs : resident), dim3(64 * SC::kW), (size_t)SC::kLds, st, a.states,
                        a.frames_main, a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, a.queue, a.count_stats ? 1 : 0);
     return IIV_OK;
 }
@@ -861,16 +861,18 @@ template <int MODE> static int launch_shared(const GreedyArgs &a, hipStream_t st
 int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st)
 {
     // (the shared form needs every stream of the round on one bank -- always so in HGR -- and the host's stream counter)
-    const bool shared = a.shared && a.uniform_bank >= 0 && a.queue && a.lds_pad == 0 && !a.fourth;
+    const bool shared = a.shared && a.uniform_bank >= 0 && a.queue && a.lds_pad == 0;
     int rc = IIV_OK;
-    if (a.fourth && mode == kDHGR)   // (f4: a real fourth offset per opcode -- the plain one-wave form only)
+    if (shared && a.fourth)
+        rc = mode == kDHGR ? launch_shared<kDHGR, true>(a, st) : launch_shared<kHGR, true>(a, st);
+    else if (a.fourth && mode == kDHGR)   // (f4: a real fourth offset per opcode -- the plain one-wave form only)
         hipLaunchKernelGGL((greedy_wave_kernel<kDHGR, 1, true>), dim3(a.n_streams), dim3(64), (size_t)a.lds_pad, st, a.states, a.frames_main,
                            a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, (int *)nullptr, a.count_stats ? 1 : 0);
     else if (a.fourth)
         hipLaunchKernelGGL((greedy_wave_kernel<kHGR, 1, true>), dim3(a.n_streams), dim3(64), (size_t)a.lds_pad, st, a.states, a.frames_main,
                            a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, (int *)nullptr, a.count_stats ? 1 : 0);
     else if (shared)
-        rc = mode == kDHGR ? launch_shared<kDHGR>(a, st) : launch_shared<kHGR>(a, st);
+        rc = mode == kDHGR ? launch_shared<kDHGR, false>(a, st) : launch_shared<kHGR, false>(a, st);
     else if (mode == kDHGR)
         hipLaunchKernelGGL((greedy_wave_kernel<kDHGR, 1>), dim3(a.n_streams), dim3(64), (size_t)a.lds_pad, st, a.states, a.frames_main,
                            a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, (int *)nullptr, a.count_stats ? 1 : 0);

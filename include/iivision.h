@@ -228,8 +228,8 @@ void iiv_encoder_destroy(iiv_encoder *enc);
                                   * nonce when the store leaves an error) -- a quarter of the stream's stores is no longer
                                   * spent on a byte that was just written.  Defined by oracle/iiv_oracle.c
                                   * (orc_video_set_fourth_offset), which is pinned against the reference run with that one
-                                  * literal changed (tests/golden/g8_fourth_offset.npz).  Runs in the one-wave greedy kernel and, for
-                                  * few streams, the eight-wave one (IIV_GREEDY_WORKGROUP / WAVE_SHARED fall back to the plain
+                                  * literal changed (tests/golden/g8_fourth_offset.npz).  Runs in the one-wave greedy kernel (both
+                                  * forms) and, for few streams, the eight-wave one (IIV_GREEDY_WORKGROUP falls back to the
                                   * one-wave kernel; needs dm at creation); not together with IIV_CONTENT_JOINT. */
 int iiv_encoder_set_option(iiv_encoder *enc, int option, int value);
 
