@@ -71,6 +71,18 @@ def max_over_ranks(elapsed, device, world, use_dist=None):
     return float(t.item())
 
 
+def all_ranks(elapsed, device, world, use_dist=None):
+    """Every rank's timed region (seconds), rank order -- reporting only, after the timed region."""
+    if not (world > 1 if use_dist is None else use_dist):
+        return [elapsed]
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,7 +124,86 @@ def parse_args(argv=None):
                     help="(default unless --no-extras) also time encode -> .a2m byte emission -> pinned host "
                          "memory, end to end; kept as a flag for older command lines")
     ap.add_argument("--no-emit", action="store_true", help="skip the end-to-end emission leg")
+    ap.add_argument("--backend", default=os.environ.get("IIV_BENCH_BACKEND", ""),
+                    help="tests only: 'module:Class' standing in for GpuBackend (tests/bench_standin.py runs main() "
+                         "without a device; the product path has no CPU fallback)")
     return ap.parse_args(argv)
+
+
+def _resolve_backend(spec):
+    """'module:Class' -> the class (tests/bench_standin.py); '' -> GpuBackend."""
+    if not spec:
+        return GpuBackend
+    import importlib
+    mod, _, name = spec.partition(":")
+    return getattr(importlib.import_module(mod), name)
+
+
+def visible_gpus():
+    """Devices this process could bind ranks to.  torch.cuda.device_count() does not initialise the HIP runtime on
+    this image (nothing here may: the launcher below starts children, and a process that has touched the GPU must
+    not)."""
+    import torch
+    return int(torch.cuda.device_count())
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with no launcher around it: start N ranks of this script, one per GPU.
+
+    The parent never touches a GPU (no HIP call, no libiivision.so): it picks a rendezvous port on 127.0.0.1, starts
+    N children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set -- exactly what
+    `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` would give them -- forwards rank 0's
+    single JSON line, and exits non-zero if any rank fails (the others are then terminated by pid)."""
+    import socket
+    import subprocess
+    n = int(args.gpus)
+    backend = _resolve_backend(args.backend)
+    if getattr(backend, "is_gpu", True):
+        have = visible_gpus()
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible to this process\n" % (n, have))
+            return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+    import tempfile
+    procs = []
+    with tempfile.TemporaryFile("w+") as out0:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), IIV_BENCH_LAUNCHED_BY="bench.py")
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen(cmd, env=env, stdout=out0 if r == 0 else subprocess.DEVNULL))
+        # wait for all of them; the first rank that fails ends the others (by pid: they would wait for it at the
+        # rendezvous or at the next barrier for ever)
+        rcs = [None] * n
+        while any(c is None for c in rcs):
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    rcs[r] = p.poll()
+            if any(c not in (None, 0) for c in rcs):
+                for r, p in enumerate(procs):
+                    if rcs[r] is None:
+                        p.terminate()
+                        try:
+                            rcs[r] = p.wait(timeout=30)
+                        except subprocess.TimeoutExpired:
+                            p.kill()
+                            rcs[r] = p.wait()
+                break
+            time.sleep(0.05)
+        out0.seek(0)
+        line = out0.read()
+    # rank 0's stdout: the JSON line goes to ours, anything else a library printed there (gloo's connection notice) to stderr
+    for l in (line or "").splitlines():
+        (sys.stdout if l.startswith('{"metric"') else sys.stderr).write(l + "\n")
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
+    if bad:
+        sys.stderr.write("bench.py: ranks failed (rank, exit code): %s\n" % bad)
+        return 1
+    return 0
 
 
 class GpuBackend:
@@ -207,14 +298,26 @@ class GpuBackend:
         return self.args.greedy != "workgroup" and not self.args.joint
 
 
-def main(argv=None, backend_cls=GpuBackend):
+def main(argv=None, backend_cls=None):
     args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and backend_cls is None:
+        # no launcher around us: become one (before torch.distributed, libiivision.so or any HIP call)
+        rc = launch_ranks(args, argv)
+        if rc:
+            raise SystemExit(rc)
+        return None
+    if backend_cls is None:
+        backend_cls = _resolve_backend(args.backend)
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (the launcher's rank count and --gpus must agree)" % (args.gpus, world))
     be = backend_cls(args, local_rank, world)
+    if getattr(be, "is_gpu", True) and world > 1 and visible_gpus() <= local_rank:
+        raise SystemExit("bench.py: rank %d has no GPU %d (%d visible)" % (rank, local_rank, visible_gpus()))
     # the process group exists for N > 1 only; IIV_BENCH_FORCE_DIST=1 creates it for one rank too, so that
     # the RCCL initialisation, the barrier and the two scalar reductions can be exercised on a 1-GPU box
     # (python -m torch.distributed.run --nproc-per-node 1 ... bench.py)
@@ -253,6 +356,9 @@ def main(argv=None, backend_cls=GpuBackend):
 
     leg = timed_leg(be, args.steps, args.warmup, barrier)
     first_ops, op_count, seg_count, prof = leg["first_ops"], leg["op_count"], leg["seg_count"], leg["prof"]
+    rank_elapsed = all_ranks(leg["elapsed"], be.device, world, use_dist)   # (one float per rank: what the line's per-rank rates come from)
+    seed_lo = all_ranks(float(seeds[0][0]), be.device, world, use_dist)     # first / last stream seed of every rank: disjoint ranges
+    seed_hi = all_ranks(float(seeds[-1][0]), be.device, world, use_dist)
     elapsed = max_over_ranks(leg["elapsed"], be.device, world, use_dist)
 
     frames_done = args.steps * F * S * n_gpus
@@ -263,6 +369,12 @@ def main(argv=None, backend_cls=GpuBackend):
         "value": fps,
         "unit": "frames/s",
         "n_gpus": n_gpus,
+        "world_size": dist.get_world_size() if use_dist else 1,   # ranks the process group actually saw (1: no group)
+        "dist_backend": (dist.get_backend() if use_dist else None),
+        "launcher": os.environ.get("IIV_BENCH_LAUNCHED_BY") or ("torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "env" if world > 1 else None),
+        "per_rank_frames_per_s": {"min": args.steps * F * S / max(rank_elapsed), "max": args.steps * F * S / min(rank_elapsed),
+                                  "ranks": len(rank_elapsed)},
+        "per_rank_stream_seeds": [[int(a), int(b)] for a, b in zip(seed_lo, seed_hi)],
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1000.0 * elapsed / args.steps,

@@ -16,6 +16,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def _worker(rank, world, port, q):
@@ -55,59 +56,7 @@ def test_two_ranks_shard_streams_and_reduce_time():
     assert d0 != d1                               # different synthetic clips per rank
 
 
-class _CpuStandIn:
-    """bench.GpuBackend's interface without a device: records the calls of bench.main()."""
-
-    dist_backend = "gloo"
-    is_gpu = False
-
-    def __init__(self, args, local_rank, world):
-        import stream_batch
-        self.args = args
-        self.device = torch.device("cpu")
-        self.dhgr = args.mode == "DHGR"
-        self.clock = stream_batch.MovieClock(self.dhgr)
-        self.rank = int(os.environ["RANK"])
-        self.log = {"steps": 0, "checks": 0, "sync": 0}
-
-    def dist_kwargs(self):
-        return {}
-
-    def free_bytes(self):
-        # rank 1 pretends to have less free memory: the ranks must agree on the smaller clip count
-        return (240 << 30) if self.rank == 0 else (5 << 30)
-
-    def synchronize(self):
-        self.log["sync"] += 1
-
-    def build_tables(self):
-        return 0.0
-
-    def make_clips(self, S, n_frames, seed):
-        self.log["clips"] = (S, n_frames, seed)
-
-    def make_batch(self, S, seeds):
-        self.S = S
-        self.log["seeds"] = (seeds[0], seeds[-1], len(seeds))
-
-    def step(self):
-        self.log["steps"] += 1
-        return self.clock.segments(self.args.frames_per_step)
-
-    def first_ops(self, segs):
-        return torch.zeros((sum(s[3] for s in segs), 6), dtype=torch.uint8)
-
-    def check(self):
-        self.log["checks"] += 1
-
-    def profile(self, on):
-        pass
-
-    def profile_read(self):
-        return {"prologue_ms": 1.0, "greedy_ms": 2.0, "prologue_launches": 1, "greedy_launches": 1}
-
-    def uses_wave_kernel(self):
-        return True
+from bench_standin import CpuStandIn as _CpuStandIn  # noqa: E402
 
 
 def _bench_worker(rank, world, port, q, argv):
@@ -116,7 +65,7 @@ def _bench_worker(rank, world, port, q, argv):
     os.environ["RANK"] = str(rank)
     os.environ["LOCAL_RANK"] = str(rank)
     os.environ["WORLD_SIZE"] = str(world)
-    for p in (ROOT, os.path.join(ROOT, "ii-vision_amd", "transcoder")):
+    for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "ii-vision_amd", "transcoder")):
         sys.path.insert(0, p)
     import contextlib
     import io
@@ -152,3 +101,44 @@ def test_bench_main_runs_in_two_ranks():
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in d
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["roofline"]["bound"] == "hbm"
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2 ...` with NO launcher and NO rank environment: the script starts its two ranks itself
+    (bench.launch_ranks), each builds its own process group, and rank 0's one JSON line says what the group saw."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "tests"), os.path.join(ROOT, "ii-vision_amd", "transcoder"), env.get("PYTHONPATH", "")])
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames-per-step", "4",
+           "--backend", "bench_standin:CpuStandIn"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1                                   # exactly one line, rank 0's
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size"] == 2 and d["dist_backend"] == "gloo" and d["launcher"] == "bench.py"
+    assert d["per_rank_frames_per_s"]["ranks"] == 2
+    (a0, a1), (b0, b1) = d["per_rank_stream_seeds"]
+    assert a1 < b0 or b1 < a0                                # disjoint seed ranges => independent streams
+    assert "2 GPU" in d["config"]["parallelism"] and d["scaling"] == "weak"
+    # --gpus 1: no ranks started, no process group, the line as before
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "0", "--frames-per-step", "4",
+                         "--backend", "bench_standin:CpuStandIn", "--streams", "8"], env=dict(env, RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    d1 = json.loads(r1.stdout.strip().splitlines()[-1])
+    assert d1["n_gpus"] == 1 and d1["world_size"] == 1 and d1["dist_backend"] is None and d1["launcher"] is None
+    # a rank that fails takes the whole call down with a non-zero exit
+    r2 = subprocess.run(cmd + ["--mode", "DHGR", "--streams", "-7"], env=dict(env, IIV_STANDIN_FAIL_RANK="1"), capture_output=True, text=True, timeout=300)
+    assert r2.returncode != 0
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """No GPU in the build container: the real backend with --gpus 2 must refuse before starting anything."""
+    import subprocess
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("two GPUs visible here")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "visible" in r.stderr and r.stdout.strip() == ""
