@@ -213,7 +213,7 @@ int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, c
     e->d_store = d_store;
     e->d_left = e->d_right = nullptr;
     e->nt.base = nullptr;
-    e->nt.xmask = nullptr;
+    e->nt.exact = 0;
     e->d_dwl = e->d_dwr = nullptr;
     e->d_left_t = e->d_right_t = nullptr;
     e->d_brief = nullptr;
@@ -280,7 +280,8 @@ int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, c
             if ((rc = hip_check(hipMalloc(&e->d_left, split_entries(mode, 0) * 4), "hipMalloc(split left)"))) break;
             if ((rc = hip_check(hipMalloc(&e->d_right, split_entries(mode, 1) * 4), "hipMalloc(split right)"))) break;
             if ((rc = build_split_tables(mode, e->d_strings, e->d_sub, e->d_left, e->d_right, 0))) break;
-            if ((rc = build_narrow_tables(mode, e->d_left, e->d_right, d_store, &e->nt, 0))) break;
+            // (the folded narrow form is compared with the caller's store table entry by entry: e->nt.exact)
+            if ((rc = build_narrow_tables(mode, e->d_strings, e->d_sub, e->d_left, d_store, &e->nt, 0))) break;
         }
         // Video.__init__ (video.py:21-62); RNG streams default to random.seed(0) / np.random.seed(0)
         uint32_t rng0[1248], key0 = 0;
@@ -350,6 +351,9 @@ int encoder_set_option(Encoder *e, int option, int value)
         if ((value == IIV_GREEDY_WAVE || value == IIV_GREEDY_TEAM || value == IIV_GREEDY_WAVE_SHARED || value == IIV_GREEDY_WAVE_PLAIN) && !e->d_left)
             return set_error(IIV_ERR_INVALID, "the one-wave kernel reads the split store table, which is built from dm "
                                                "(none was given at creation)");
+        if (value != IIV_GREEDY_WORKGROUP && value != IIV_GREEDY_AUTO && !e->nt.exact)
+            return set_error(IIV_ERR_INVALID, "the split store table built from dm does not reproduce the store table given at creation: "
+                                               "this encoder runs the dense-table workgroup kernel only");
         e->greedy_mode = value;
         return IIV_OK;
     }
@@ -377,9 +381,9 @@ int encoder_set_option(Encoder *e, int option, int value)
     }
     if (option == IIV_OPT_FOURTH_OFFSET) {
         if (value != 0 && value != 1) return set_error(IIV_ERR_INVALID, "bad value");
-        if (value && !e->d_left)
+        if (value && (!e->d_left || !e->nt.exact))
             return set_error(IIV_ERR_INVALID, "the fourth offset runs in the one-wave kernel, which reads the split store table "
-                                               "built from dm (none was given at creation)");
+                                               "built from dm (none was given at creation, or it does not reproduce the store table given)");
         if (value && e->content_choice == IIV_CONTENT_JOINT)
             return set_error(IIV_ERR_INVALID, "the joint content choice and the fourth offset are not implemented together");
         e->fourth_offset = value;
@@ -805,7 +809,9 @@ static int launch_round(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux,
     // workgroup kernel remains for encoders created without dm, and as a second implementation
     // (the joint content choice, not a reference behaviour, exists in the workgroup kernel only)
     // (f4's fourth offset: in the plain one-wave kernel only, whatever the kernel option says)
-    const bool use_wave = e->fourth_offset || (e->d_left && e->greedy_mode != IIV_GREEDY_WORKGROUP && e->content_choice == IIV_CONTENT_TARGET);
+    // (e->nt.exact: the folded narrow form reproduced every entry of the caller's store table at creation -- always so for
+    // tables built from the same dm; otherwise the dense-table workgroup kernel runs)
+    const bool use_wave = e->fourth_offset || (e->d_left && e->nt.exact && e->greedy_mode != IIV_GREEDY_WORKGROUP && e->content_choice == IIV_CONTENT_TARGET);
     // few streams: a team of eight waves per stream scores the next entries of the list
     // concurrently (iiv_team.hip); from ~900 streams on, one wave per stream fills the GPU
     const bool use_team = use_wave && (e->greedy_mode == IIV_GREEDY_TEAM ||
@@ -1088,11 +1094,11 @@ int iiv_build_split_store_table(int mode, const int32_t dm[256], uint32_t *d_lef
 }
 
 int iiv_build_narrow_store_table(int mode, const int32_t dm[256], const uint16_t *d_store_table, uint16_t *d_expanded,
-                                 unsigned long long *n_exceptions, void *stream)
+                                 unsigned long long *n_mismatch, void *stream)
 {
-    if ((mode != IIV_HGR && mode != IIV_DHGR) || !dm || !d_store_table || !d_expanded || !n_exceptions)
+    if ((mode != IIV_HGR && mode != IIV_DHGR) || !dm || !d_store_table || !d_expanded || !n_mismatch)
         return iiv::set_error(IIV_ERR_INVALID, "iiv_build_narrow_store_table: bad argument");
-    return iiv::build_narrow_store_table(mode, dm, d_store_table, d_expanded, n_exceptions, (hipStream_t)stream);
+    return iiv::build_narrow_store_table(mode, dm, d_store_table, d_expanded, n_mismatch, (hipStream_t)stream);
 }
 
 size_t iiv_split_table_entries(int mode, int right_half) { return iiv::split_entries(mode, right_half ? 1 : 0); }

@@ -33,6 +33,7 @@
 #include "iiv_host.h"
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 #include "iiv_stream.h"
 #include "iiv_wave.h"
@@ -73,8 +74,7 @@ template <int MODE> struct SharedCfg {
     static constexpr int kOffsets = MODE == kDHGR ? 2 : 1;                                  // byte offsets whose L1 lives in LDS
     static constexpr int kHalfBytes = 2 << (SplitTraits<MODE>::kLeftCBits + SplitTraits<MODE>::kLeftRowBits);   // one offset's L1
     static constexpr int kL1Bytes = kOffsets * kHalfBytes;
-    static constexpr int kZero = kL1Bytes;       // a zero word behind them (excepted bytes, iiv_stream.h)
-    static constexpr int kPad = kL1Bytes + 256;
+    static constexpr int kPad = kL1Bytes;
     static constexpr int kW = MODE == kDHGR ? IIV_SHARED_W : IIV_SHARED_W_HGR;
     static constexpr int kLds = kPad + kW * (int)sizeof(WaveLds);
 };
@@ -126,7 +126,6 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
             const uint4 *src = reinterpret_cast<const uint4 *>(nt.base + ((size_t)o << (T::kLeftCBits + T::kLeftRowBits + 1)));
             for (int i = threadIdx.x; i < kQuads; i += 64 * W) dst[h * kQuads + i] = src[i];
         }
-        if (threadIdx.x < 64) dyn_lds[SC::kZero / 4 + threadIdx.x] = 0u;
         __syncthreads();
     }
 
@@ -222,63 +221,52 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
     const uint32_t pad_content = (uint32_t)IIV_SGPR(S.pad_content);
 
     // table slices of the even / odd page bytes of this bank (narrow form, iiv_stream.h): byte
-    // offsets, inside the one allocation, of L1[o], R1[o] and dense[o]
-    constexpr int BITS = ModeTraits<MODE>::kBits, CB = ModeTraits<MODE>::kContentBits;
+    // offsets, inside the one allocation, of L1[o] and RF[o]
     const int o_e = byte_offset<MODE>(0, is_aux), o_d = byte_offset<MODE>(1, is_aux);
     const uint32_t l1_e = (uint32_t)o_e << (T::kLeftCBits + T::kLeftRowBits + 1), l1_d = (uint32_t)o_d << (T::kLeftCBits + T::kLeftRowBits + 1);
     const uint32_t r1_e = nt.right_off + ((uint32_t)o_e << (T::kRightCBits + T::kRightRowBits + 1));
     const uint32_t r1_d = nt.right_off + ((uint32_t)o_d << (T::kRightCBits + T::kRightRowBits + 1));
-    const uint32_t ds_e = nt.dense_off + ((uint32_t)o_e << (CB + BITS + 1)), ds_d = nt.dense_off + ((uint32_t)o_d << (CB + BITS + 1));
-    // the exception masks of both parities: lane i holds the word of content part i
-    typedef typename std::conditional<MODE == kDHGR, uint32_t, unsigned long long>::type xmask_t;
-    const xmask_t xm_e = reinterpret_cast<const xmask_t *>(nt.xmask)[(o_e << 6) + lane];
-    const xmask_t xm_d = reinterpret_cast<const xmask_t *>(nt.xmask)[(o_d << 6) + lane];
     // this stream's state as a raw buffer, for the stores of a step
     const __amdgpu_buffer_rsrc_t rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void *)&S, 0, (int)sizeof(StreamState), 0x00020000);
     const int up_off = (int)offsetof(StreamState, up) + is_aux * 8192 * 4, mem_off = (int)offsetof(StreamState, mem) + is_aux * 8192;
     // the allocation as a raw buffer (no bounds: every offset formed below lies inside it by construction)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)nt.base, 0, 0x7fffffff, 0x00020000);
-    auto xmask_of = [&](xmask_t v, uint32_t part) -> xmask_t {
-        if (MODE == kDHGR) return (xmask_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)part);
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)part);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)v >> 32), (int)part);
-        return (xmask_t)(((unsigned long long)hi << 32) | lo);
-    };
     const uint8_t *tgt_frames = (MODE == kDHGR && is_aux ? frames_aux : frames_main) +
                                 ((size_t)stream * n_frames + frame) * 8192;
     const uint4 *wd_rows = reinterpret_cast<const uint4 *>(S.wd);
     const int wsel = lane >> 3;          // this lane's word inside a page's 8 bitmap words
     const int sh0 = (4 * lane) & 31;     // its 4 bits inside that word
     const uint32_t y0 = 4u * (uint32_t)lane;
+    // A key is value * kKeyMul + (wd << 20) + y = delta << 20 | value << 8 | y (iiv_stream.h: wd carries minus the diff
+    // weight in its low bits); RF's bias leaves through the per-byte constant that also brings the offset y in
+    constexpr uint32_t kKeyMul = (1u << kWdDwShift) | (1u << 8);
+    const uint32_t ycst0 = y0 - kNarrowBias * kKeyMul;
 
     // What a step needs of one entry: its eight table words and the diff-weight fields of its
     // row.  Two such sets alternate (one is scored while the other is being loaded); the loop
     // below is written out twice so that no in-flight register is ever copied -- a copy
     // would make the compiler wait for the load right there.
     struct Loaded {
-        uint32_t gl[4], gr[4], dwm[4];
+        uint32_t gl[4], gr[4], kb[4];   // the two table words per byte; -diff weight << 20 | y (less the bias term)
     };
     // the eight table loads of one entry (content c, row w): a lane's bytes 0, 2 are even page
     // offsets, 1, 3 odd ones; both lookups of a slice back to back (the second finds the
     // slice's lines in L1)
     auto gather8 = [&](const uint4 &w, uint32_t c, Loaded &L) {
-        // slice bases of this content byte, and where an excepted byte's loads go instead
+        // slice bases of this content byte
         // (W > 1: byte offsets into the LDS copy -- the bank's even-offset half, then its odd-offset half)
         const uint32_t sl_e = (W == 1 ? l1_e : 0u) + (split_content_left<MODE>(c, 0) << (T::kLeftRowBits + 1));
         constexpr bool kOddInLds = W > 1 && SC::kOffsets == 2;   // (HGR: the odd bytes' L1 stays with the L1 / TA)
         const uint32_t sl_d = (kOddInLds ? (uint32_t)SC::kHalfBytes : l1_d) + (split_content_left<MODE>(c, 1) << (T::kLeftRowBits + 1));
         const uint32_t sr_e = r1_e + (split_content_right<MODE>(c, 0) << (T::kRightRowBits + 1));
         const uint32_t sr_d = r1_d + (split_content_right<MODE>(c, 1) << (T::kRightRowBits + 1));
-        const uint32_t zr_e = (W == 1 ? nt.zero_off : (uint32_t)SC::kZero) - sl_e, zr_d = (kOddInLds ? (uint32_t)SC::kZero : nt.zero_off) - sl_d;
-        const uint32_t cd = (c & ((1u << CB) - 1)) << (BITS + 1);   // (a DHGR byte with bit 7 set is an error elsewhere)
-        const uint32_t dr_e = ds_e + cd - sr_e, dr_d = ds_d + cd - sr_d;
-        const xmask_t me = xmask_of(xm_e, narrow_mask_content<MODE>(c, 0)), md = xmask_of(xm_d, narrow_mask_content<MODE>(c, 1));
         const uint32_t wr[4] = {w.x, w.y, w.z, w.w};
         uint32_t ol[4], orr[4];
-        narrow_offsets<MODE, 0>(wr[0], me, zr_e, dr_e, ol[0], orr[0]);
-        narrow_offsets<MODE, 0>(wr[2], me, zr_e, dr_e, ol[2], orr[2]);
-        narrow_offsets<MODE, 1>(wr[1], md, zr_d, dr_d, ol[1], orr[1]);
-        narrow_offsets<MODE, 1>(wr[3], md, zr_d, dr_d, ol[3], orr[3]);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            ol[r] = wd_off_left(wr[r]);     // one shift
+            orr[r] = wd_off_right(wr[r]);   // one bit-field extract
+        }
         // buffer loads: address = allocation + scalar slice offset + lane offset, so a slice base is
         // one 32-bit SGPR instead of a 64-bit pointer formed per opcode (-8 scalar instructions, +1 %)
         if (W == 1) {
@@ -301,12 +289,12 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
         L.gr[2] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)orr[2], (int)sr_e, 0);
         L.gr[1] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)orr[1], (int)sr_d, 0);
         L.gr[3] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)orr[3], (int)sr_d, 0);
-        // (the empty asm keeps the compiler from sinking these four ANDs to the scoring two
+        // (the empty asm keeps the compiler from sinking these four shift-adds to the scoring two
         // half-iterations later, which would keep the whole row alive until then)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            L.dwm[r] = wr[r] & kWdDwMask;
-            asm volatile("" : "+v"(L.dwm[r]));
+            L.kb[r] = (wr[r] << kWdDwShift) + (ycst0 + (uint32_t)r);
+            asm volatile("" : "+v"(L.kb[r]));
         }
     };
 
@@ -426,10 +414,10 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
         unsigned long long cand[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            nd[r] = L.gl[r] + L.gr[r];   // l1 + r1, or 0 + the dense value (iiv_stream.h: narrow form)
+            nd[r] = L.gl[r] + L.gr[r];   // L1 + RF = store value + kNarrowBias (iiv_stream.h: narrow form)
             // delta << 20 | store value << 8 | offset: the value (11 bits) rides in the key's spare bits, so a winner's key
-            // brings it along (one multiply-add: nd * (2^20 + 2^8) + y; the subtraction touches bits >= 20 only)
-            const int d = (int)(__umul24(nd[r], (1u << kWdDwShift) | (1u << 8)) + (y0 + r)) - (int)L.dwm[r];
+            // brings it along (one multiply-add: nd * (2^20 + 2^8) + kb, kb = -diff weight << 20 | y less the bias term)
+            const int d = (int)(__umul24(nd[r], kKeyMul) + L.kb[r]);
             const int gone = __builtin_amdgcn_sbfe((int)pdw, sh0 + r, 1);
             const int live = __builtin_amdgcn_sbfe((int)nzw, sh0 + r, 1);
             ke[r] = d & live;
@@ -448,7 +436,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
             const uint32_t nd01 = nd[0] | (nd[1] << 16), nd23 = nd[2] | (nd[3] << 16);
             const uint32_t pa = (uint32_t)__builtin_amdgcn_readlane((int)nd01, y >> 2);
             const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane((int)nd23, y >> 2);
-            return (((y & 2) ? pb : pa) >> ((y & 1) * 16)) & 0xffffu;
+            return ((((y & 2) ? pb : pa) >> ((y & 1) * 16)) & 0xffffu) - kNarrowBias;
         };
         // The exact path below is complete by itself (it orders every eligible byte by (delta, nonce, offset)); the fast
         // path in front of it only pays where ties are rare.  On picture-like input they are the rule (96 % of the
@@ -694,7 +682,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
     // ---- phase B: the re-queued bag (video.py:124-131, 170-178), one entry at a time.
     // Entry i of pushed[] belongs to sub-bag i % 64, and lane l keeps the smallest key of sub-bag l (and where it
     // is) in a register: a pop is a wave minimum over that register; only the sub-bag it came from is read again
-    // (by all lanes, its <= 256 entries: one to four loads each, requested before the step and used after it);
+    // (by all lanes, its <= kPushedCap / 64 = 384 entries: up to kSub loads each, requested before the step and used after it);
     // a push is a comparison with one lane's minimum.  (It was a scan of the whole bag per pop: on input that
     // converges -- a static background -- every opcode comes from here, and the bag holds two entries per
     // opcode emitted so far.)
@@ -737,9 +725,13 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
             if (lane == 0) S.pushed[bi] = INF;
             // what is left of that sub-bag: entries wl + 64 j (the popped one excluded by its index, the store
             // above is for later visits)
-            uint32_t rk[4], ridx[4];
+            // (sized from the cap: with the fourth offset a generator can push 3 entries per step, and an entry at an
+            // index >= 4 * 4096 that the rescan did not reach would be dropped from its sub-bag's minimum)
+            constexpr int kSub = (kPushedCap + 4095) / 4096;
+            static_assert(kPushedCap <= 64 * 64 * kSub, "the rescan of a sub-bag must reach every index below kPushedCap");
+            uint32_t rk[kSub], ridx[kSub];
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
+            for (int t = 0; t < kSub; t++) {
                 ridx[t] = (uint32_t)wl + 64u * (uint32_t)(lane + 64 * t);
                 rk[t] = INF;
                 if (ridx[t] < (uint32_t)n_pushed && ridx[t] != bi) rk[t] = S.pushed[ridx[t]];
@@ -757,7 +749,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
             // the sub-bag's new minimum, then what this step pushed
             uint32_t mk = rk[0], mi = ridx[0];
 #pragma unroll
-            for (int t = 1; t < 4; t++) {
+            for (int t = 1; t < kSub; t++) {
                 mi = rk[t] < mk ? ridx[t] : mi;
                 mk = rk[t] < mk ? rk[t] : mk;
             }
@@ -840,17 +832,29 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
 template <int MODE, bool FOUR> static int launch_shared(const GreedyArgs &a, hipStream_t st)
 {
     using SC = SharedCfg<MODE>;
-    static int resident = 0;
-    if (!resident) {
-        int per_cu = 0, dev = 0;
-        hipDeviceProp_t prop;
-        if (hip_check(hipFuncSetAttribute((const void *)greedy_wave_kernel<MODE, SC::kW, FOUR>, hipFuncAttributeMaxDynamicSharedMemorySize, SC::kLds),
-                      "greedy_wave_kernel LDS attribute") ||
-            hip_check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)greedy_wave_kernel<MODE, SC::kW, FOUR>, 64 * SC::kW, (size_t)SC::kLds),
-                      "greedy_wave_kernel occupancy") ||
-            hip_check(hipGetDevice(&dev), "hipGetDevice") || hip_check(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties"))
-            return IIV_ERR_HIP;
-        resident = (per_cu > 0 ? per_cu : 1) * prop.multiProcessorCount;
+    // workgroups resident at once, per DEVICE (a process may drive several GPUs; the LDS attribute is per device too) and
+    // per instantiation; encoders on different host threads may get here together
+    constexpr int kMaxDev = 64;
+    static int resident_of[kMaxDev] = {};
+    static std::mutex mu;
+    int dev = 0;
+    if (hip_check(hipGetDevice(&dev), "hipGetDevice")) return IIV_ERR_HIP;
+    if (dev < 0 || dev >= kMaxDev) return set_error(IIV_ERR_INVALID, "greedy_wave_kernel: device index %d", dev);
+    int resident;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!resident_of[dev]) {
+            int per_cu = 0;
+            hipDeviceProp_t prop;
+            if (hip_check(hipFuncSetAttribute((const void *)greedy_wave_kernel<MODE, SC::kW, FOUR>, hipFuncAttributeMaxDynamicSharedMemorySize, SC::kLds),
+                          "greedy_wave_kernel LDS attribute") ||
+                hip_check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)greedy_wave_kernel<MODE, SC::kW, FOUR>, 64 * SC::kW, (size_t)SC::kLds),
+                          "greedy_wave_kernel occupancy") ||
+                hip_check(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties"))
+                return IIV_ERR_HIP;
+            resident_of[dev] = (per_cu > 0 ? per_cu : 1) * prop.multiProcessorCount;
+        }
+        resident = resident_of[dev];
     }
     const int wgs = (a.n_streams + SC::kW - 1) / SC::kW;
     hipLaunchKernelGGL((greedy_wave_kernel<MODE, SC::kW, FOUR>), dim3(wgs < resident ? wgs : resident), dim3(64 * SC::kW), (size_t)SC::kLds, st, a.states,

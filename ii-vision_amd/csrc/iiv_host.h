@@ -35,12 +35,13 @@ size_t split_entries(int mode, int right);
 int build_split_tables(int mode, const ulonglong2 *d_strings, const uint16_t *d_sub, uint32_t *d_left, uint32_t *d_right,
                        hipStream_t st);
 struct NarrowTables;
-int build_narrow_tables(int mode, const uint32_t *d_left, const uint32_t *d_right, const uint16_t *d_store, NarrowTables *out,
-                        hipStream_t st);
+int build_narrow_tables(int mode, const ulonglong2 *d_strings, const uint16_t *d_sub, const uint32_t *d_left, const uint16_t *d_store,
+                        NarrowTables *out, hipStream_t st);
 void free_narrow_tables(NarrowTables *nt);
-int expand_narrow_tables(int mode, const NarrowTables &nt, uint16_t *d_out, unsigned long long *n_exceptions, hipStream_t st);
+int expand_narrow_tables(int mode, const NarrowTables &nt, const uint16_t *d_store, uint16_t *d_out, unsigned long long *n_mismatch,
+                         hipStream_t st);
 int build_narrow_store_table(int mode, const int32_t dm[256], const uint16_t *d_store, uint16_t *d_expanded,
-                             unsigned long long *n_exceptions, hipStream_t st);
+                             unsigned long long *n_mismatch, hipStream_t st);
 int transpose_split_tables(int mode, const uint32_t *d_left, const uint32_t *d_right, uint32_t *d_left_t,
                            uint32_t *d_right_t, hipStream_t st);
 size_t split_dw_entries(int mode, int right);

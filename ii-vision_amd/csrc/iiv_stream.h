@@ -12,23 +12,24 @@ constexpr int kPushedCap = 24576;  // >= 3 pushes (two, or three with the fourth
 
 // ---- wd[]: one word per byte of the live generator's bank, written once by the prologue
 // and immutable while the generator lives:
-//   bits  0..8   row index into the RIGHT half of the split store table  (split_row_right);
-//                its low 5 / 6 bits are also the index into the "exception" masks below, which
-//                is why it sits at bit 0: a shift instruction takes them as they are
-//   bits 10..18  row index into the LEFT half                            (split_row_left);
-//                with bit 9 (always 0) the 10-bit field at bit 9 is the byte offset of the
-//                row's u16 inside a slice
-//   bits 20..30  diff weight of the byte (Bitmap.diff_weights, screen.py:400-449), <= 2047
-// Keys of the greedy step are `value << 20 | offset`, so `key - (wd & kWdDwMask)` is
-// `delta << 20 | offset` with delta = store value - diff weight (screen.py:547) in [-2047, 2047].
-constexpr int kWdDwShift = 20;
-constexpr uint32_t kWdDwMask = 0xffffffffu << kWdDwShift;
-constexpr int kWdLeftShift = 10, kWdRightShift = 0;
-constexpr uint32_t kWdRowMask = 0x1ffu;
+//   bits  0..11  MINUS the diff weight of the byte (Bitmap.diff_weights, screen.py:400-449; <= 2047), modulo 4096
+//   bits 12..21  byte offset of the byte's u16 inside a slice of the RIGHT half of the split store
+//                table: split_row_right << 1  (bit 12 is 0)
+//   bits 22..31  the same for the LEFT half: split_row_left << 1  (bit 22 is 0)
+// A greedy step needs three things of a byte, one instruction each: the left offset (a shift), the
+// right offset (a bit-field extract), and `(wd << 20) + offset constant` = -diff weight << 20 | y,
+// the addend of the key `value * (2^20 + 2^8) + ...` = delta << 20 | value << 8 | y with
+// delta = store value - diff weight (screen.py:547) in [-2047, 2047].
+constexpr int kWdDwShift = 20;     // where a key carries its delta
+constexpr int kWdDwBits = 12;
+constexpr int kWdRightShift = 12, kWdLeftShift = 22;
 __host__ __device__ inline uint32_t wd_word(uint32_t row_left, uint32_t row_right, uint32_t dw)
 {
-    return (row_left << kWdLeftShift) | (row_right << kWdRightShift) | (dw << kWdDwShift);
+    return (row_left << (kWdLeftShift + 1)) | (row_right << (kWdRightShift + 1)) | ((0u - dw) & ((1u << kWdDwBits) - 1u));
 }
+__host__ __device__ inline uint32_t wd_dw(uint32_t wd) { return (0u - wd) & ((1u << kWdDwBits) - 1u); }   // the diff weight back
+__host__ __device__ inline uint32_t wd_off_left(uint32_t wd) { return wd >> kWdLeftShift; }
+__host__ __device__ inline uint32_t wd_off_right(uint32_t wd) { return (wd >> kWdRightShift) & 0x3ffu; }
 constexpr int kMaxValue = 2047;  // every table value and diff weight must fit 11 bits
 
 struct StreamState {
@@ -156,80 +157,41 @@ __host__ __device__ inline uint32_t split_combine(uint32_t l, uint32_t r)
 }
 
 // ---- the narrow form the greedy kernels read -------------------------------------------------
-// A greedy step is bound by the L1's rate for divergent loads, and that rate follows the bytes
-// its slices occupy (tools/gather_ceiling.hip: the access pattern alone, no arithmetic, takes
-// 1.42 ms per 12288-stream launch with 4-byte entries and 0.92 ms with 2-byte ones).  Of the two
-// paths of S = min(l0 + r0, l1 + r1), path 0 -- a transposition of the two pixels across the
-// cut -- exists only when the source's pixels (M, M+1) are the target's swapped, 1.6 % of all
-// (content, window) pairs.  So the kernels read
-//     L1[o][content part][row] = l1,   R1[o][content part][row] = r1      (u16 each)
-// and S = l1 + r1, except where an *exception mask* says the pair may differ from that: there
-// the value comes from the dense store table S[o][content][window] itself (one more table, read
-// by one lane in 64).  The mask is indexed by the few bits the swap condition can depend on:
-//     X[o][content part][index],  index = low 5 (DHGR) / 6 (HGR) bits of the right row
-//                                         (HGR odd bytes: bits 3..8 of the left row)
-// and is *built by comparison*: a bit is set iff some (content, window) it covers has
-// l1 + r1 != S (iiv_tables.hip: narrow_mask_kernel), so the scheme is exact by construction
-// whatever the bits chosen; choosing them well only keeps the exceptions rare.
-// To keep every load of a step unconditional (the software pipeline of iiv_greedy.hip depends on
-// that), an excepted byte does not branch: its RIGHT load is redirected to the dense entry and
-// its LEFT load to a zero word -- L1 | zero | R1 | dense copy live in ONE allocation, so a
-// redirection is a different 32-bit offset from the same slice base.
+// A greedy step is bound by what its 256 lookups cost, and that follows the bytes its slices occupy
+// (tools/gather_ceiling.hip: the access pattern alone, no arithmetic, takes 1.42 ms per 12288-stream
+// launch with 4-byte entries and 0.92 ms with 2-byte ones).  So the kernels read two u16 per byte and
+// add them.  Of the two paths of S = min(l0 + r0, l1 + r1), path 0 -- a transposition of the two
+// pixels across the cut -- needs the left state's OTHER component, l0 = E[M-2].  But
+//     l1 = E[M-1] = min(l0 + s, E[M-3] + 1 if pixels (M-2, M-1) transpose),   s = sub(a[M-1], b[M-1]),
+// and a transposition of (M-2, M-1) excludes one of (M-1, M) where the two paths differ: adjacent
+// pixels are 4-dot windows that share three dots, so a string cannot swap the same pixel with both
+// neighbours unless the three are equal.  Hence l0 = l1 - s wherever path 0 matters, s is known to the
+// RIGHT half (pixel M-1 lies inside its bits), and
+//     S = L1 + RF,    L1[o][content part][row] = l1,    RF[o][content part][row] = min(r1, r0 - s)
+// for EVERY (offset, content, window): no exceptions, no third table.  Round 3 read R1 = r1 instead
+// and sent the 1/64 of the pairs where path 0 wins to the dense table through per-content exception
+// masks -- eleven address instructions per byte instead of two.  That the folded form is exact is not
+// taken on trust: iiv_encoder_create expands it for every entry and compares with the caller's store
+// table (an encoder whose tables disagree runs the dense-table workgroup kernel instead), and
+// tests/test_gpu_tables.py::test_narrow_store_table_is_exact does the same for both modes, both
+// palettes and random diff matrices.  r0 - s may be negative for matrices that are not metrics, so
+// RF is stored with a bias that the step's key constant takes out again.
+constexpr uint32_t kNarrowBias = 256;   // > max(dm) (<= 204: iiv_encoder_create)
 struct NarrowTables {
-    const uint8_t *base;                         // the allocation (its first bytes are L1)
-    uint32_t zero_off, right_off, dense_off;     // byte offsets of the zero word, R1, the dense copy
-    const void *xmask;                           // DHGR: u32 [4][64]; HGR: u64 [2][64]
+    const uint8_t *base;      // the allocation: L1 | RF
+    uint32_t right_off;       // byte offset of RF
+    int exact;                // build_narrow_tables: the expansion equals the dense store table for every entry
 };
-template <int MODE> __host__ __device__ constexpr uint32_t narrow_zero_off() { return (uint32_t)split_left_entries<MODE>() * 2; }
-template <int MODE> __host__ __device__ constexpr uint32_t narrow_right_off() { return narrow_zero_off<MODE>() + 256; }
-template <int MODE> __host__ __device__ constexpr uint32_t narrow_dense_off()
-{
-    return narrow_right_off<MODE>() + (uint32_t)split_right_entries<MODE>() * 2;
-}
+template <int MODE> __host__ __device__ constexpr uint32_t narrow_right_off() { return (uint32_t)split_left_entries<MODE>() * 2; }
 template <int MODE> __host__ __device__ constexpr size_t narrow_total_bytes()
 {
-    return narrow_dense_off<MODE>() + (((size_t)ModeTraits<MODE>::kOffsets << (ModeTraits<MODE>::kContentBits + ModeTraits<MODE>::kBits)) * 2);
-}
-// which mask word / bit a (content, rows) pair falls under
-template <int MODE> __host__ __device__ inline uint32_t narrow_mask_content(uint32_t c, int odd)
-{
-    if (MODE == kDHGR) return split_content_right<MODE>(c, odd);
-    return odd ? split_content_left<MODE>(c, 1) : split_content_right<MODE>(c, 0);
-}
-template <int MODE> __host__ __device__ inline uint32_t narrow_mask_index(uint32_t row_left, uint32_t row_right, int odd)
-{
-    if (MODE == kDHGR) return row_right & 31u;
-    return odd ? (row_left >> 3) & 63u : row_right & 63u;
+    return narrow_right_off<MODE>() + split_right_entries<MODE>() * 2;
 }
 // the window back from its two rows
 template <int MODE> __host__ __device__ inline uint32_t split_window_from_rows(uint32_t row_left, uint32_t row_right, int odd)
 {
     if (MODE == kDHGR) return (row_right << 4) | (row_left & 15u);
     return odd ? ((row_right >> 1) << 6) | (row_left & 63u) : (row_right << 5) | (row_left & 31u);
-}
-// byte offsets, relative to the (offset, content) slice bases of L1 and R1, of the two u16 a
-// byte's value is the sum of.  xm = the byte's mask word (u32 DHGR / u64 HGR, wave-uniform per
-// parity), zrel = zero word - L1 slice base, drel = dense[o][content][0] - R1 slice base.
-template <int MODE, int ODD, typename M>
-__device__ static inline void narrow_offsets(uint32_t wd, M xm, uint32_t zrel, uint32_t drel, uint32_t &off_l, uint32_t &off_r)
-{
-    const uint32_t rr = wd & kWdRowMask;
-    const uint32_t lr2 = __builtin_amdgcn_ubfe(wd, kWdLeftShift - 1, 10);   // left row << 1: bit 9 of wd is 0
-    // the byte's exception bit (v_bfe_u32 takes the low 5 bits of its offset operand as they are)
-    uint32_t t;
-    if (MODE == kDHGR) t = __builtin_amdgcn_ubfe((uint32_t)xm, wd, 1);
-    else if (!ODD) t = (uint32_t)(xm >> (wd & 63u)) & 1u;
-    else t = (uint32_t)(xm >> ((wd >> (kWdLeftShift + 3)) & 63u)) & 1u;
-    // (window << 1) + drel, the window put back together from its rows (split_window_from_rows)
-    uint32_t dl;
-    if (MODE == kDHGR) dl = (rr << 5) + ((lr2 & 30u) + drel);
-    else if (!ODD) dl = (rr << 6) + ((lr2 & 62u) + drel);
-    else dl = ((rr >> 1) << 7) + ((lr2 & 126u) + drel);
-    // (bit selects on the exception bit spread over the word: one v_bfe_i32 and two v_bfi_b32 instead of a compare and
-    // two conditional moves)
-    const uint32_t m = 0u - t;
-    off_l = (zrel & m) | (lr2 & ~m);
-    off_r = (dl & m) | ((rr << 1) & ~m);
 }
 
 // LDS accesses of one wave execute in order: making one lane's LDS writes visible to the

@@ -302,47 +302,57 @@ __global__ __launch_bounds__(256) void split_kernel(const ulonglong2 *__restrict
 
 // ------------------------------------------------------------------ narrow form (iiv_stream.h)
 
-// L1 / R1: component 1 of every entry of the two halves, as u16
+// L1 (u16): component 1 of every entry of the left half.  RF (u16): min(r1, r0 - s) + kNarrowBias for every entry of
+// the right half, s = the substitution cost of the last pixel of the LEFT half (pixel kCut - 1, which lies inside the
+// right half's bits): one thread per entry, same representative windows and recurrence as split_kernel.
 template <int MODE>
-__global__ __launch_bounds__(256) void narrow_fill_kernel(const uint32_t *__restrict__ left, const uint32_t *__restrict__ right,
-                                                          uint8_t *__restrict__ buf)
-{
-    const size_t nl = split_left_entries<MODE>(), nr = split_right_entries<MODE>();
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx < nl)
-        reinterpret_cast<uint16_t *>(buf)[idx] = (uint16_t)(left[idx] >> 16);
-    else if (idx < nl + nr)
-        reinterpret_cast<uint16_t *>(buf + narrow_right_off<MODE>())[idx - nl] = (uint16_t)(right[idx - nl] >> 16);
-    if (idx < 128) reinterpret_cast<uint16_t *>(buf + narrow_zero_off<MODE>())[idx] = 0;
-}
-
-// exception masks, by comparison with the dense table: one thread per (offset, content, window)
-template <int MODE>
-__global__ __launch_bounds__(256) void narrow_mask_kernel(const uint8_t *__restrict__ buf, const uint16_t *__restrict__ dense,
-                                                          unsigned long long *__restrict__ xmask64, uint32_t *__restrict__ xmask32)
+__global__ __launch_bounds__(256) void narrow_fold_kernel(const ulonglong2 *__restrict__ strings, const uint16_t *__restrict__ sub,
+                                                          const uint32_t *__restrict__ left, uint8_t *__restrict__ buf)
 {
     using T = SplitTraits<MODE>;
-    constexpr int BITS = ModeTraits<MODE>::kBits, CB = ModeTraits<MODE>::kContentBits;
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // ((o << CB) + content) << BITS) + window
-    if (idx >= ((size_t)ModeTraits<MODE>::kOffsets << (CB + BITS))) return;
-    const uint32_t m = idx & ((1u << BITS) - 1), c = (idx >> BITS) & ((1u << CB) - 1);
-    const int o = (int)(idx >> (BITS + CB)), odd = o & 1;
-    const uint32_t lr = split_row_left<MODE>(m, odd), rr = split_row_right<MODE>(m, odd);
-    const uint16_t *l1 = reinterpret_cast<const uint16_t *>(buf), *r1 = reinterpret_cast<const uint16_t *>(buf + narrow_right_off<MODE>());
-    const uint32_t v = (uint32_t)l1[((((size_t)o << T::kLeftCBits) + split_content_left<MODE>(c, odd)) << T::kLeftRowBits) + lr] +
-                       (uint32_t)r1[((((size_t)o << T::kRightCBits) + split_content_right<MODE>(c, odd)) << T::kRightRowBits) + rr];
-    if (v != dense[idx]) {
-        const uint32_t word = ((uint32_t)o << 6) + narrow_mask_content<MODE>(c, odd), bit = narrow_mask_index<MODE>(lr, rr, odd);
-        if (MODE == kDHGR) atomicOr(&xmask32[word], 1u << bit);
-        else atomicOr(&xmask64[word], 1ull << bit);
+    constexpr int BITS = ModeTraits<MODE>::kBits, ND = ModeTraits<MODE>::kDots;
+    __shared__ uint16_t lut[256];
+    load_cost_lut(lut, sub, threadIdx.x);
+    __syncthreads();
+    const size_t nl = split_left_entries<MODE>(), nr = split_right_entries<MODE>();
+    size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx < nl) {
+        reinterpret_cast<uint16_t *>(buf)[idx] = (uint16_t)(left[idx] >> 16);
+        return;
     }
+    idx -= nl;
+    if (idx >= nr) return;
+    const uint32_t row = idx & ((1u << T::kRightRowBits) - 1), cpart = (idx >> T::kRightRowBits) & ((1u << T::kRightCBits) - 1);
+    const int o = (int)(idx >> (T::kRightRowBits + T::kRightCBits));
+    const uint32_t mask = split_mask_right<MODE>(o), own = mask & split_mask_own<MODE>();
+    const uint32_t wt = pdep32(row, mask);
+    const uint32_t ws = (wt & ~own) | pdep32(cpart, own);
+    const ulonglong2 a = strings[((size_t)o << BITS) + ws], b = strings[((size_t)o << BITS) + wt];
+    uint32_t r[2];
+    for (int j = 0; j < 2; j++) {
+        uint32_t e2 = j == 0 ? 0u : kSplitInf, e1 = j == 0 ? kSplitInf : 0u;
+        for (int k = T::kCut; k < ND; k++) {
+            const uint32_t ak = string_pixel(a, k), bk = string_pixel(b, k);
+            uint32_t e = e1 + lut[ak * 16 + bk];
+            const uint32_t ap = string_pixel(a, k - 1), bp = string_pixel(b, k - 1);
+            if (ap == bk && ak == bp && e2 + 1 < e) e = e2 + 1;
+            e = e < kSplitInf ? e : kSplitInf;
+            e2 = e1;
+            e1 = e;
+        }
+        r[j] = e1;
+    }
+    const uint32_t s = lut[string_pixel(a, T::kCut - 1) * 16 + string_pixel(b, T::kCut - 1)];
+    int v = (int)r[1];
+    if (r[0] < kSplitInf && (int)r[0] - (int)s < v) v = (int)r[0] - (int)s;   // path 0: the transposition across the cut
+    reinterpret_cast<uint16_t *>(buf + narrow_right_off<MODE>())[idx] = (uint16_t)(v + (int)kNarrowBias);
 }
 
-// every value as the kernels obtain it (narrow_offsets), for the exactness test; also counts the
-// (content, window) pairs that go through the dense table
+// every value as the kernels obtain it (wd word -> two offsets -> two u16 -> sum - bias), for the exactness check at
+// encoder creation and in the tests; counts the entries that differ from the dense store table
 template <int MODE>
-__global__ __launch_bounds__(256) void narrow_expand_kernel(NarrowTables nt, uint16_t *__restrict__ out,
-                                                            unsigned long long *__restrict__ n_exceptions)
+__global__ __launch_bounds__(256) void narrow_expand_kernel(NarrowTables nt, const uint16_t *__restrict__ dense, uint16_t *__restrict__ out,
+                                                            unsigned long long *__restrict__ n_mismatch)
 {
     using T = SplitTraits<MODE>;
     constexpr int BITS = ModeTraits<MODE>::kBits, CB = ModeTraits<MODE>::kContentBits;
@@ -354,78 +364,14 @@ __global__ __launch_bounds__(256) void narrow_expand_kernel(NarrowTables nt, uin
     const uint32_t slab_l = (uint32_t)((((size_t)o << T::kLeftCBits) + split_content_left<MODE>(c, odd)) << (T::kLeftRowBits + 1));
     const uint32_t slab_r =
         nt.right_off + (uint32_t)((((size_t)o << T::kRightCBits) + split_content_right<MODE>(c, odd)) << (T::kRightRowBits + 1));
-    const uint32_t dense0 = nt.dense_off + (uint32_t)((((size_t)o << CB) + c) << (BITS + 1));
-    const uint32_t word = ((uint32_t)o << 6) + narrow_mask_content<MODE>(c, odd);
-    uint32_t off_l, off_r;
-    if (MODE == kDHGR) {
-        const uint32_t xm = reinterpret_cast<const uint32_t *>(nt.xmask)[word];
-        if (odd) narrow_offsets<MODE, 1>(wd, xm, nt.zero_off - slab_l, dense0 - slab_r, off_l, off_r);
-        else narrow_offsets<MODE, 0>(wd, xm, nt.zero_off - slab_l, dense0 - slab_r, off_l, off_r);
-    } else {
-        const unsigned long long xm = reinterpret_cast<const unsigned long long *>(nt.xmask)[word];
-        if (odd) narrow_offsets<MODE, 1>(wd, xm, nt.zero_off - slab_l, dense0 - slab_r, off_l, off_r);
-        else narrow_offsets<MODE, 0>(wd, xm, nt.zero_off - slab_l, dense0 - slab_r, off_l, off_r);
-    }
-    const uint32_t v = (uint32_t)*reinterpret_cast<const uint16_t *>(nt.base + slab_l + off_l) +
-                       (uint32_t)*reinterpret_cast<const uint16_t *>(nt.base + slab_r + off_r);
-    out[idx] = (uint16_t)v;
-    if (off_r >= nt.dense_off - slab_r) atomicAdd(n_exceptions, 1ull);
+    const uint32_t v = (uint32_t)*reinterpret_cast<const uint16_t *>(nt.base + slab_l + wd_off_left(wd)) +
+                       (uint32_t)*reinterpret_cast<const uint16_t *>(nt.base + slab_r + wd_off_right(wd)) - kNarrowBias;
+    if (out) out[idx] = (uint16_t)v;
+    if (dense && v != (uint32_t)dense[idx]) atomicAdd(n_mismatch, 1ull);
 }
 
-template <int MODE>
-static int build_narrow_impl(const uint32_t *d_left, const uint32_t *d_right, const uint16_t *d_store, NarrowTables *out,
-                             hipStream_t st)
-{
-    constexpr int BITS = ModeTraits<MODE>::kBits, CB = ModeTraits<MODE>::kContentBits;
-    uint8_t *buf = nullptr;
-    void *mask = nullptr;
-    IIV_HIP(hipMalloc(&buf, narrow_total_bytes<MODE>()));
-    hipError_t he = hipMalloc(&mask, 4 * 64 * 8);
-    if (he != hipSuccess) { (void)hipFree(buf); return hip_check(he, "hipMalloc(narrow masks)"); }
-    int rc = IIV_OK;
-    do {
-        if ((rc = hip_check(hipMemsetAsync(mask, 0, 4 * 64 * 8, st), "memset masks"))) break;
-        const size_t n_dense = (size_t)ModeTraits<MODE>::kOffsets << (CB + BITS);
-        if ((rc = hip_check(hipMemcpyAsync(buf + narrow_dense_off<MODE>(), d_store, n_dense * 2, hipMemcpyDeviceToDevice, st),
-                            "copy dense store table")))
-            break;
-        const size_t n_fill = split_left_entries<MODE>() + split_right_entries<MODE>();
-        hipLaunchKernelGGL(narrow_fill_kernel<MODE>, dim3((unsigned)((n_fill + 255) / 256)), dim3(256), 0, st, d_left, d_right, buf);
-        hipLaunchKernelGGL(narrow_mask_kernel<MODE>, dim3((unsigned)((n_dense + 255) / 256)), dim3(256), 0, st, buf, d_store,
-                           (unsigned long long *)mask, (uint32_t *)mask);
-        if ((rc = hip_check(hipGetLastError(), "narrow table kernels"))) break;
-        rc = hip_check(hipStreamSynchronize(st), "narrow tables sync");
-    } while (0);
-    if (rc) {
-        (void)hipFree(buf);
-        (void)hipFree(mask);
-        return rc;
-    }
-    out->base = buf;
-    out->zero_off = narrow_zero_off<MODE>();
-    out->right_off = narrow_right_off<MODE>();
-    out->dense_off = narrow_dense_off<MODE>();
-    out->xmask = mask;
-    return IIV_OK;
-}
-
-// d_left / d_right: the u32 halves (build_split_tables); d_store: the dense store table
-int build_narrow_tables(int mode, const uint32_t *d_left, const uint32_t *d_right, const uint16_t *d_store, NarrowTables *out,
-                        hipStream_t st)
-{
-    return mode == kDHGR ? build_narrow_impl<kDHGR>(d_left, d_right, d_store, out, st)
-                         : build_narrow_impl<kHGR>(d_left, d_right, d_store, out, st);
-}
-
-void free_narrow_tables(NarrowTables *nt)
-{
-    if (nt->base) (void)hipFree(const_cast<uint8_t *>(nt->base));
-    if (nt->xmask) (void)hipFree(const_cast<void *>(nt->xmask));
-    nt->base = nullptr;
-    nt->xmask = nullptr;
-}
-
-int expand_narrow_tables(int mode, const NarrowTables &nt, uint16_t *d_out, unsigned long long *n_exceptions, hipStream_t st)
+int expand_narrow_tables(int mode, const NarrowTables &nt, const uint16_t *d_store, uint16_t *d_out, unsigned long long *n_mismatch,
+                         hipStream_t st)
 {
     const size_t n = (size_t)num_offsets(mode) << (content_bits(mode) + masked_bits(mode));
     unsigned long long *d_cnt = nullptr;
@@ -433,14 +379,48 @@ int expand_narrow_tables(int mode, const NarrowTables &nt, uint16_t *d_out, unsi
     int rc = hip_check(hipMemsetAsync(d_cnt, 0, 8, st), "memset");
     if (!rc) {
         const dim3 grid((unsigned)((n + 255) / 256));
-        if (mode == kDHGR) hipLaunchKernelGGL(narrow_expand_kernel<kDHGR>, grid, dim3(256), 0, st, nt, d_out, d_cnt);
-        else hipLaunchKernelGGL(narrow_expand_kernel<kHGR>, grid, dim3(256), 0, st, nt, d_out, d_cnt);
+        if (mode == kDHGR) hipLaunchKernelGGL(narrow_expand_kernel<kDHGR>, grid, dim3(256), 0, st, nt, d_store, d_out, d_cnt);
+        else hipLaunchKernelGGL(narrow_expand_kernel<kHGR>, grid, dim3(256), 0, st, nt, d_store, d_out, d_cnt);
         rc = hip_check(hipGetLastError(), "narrow_expand_kernel launch");
     }
-    if (!rc) rc = hip_check(hipMemcpyAsync(n_exceptions, d_cnt, 8, hipMemcpyDeviceToHost, st), "copy count");
+    if (!rc) rc = hip_check(hipMemcpyAsync(n_mismatch, d_cnt, 8, hipMemcpyDeviceToHost, st), "copy count");
     if (!rc) rc = hip_check(hipStreamSynchronize(st), "sync");
     (void)hipFree(d_cnt);
     return rc;
+}
+
+// d_strings / d_sub: build_strings; d_left: the u32 left half (build_split_tables); d_store: the dense store table the
+// folded form is held to -- out->exact says whether every one of its entries is reproduced
+int build_narrow_tables(int mode, const ulonglong2 *d_strings, const uint16_t *d_sub, const uint32_t *d_left, const uint16_t *d_store,
+                        NarrowTables *out, hipStream_t st)
+{
+    const size_t total = mode == kDHGR ? narrow_total_bytes<kDHGR>() : narrow_total_bytes<kHGR>();
+    const size_t n_fill = split_entries(mode, 0) + split_entries(mode, 1);
+    uint8_t *buf = nullptr;
+    IIV_HIP(hipMalloc(&buf, total));
+    if (mode == kDHGR)
+        hipLaunchKernelGGL(narrow_fold_kernel<kDHGR>, dim3((unsigned)((n_fill + 255) / 256)), dim3(256), 0, st, d_strings, d_sub, d_left, buf);
+    else
+        hipLaunchKernelGGL(narrow_fold_kernel<kHGR>, dim3((unsigned)((n_fill + 255) / 256)), dim3(256), 0, st, d_strings, d_sub, d_left, buf);
+    int rc = hip_check(hipGetLastError(), "narrow_fold_kernel launch");
+    out->base = buf;
+    out->right_off = mode == kDHGR ? narrow_right_off<kDHGR>() : narrow_right_off<kHGR>();
+    out->exact = 0;
+    unsigned long long bad = 0;
+    if (!rc) rc = expand_narrow_tables(mode, *out, d_store, nullptr, &bad, st);
+    if (rc) {
+        (void)hipFree(buf);
+        out->base = nullptr;
+        return rc;
+    }
+    out->exact = bad == 0 ? 1 : 0;
+    return IIV_OK;
+}
+
+void free_narrow_tables(NarrowTables *nt)
+{
+    if (nt->base) (void)hipFree(const_cast<uint8_t *>(nt->base));
+    nt->base = nullptr;
 }
 
 // The halves with content innermost -- T[o][row][content part] -- for the joint content choice
@@ -790,10 +770,10 @@ int build_split_store_table(int mode, const int32_t dm[256], uint32_t *d_left, u
     return hip_check(he, "sync");
 }
 
-// for the exactness test: halves from dm, narrow form from them and d_store, every value re-read
-// through narrow_offsets into d_expanded
+// for the exactness test: the left half and the folded narrow form from dm, every value re-read the way the kernels
+// read it into d_expanded; *n_mismatch = entries that differ from d_store
 int build_narrow_store_table(int mode, const int32_t dm[256], const uint16_t *d_store, uint16_t *d_expanded,
-                             unsigned long long *n_exceptions, hipStream_t st)
+                             unsigned long long *n_mismatch, hipStream_t st)
 {
     TableScratch sc;
     int rc = prepare_scratch(mode, dm, sc, st);
@@ -804,8 +784,8 @@ int build_narrow_store_table(int mode, const int32_t dm[256], const uint16_t *d_
         if ((rc = hip_check(hipMalloc(&d_l, split_entries(mode, 0) * 4), "hipMalloc(split left)"))) break;
         if ((rc = hip_check(hipMalloc(&d_r, split_entries(mode, 1) * 4), "hipMalloc(split right)"))) break;
         if ((rc = build_split_tables(mode, sc.strings, sc.sub, d_l, d_r, st))) break;
-        if ((rc = build_narrow_tables(mode, d_l, d_r, d_store, &nt, st))) break;
-        rc = expand_narrow_tables(mode, nt, d_expanded, n_exceptions, st);
+        if ((rc = build_narrow_tables(mode, sc.strings, sc.sub, d_l, d_store, &nt, st))) break;
+        rc = expand_narrow_tables(mode, nt, d_store, d_expanded, n_mismatch, st);
     } while (0);
     free_narrow_tables(&nt);
     if (d_l) (void)hipFree(d_l);

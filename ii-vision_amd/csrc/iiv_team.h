@@ -130,20 +130,9 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
 
     const int o_e = byte_offset<MODE>(0, is_aux), o_d = byte_offset<MODE>(1, is_aux);
     // (narrow form of the split store table: see iiv_stream.h and greedy_wave_kernel)
-    constexpr int BITS = ModeTraits<MODE>::kBits, CB = ModeTraits<MODE>::kContentBits;
     const uint32_t l1_e = (uint32_t)o_e << (T::kLeftCBits + T::kLeftRowBits + 1), l1_d = (uint32_t)o_d << (T::kLeftCBits + T::kLeftRowBits + 1);
     const uint32_t r1_e = nt.right_off + ((uint32_t)o_e << (T::kRightCBits + T::kRightRowBits + 1));
     const uint32_t r1_d = nt.right_off + ((uint32_t)o_d << (T::kRightCBits + T::kRightRowBits + 1));
-    const uint32_t ds_e = nt.dense_off + ((uint32_t)o_e << (CB + BITS + 1)), ds_d = nt.dense_off + ((uint32_t)o_d << (CB + BITS + 1));
-    typedef typename std::conditional<MODE == kDHGR, uint32_t, unsigned long long>::type xmask_t;
-    const xmask_t xm_e = reinterpret_cast<const xmask_t *>(nt.xmask)[(o_e << 6) + lane];
-    const xmask_t xm_d = reinterpret_cast<const xmask_t *>(nt.xmask)[(o_d << 6) + lane];
-    auto xmask_of = [&](xmask_t v, uint32_t part) -> xmask_t {
-        if (MODE == kDHGR) return (xmask_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)part);
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)part);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)v >> 32), (int)part);
-        return (xmask_t)(((unsigned long long)hi << 32) | lo);
-    };
     const uint8_t *tgt_frames = (MODE == kDHGR && is_aux ? frames_aux : frames_main) +
                                 ((size_t)blockIdx.x * n_frames + frame) * 8192;
     const uint4 *wd_rows = reinterpret_cast<const uint4 *>(wd_lds);
@@ -184,21 +173,12 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
         const uint32_t sr_e = r1_e + (split_content_right<MODE>(c, 0) << (T::kRightRowBits + 1));
         const uint32_t sr_d = r1_d + (split_content_right<MODE>(c, 1) << (T::kRightRowBits + 1));
         const uint8_t *le = nt.base + sl_e, *ld = nt.base + sl_d, *re = nt.base + sr_e, *rd = nt.base + sr_d;
-        const uint32_t zr_e = nt.zero_off - sl_e, zr_d = nt.zero_off - sl_d;
-        const uint32_t cd = (c & ((1u << CB) - 1)) << (BITS + 1);
-        const uint32_t dr_e = ds_e + cd - sr_e, dr_d = ds_d + cd - sr_d;
-        const xmask_t me = xmask_of(xm_e, narrow_mask_content<MODE>(c, 0)), md = xmask_of(xm_d, narrow_mask_content<MODE>(c, 1));
         const uint32_t wr[4] = {w.x, w.y, w.z, w.w};
-        uint32_t ol[4], orr[4];
-        narrow_offsets<MODE, 0>(wr[0], me, zr_e, dr_e, ol[0], orr[0]);
-        narrow_offsets<MODE, 0>(wr[2], me, zr_e, dr_e, ol[2], orr[2]);
-        narrow_offsets<MODE, 1>(wr[1], md, zr_d, dr_d, ol[1], orr[1]);
-        narrow_offsets<MODE, 1>(wr[3], md, zr_d, dr_d, ol[3], orr[3]);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            L.gl[r] = *reinterpret_cast<const uint16_t *>(((r & 1) ? ld : le) + ol[r]);
-            L.gr[r] = *reinterpret_cast<const uint16_t *>(((r & 1) ? rd : re) + orr[r]);
-            L.dwm[r] = wr[r] & kWdDwMask;
+            L.gl[r] = *reinterpret_cast<const uint16_t *>(((r & 1) ? ld : le) + wd_off_left(wr[r]));
+            L.gr[r] = *reinterpret_cast<const uint16_t *>(((r & 1) ? rd : re) + wd_off_right(wr[r]));
+            L.dwm[r] = wd_dw(wr[r]) << kWdDwShift;
         }
         L.e = e | 0x80000000u;
     };
@@ -217,7 +197,7 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
         sc.C = 0;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            nd[r] = L.gl[r] + L.gr[r];
+            nd[r] = L.gl[r] + L.gr[r] - kNarrowBias;   // L1 + RF (iiv_stream.h: narrow form)
             const int d = (int)((nd[r] << kWdDwShift) | (y0 + r)) - (int)L.dwm[r];   // screen.py:547
             const int gone = __builtin_amdgcn_sbfe((int)pdw, sh0 + r, 1);
             const int live = __builtin_amdgcn_sbfe((int)nzw, sh0 + r, 1);

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void greedy_kernel(StreamState *__restrict__ s
     for (int i = tid; i < 8192; i += 256) {
         uint32_t bit = (S.nzbits[i >> 5] >> (i & 31)) & 1u;
         uint32_t dn = (S.pdone[i >> 5] >> (i & 31)) & 1u;
-        dwf[i] = (uint16_t)((dn ? 0u : (S.wd[i] >> kWdDwShift)) | (bit << 15));
+        dwf[i] = (uint16_t)((dn ? 0u : wd_dw(S.wd[i])) | (bit << 15));
     }
     for (int i = tid; i < 624; i += 256) mt[0][i] = S.mt_py[i];
     __syncthreads();
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256) void greedy_kernel(StreamState *__restrict__ s
             uint32_t v = dwf[wi * 32 + b];
             nzw |= ((v >> 15) & 1u) << b;
             // a byte whose diff weight was non-zero at the prologue and is zero now was a primary
-            if ((v & 0x7fffu) == 0 && (S.wd[wi * 32 + b] >> kWdDwShift) != 0) pdw |= 1u << b;
+            if ((v & 0x7fffu) == 0 && wd_dw(S.wd[wi * 32 + b]) != 0) pdw |= 1u << b;
         }
         S.nzbits[wi] = nzw;
         S.pdone[wi] = pdw;

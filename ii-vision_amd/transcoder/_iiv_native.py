@@ -257,9 +257,9 @@ def check_split_diff_table(mode, dm, table):
 
 
 def build_narrow_store_table(mode, dm, store):
-    """(expanded, n_exceptions): every store value as the greedy kernels obtain it from the narrow
-    form of the split table (u16 halves + exception masks + the dense table), and the number of
-    (content, window) pairs that go through the dense table."""
+    """(expanded, n_mismatch): every store value as the greedy kernels obtain it from the narrow
+    form of the split table (S = L1 + RF, two u16 tables), and the number of entries that differ
+    from `store` (0 when both come from the same dm)."""
     torch = _torch()
     dm = np.ascontiguousarray(dm, dtype=np.int32).reshape(256)
     exp = torch.empty_like(store)
@@ -368,9 +368,15 @@ class Encoder:
         """True: one wave per stream; False: one 256-thread workgroup; "team": eight waves per stream;
         "shared" / "plain": one wave per stream with / without the bank's L1 table half shared in LDS by
         the eight streams of a workgroup (True picks by batch size); None: automatic."""
-        v = {None: GREEDY_AUTO, "team": GREEDY_TEAM, "shared": GREEDY_WAVE_SHARED, "plain": GREEDY_WAVE_PLAIN}.get(
-            wave_per_stream if wave_per_stream is None or isinstance(wave_per_stream, str) else 0,
-            GREEDY_WAVE if wave_per_stream else GREEDY_WORKGROUP)
+        names = {None: GREEDY_AUTO, "auto": GREEDY_AUTO, "team": GREEDY_TEAM, "shared": GREEDY_WAVE_SHARED, "plain": GREEDY_WAVE_PLAIN,
+                 "wave": GREEDY_WAVE, "workgroup": GREEDY_WORKGROUP}
+        if wave_per_stream is None or isinstance(wave_per_stream, str):
+            if wave_per_stream not in names:
+                raise ValueError("set_greedy_kernel: unknown kernel %r (one of %s, True, False, None)"
+                                 % (wave_per_stream, ", ".join(repr(k) for k in names if k)))
+            v = names[wave_per_stream]
+        else:
+            v = GREEDY_WAVE if wave_per_stream else GREEDY_WORKGROUP
         check(lib().iiv_encoder_set_option(self._h, OPT_GREEDY_KERNEL, v))
 
     def set_prefix_sort(self, enable):

@@ -130,15 +130,16 @@ int iiv_build_split_store_table(int mode, const int32_t dm[256], uint32_t *d_lef
 size_t iiv_split_table_entries(int mode, int right_half);
 
 /* The form of the split store table the one-wave and the team greedy kernel actually read
- * (csrc/iiv_stream.h, "narrow form"): 2-byte entries l1, r1 with S = l1 + r1, and -- for the 1.6 %
- * of (content, window) pairs whose colour strings could be transposed across the cut -- the dense
- * table's own value, selected by exception masks that are built by comparing l1 + r1 with
- * d_store_table entry by entry.  This call builds that form from dm and d_store_table and writes
- * every value, obtained with the kernels' own index arithmetic, to d_expanded (same layout as
- * d_store_table: a test requires equality everywhere); *n_exceptions = pairs served by the
- * dense table. */
+ * (csrc/iiv_stream.h, "narrow form"): two 2-byte tables with S = L1 + RF, L1 = l1 and
+ * RF = min(r1, r0 - s) + bias, s = the substitution cost of the last pixel left of the cut -- the
+ * path over a transposition across the cut folded into the right half, exact for every (offset,
+ * content, window) (no exception masks, no dense copy).  This call builds that form from dm and
+ * writes every value, obtained with the kernels' own index arithmetic, to d_expanded (same layout as
+ * d_store_table); *n_mismatch = entries that differ from d_store_table (0 for a store table built
+ * from the same dm: tests).  iiv_encoder_create makes the same comparison with the store table it
+ * is given, and an encoder whose tables disagree runs the dense-table workgroup kernel only. */
 int iiv_build_narrow_store_table(int mode, const int32_t dm[256], const uint16_t *d_store_table, uint16_t *d_expanded,
-                                 unsigned long long *n_exceptions, void *stream);
+                                 unsigned long long *n_mismatch, void *stream);
 
 /* Bitmap.diff_weights' table (screen.py:343-367, 436-443) cut the same way: a diff weight is
  * min(l0 + r0, l1 + r1) of DWL[o][left row of source][left row of target] and
