@@ -64,6 +64,7 @@ struct Encoder {
     void *d_brief;                   // iiv_encoder_get_video_brief's 32 bytes
     ulonglong2 *d_strings;  // colour string of every masked value (recurrence mode)
     uint2 *d_hgr_slut;      // HGR: the three-lookup string table the prologue copies into LDS (iiv_edit.h)
+    uint32_t *d_dw_pieces;  // DHGR: the diff weights' pair-term table the prologue copies into LDS (iiv_tables.hip)
     uint16_t *d_sub;        // 16x16 substitute costs
     int dw_mode;            // IIV_DW_TABLE / IIV_DW_RECURRENCE
     int greedy_mode;        // IIV_GREEDY_WAVE / IIV_GREEDY_WORKGROUP / IIV_GREEDY_AUTO
@@ -174,6 +175,7 @@ void encoder_destroy(Encoder *e)
     if (e->d_snapshot) (void)hipFree(e->d_snapshot);
     if (e->d_strings) (void)hipFree(e->d_strings);
     if (e->d_hgr_slut) (void)hipFree(e->d_hgr_slut);
+    if (e->d_dw_pieces) (void)hipFree(e->d_dw_pieces);
     if (e->d_sub) (void)hipFree(e->d_sub);
     if (e->d_left) (void)hipFree(e->d_left);
     if (e->d_right) (void)hipFree(e->d_right);
@@ -220,6 +222,7 @@ int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, c
     e->d_states = e->d_snapshot = nullptr;
     e->d_strings = nullptr;
     e->d_hgr_slut = nullptr;
+    e->d_dw_pieces = nullptr;
     e->d_sub = nullptr;
     e->dw_mode = dm ? IIV_DW_RECURRENCE : IIV_DW_TABLE;
     e->greedy_mode = IIV_GREEDY_AUTO;
@@ -277,6 +280,7 @@ int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, c
         if (dm) {
             if ((rc = build_strings(mode, dm, &e->d_strings, &e->d_sub, 0))) break;
             if (mode == kHGR && (rc = build_hgr_string_lut(&e->d_hgr_slut, 0))) break;
+            if (mode == kDHGR && (rc = build_dw_piece_table(e->d_sub, &e->d_dw_pieces, 0))) break;
             if ((rc = hip_check(hipMalloc(&e->d_left, split_entries(mode, 0) * 4), "hipMalloc(split left)"))) break;
             if ((rc = hip_check(hipMalloc(&e->d_right, split_entries(mode, 1) * 4), "hipMalloc(split right)"))) break;
             if ((rc = build_split_tables(mode, e->d_strings, e->d_sub, e->d_left, e->d_right, 0))) break;
@@ -796,7 +800,7 @@ static int launch_round(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux,
     if (any_prologue) {
         if (e->profiling) { int prc = prof_begin(e, 0, st, slot); if (prc) return prc; }
         const PrologueArgs pa{e->d_states, d_main, d_aux, n_frames, e->n_streams, d_round, seg_stride, e->d_table, e->d_strings,
-                              e->d_sub, e->d_dwl, e->d_dwr, e->d_hgr_slut};
+                              e->d_sub, e->d_dwl, e->d_dwr, e->d_hgr_slut, e->d_dw_pieces};
         int prc2 = launch_prologue(e->mode, e->dw_mode, pa, st);
         if (prc2) return prc2;
         if (e->profiling) { int prc = prof_end(e, slot, st); if (prc) return prc; }
@@ -1083,6 +1087,14 @@ int iiv_check_split_diff_table(int mode, const int32_t dm[256], const uint16_t *
     if ((mode != IIV_HGR && mode != IIV_DHGR) || !dm || !d_table || !mismatches)
         return iiv::set_error(IIV_ERR_INVALID, "iiv_check_split_diff_table: bad argument");
     return iiv::check_split_dw_table(mode, dm, d_table, mismatches, (hipStream_t)stream);
+}
+
+int iiv_check_diff_weight_pieces(int mode, const int32_t dm[256], const uint16_t *d_table, unsigned long long *mismatches,
+                                 void *stream)
+{
+    if ((mode != IIV_HGR && mode != IIV_DHGR) || !dm || !d_table || !mismatches)
+        return iiv::set_error(IIV_ERR_INVALID, "iiv_check_diff_weight_pieces: bad argument");
+    return iiv::check_dw_piece_table(mode, dm, d_table, mismatches, (hipStream_t)stream);
 }
 
 int iiv_build_split_store_table(int mode, const int32_t dm[256], uint32_t *d_left, uint32_t *d_right,

@@ -30,6 +30,7 @@ __host__ __device__ inline uint32_t wd_word(uint32_t row_left, uint32_t row_righ
 __host__ __device__ inline uint32_t wd_dw(uint32_t wd) { return (0u - wd) & ((1u << kWdDwBits) - 1u); }   // the diff weight back
 __host__ __device__ inline uint32_t wd_off_left(uint32_t wd) { return wd >> kWdLeftShift; }
 __host__ __device__ inline uint32_t wd_off_right(uint32_t wd) { return (wd >> kWdRightShift) & 0x3ffu; }
+constexpr uint32_t kDwPieceBias = 512;   // added to every entry of the DHGR prologue's pair-term table (its terms can be negative)
 constexpr int kMaxValue = 2047;  // every table value and diff weight must fit 11 bits
 
 struct StreamState {
@@ -203,28 +204,46 @@ __device__ static inline void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// next MT19937 block, one wave, fully unrolled (constant LDS offsets, no loop counters)
+// Next MT19937 block, one wave, fully unrolled (constant LDS offsets, no loop counters).  Word i of the new block is
+// new[i - 227] ^ mix(old[i], old[i + 1]) for i >= 227: with lane l computing words l + 64 g of the first third (i < 227),
+// then 227 + l + 64 g, then 454 + l + 64 g, the new word each needs is the SAME lane's own earlier result -- a register.
+// Every LDS read is of the OLD block, all of them issued up front; the block costs one LDS turn-around (its words are the
+// next block's inputs) instead of three.  (The thirteen blocks of a prologue call took one wave 20 k cycles with a
+// write -> barrier -> read per third: longer than the rest of the workgroup needs to score.)
 __device__ static inline void mt_twist_wave(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int lane)
 {
+    auto mt_mix = [](uint32_t x, uint32_t y) -> uint32_t {   // iiv_device.h: mt_mix, its select as bit-field extract + and
+        const uint32_t v = (x & 0x80000000u) | (y & 0x7fffffffu);
+        return (v >> 1) ^ ((uint32_t)__builtin_amdgcn_sbfe(y, 0, 1) & 0x9908b0dfu);
+    };
+    uint32_t a[4], b[4], c[3];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int i = lane + 64 * k;
-        if (k < 3 || i < 227) dst[i] = src[i + 397] ^ mt_mix(src[i], src[i + 1]);
-    }
-    wave_lds_sync();
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int i = 227 + lane + 64 * k;
-        if (k < 3 || i < 454) dst[i] = dst[i - 227] ^ mt_mix(src[i], src[i + 1]);
-    }
-    wave_lds_sync();
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int i = 454 + lane + 64 * k;
-        if (k < 2 || i < 624) {
-            const uint32_t nx = (i == 623) ? dst[0] : src[i + 1];
-            dst[i] = dst[i - 227] ^ mt_mix(src[i], nx);
+    for (int g = 0; g < 4; g++) {
+        const int j = lane + 64 * g;
+        a[g] = b[g] = 0;
+        if (g < 3 || j < 227) {
+            a[g] = src[j + 397] ^ mt_mix(src[j], src[j + 1]);
+            b[g] = a[g] ^ mt_mix(src[227 + j], src[228 + j]);
         }
+    }
+    const uint32_t new0 = (uint32_t)__builtin_amdgcn_readlane((int)a[0], 0);   // "old[624]" of word 623 is the new word 0
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+        const int j = lane + 64 * g;
+        c[g] = 0;
+        if (g < 2 || j < 170) {
+            const uint32_t nx = (g == 2 && j == 169) ? new0 : src[(g == 2 && j == 169) ? 0 : 455 + j];
+            c[g] = b[g] ^ mt_mix(src[454 + j], nx);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const int j = lane + 64 * g;
+        if (g < 3 || j < 227) {
+            dst[j] = a[g];
+            dst[227 + j] = b[g];
+        }
+        if (g < 2 || (g == 2 && j < 170)) dst[454 + j] = c[g];
     }
     wave_lds_sync();
 }
@@ -266,6 +285,7 @@ struct PrologueArgs {
     const uint16_t *sub;            // 16 x 16 substitution costs
     const uint32_t *dwl, *dwr;      // split diff-weight table (IIV_DW_SPLIT)
     const uint2 *hgr_slut;          // HGR: three-lookup string table
+    const uint32_t *dw_pieces;      // DHGR: the diff weights' pair terms, [2 banks][4096] (iiv_tables.hip: dw_piece_kernel)
 };
 int launch_prologue(int mode, int dw_mode, const PrologueArgs &a, hipStream_t st);
 struct WorkgroupArgs {

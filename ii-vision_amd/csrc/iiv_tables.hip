@@ -583,6 +583,102 @@ int build_hgr_string_lut(uint2 **d_out, hipStream_t st)
     return hip_check(hipGetLastError(), "hgr_string_lut_kernel launch");
 }
 
+// ------------------------------------------------------------------ diff weights as a sum of local terms (DHGR prologue)
+// The recurrence E[k] = min(E[k-1] + s_k, E[k-2] + 1 if pixels (k-1, k) transpose) (make_data_tables.py:92-108; iiv_edit.h)
+// collapses to a SUM for the strings it is applied to.  A colour string is a sliding 4-dot window, so a_{k-1}, a_k, a_{k+1}
+// cannot be X, Y, X with X != Y (the step k-1 -> k replaces the dot of one position class, the step k -> k+1 that of the
+// next): two transpositions never overlap, E[k-1] = E[k-2] + s_{k-1} wherever pixels (k-1, k) transpose, and
+//     distance = sum over k of g_k,    g_k = s_k, or min(s_k, 1 - s_{k-1}) where pixels (k-1, k) transpose.
+// g_k depends on dots k-1 .. k+3 of both windows, so two pixels' terms are one lookup by 6 + 6 dots -- five lookups and
+// five additions per DHGR distance instead of ten dependent steps of the recurrence.  (Checked against the recurrence for
+// every pair of windows: iiv_check_dw_piece_table / tests/test_gpu_tables.py, both palettes and random matrices.)
+// Table: G[bank][cur6 << 6 | tgt6] = (g-sum of the pixel pair with rotation ph_e) | (... with rotation ph_e + 2) << 16, each
+// plus kDwPieceBias; ph_e = the phase of the bank's even bytes (its odd bytes' differs by 2), bit j of cur6 / tgt6 = dot
+// k - 1 + j, the pair being pixels (k, k + 1).  A window's dot -1 is 0 in both strings, which makes the term a pixel -1
+// would contribute vanish (a transposition of pixels (-1, 0) then needs equal colours all round).
+__global__ __launch_bounds__(256) void dw_piece_kernel(const uint16_t *__restrict__ sub, uint32_t *__restrict__ out)
+{
+    __shared__ uint16_t lut[256];
+    load_cost_lut(lut, sub, threadIdx.x);
+    __syncthreads();
+    const int idx = blockIdx.x * 256 + threadIdx.x;   // bank << 12 | cur6 << 6 | tgt6
+    if (idx >= 2 * 4096) return;
+    const int bank = idx >> 12;
+    const uint32_t cur6 = (idx >> 6) & 63u, tgt6 = idx & 63u;
+    const int ph_e = phase_of(kDHGR, byte_offset<kDHGR>(0, bank));
+    uint32_t v = 0;
+    for (int c = 0; c < 2; c++) {
+        const int r = (ph_e + 2 * c) & 3;   // rotation of pixel k; k - 1 has r - 1, k + 1 has r + 1 (colours.py:100-134)
+        int a[3], b[3];
+        for (int j = 0; j < 3; j++) {
+            const int rot = (r - 1 + j) & 3;
+            const uint32_t wa = (cur6 >> j) & 0xfu, wb = (tgt6 >> j) & 0xfu;
+            a[j] = (int)(((wa | (wa << 4)) >> (4 - rot)) & 0xfu);
+            b[j] = (int)(((wb | (wb << 4)) >> (4 - rot)) & 0xfu);
+        }
+        int s[3];
+        for (int j = 0; j < 3; j++) s[j] = (int)lut[a[j] * 16 + b[j]];
+        int g = 0;
+        for (int j = 1; j < 3; j++) {
+            const bool t = a[j - 1] == b[j] && a[j] == b[j - 1];
+            g += (t && 1 - s[j - 1] < s[j]) ? 1 - s[j - 1] : s[j];
+        }
+        v |= (uint32_t)(g + (int)kDwPieceBias) << (16 * c);
+    }
+    out[idx] = v;
+}
+
+int build_dw_piece_table(const uint16_t *d_sub, uint32_t **d_out, hipStream_t st)
+{
+    IIV_HIP(hipMalloc(d_out, 2 * 4096 * sizeof(uint32_t)));
+    hipLaunchKernelGGL(dw_piece_kernel, dim3(32), dim3(256), 0, st, d_sub, *d_out);
+    return hip_check(hipGetLastError(), "dw_piece_kernel launch");
+}
+
+// every entry of the full symmetric DHGR table against the sum of its five pair terms, read the way the prologue reads them
+__global__ __launch_bounds__(256) void dw_piece_check_kernel(const uint32_t *__restrict__ pieces, const uint16_t *__restrict__ table,
+                                                             unsigned long long *__restrict__ mismatches)
+{
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;   // ((o << 13) + current) << 13) + target
+    if (idx >= ((size_t)4 << 26)) return;
+    const uint32_t tm = idx & 8191u, cm = (idx >> 13) & 8191u;
+    const int o = (int)(idx >> 26), parity = o >> 1, is_aux = (o & 1) ? 0 : 1;   // byte_offset<kDHGR>: aux 0 / 2, main 1 / 3
+    const uint32_t W = (cm << 17) | (tm << 1);
+    const unsigned char *g = reinterpret_cast<const unsigned char *>(pieces + 4096 * is_aux);
+    uint32_t acc = 0;
+    for (int i = 0; i < 5; i++) {
+        const uint32_t cur6 = (W >> (16 + 2 * i)) & 63u, tgt6 = ((W << 2) >> (2 * i)) & 0xfcu;   // (as the prologue forms them)
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(g + ((cur6 << 8) | tgt6));
+        acc += ((i + parity) & 1) ? v >> 16 : v & 0xffffu;
+    }
+    if (acc - 5u * kDwPieceBias != (uint32_t)table[idx]) atomicAdd(mismatches, 1ull);
+}
+
+int check_dw_piece_table(int mode, const int32_t dm[256], const uint16_t *d_table, unsigned long long *mismatches, hipStream_t st)
+{
+    if (mode != kDHGR) return set_error(IIV_ERR_INVALID, "the pair-term table exists for DHGR only");
+    uint16_t sub[256], *d_sub = nullptr;
+    uint32_t *d_p = nullptr;
+    unsigned long long *d_cnt = nullptr;
+    substitute_costs(dm, sub);
+    int rc = IIV_OK;
+    do {
+        if ((rc = hip_check(hipMalloc(&d_sub, sizeof(sub)), "hipMalloc(sub)"))) break;
+        if ((rc = hip_check(hipMemcpy(d_sub, sub, sizeof(sub), hipMemcpyHostToDevice), "copy sub"))) break;
+        if ((rc = hip_check(hipMalloc(&d_cnt, 8), "hipMalloc(count)"))) break;
+        if ((rc = hip_check(hipMemsetAsync(d_cnt, 0, 8, st), "memset"))) break;
+        if ((rc = build_dw_piece_table(d_sub, &d_p, st))) break;
+        hipLaunchKernelGGL(dw_piece_check_kernel, dim3((unsigned)(((size_t)4 << 26) / 256)), dim3(256), 0, st, d_p, d_table, d_cnt);
+        if ((rc = hip_check(hipGetLastError(), "dw_piece_check_kernel launch"))) break;
+        if ((rc = hip_check(hipMemcpyAsync(mismatches, d_cnt, 8, hipMemcpyDeviceToHost, st), "copy count"))) break;
+        rc = hip_check(hipStreamSynchronize(st), "sync");
+    } while (0);
+    if (d_sub) (void)hipFree(d_sub);
+    if (d_p) (void)hipFree(d_p);
+    if (d_cnt) (void)hipFree(d_cnt);
+    return rc;
+}
+
 struct TableScratch {
     ulonglong2 *strings = nullptr;
     uint16_t *sub = nullptr;

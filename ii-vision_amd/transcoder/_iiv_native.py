@@ -45,6 +45,7 @@ SYMBOLS = [
     "iiv_encoder_check", "iiv_encoder_profile", "iiv_encoder_profile_read", "iiv_encoder_input_stats",
     "iiv_build_split_store_table", "iiv_split_table_entries", "iiv_check_split_diff_table",
     "iiv_build_narrow_store_table",
+    "iiv_check_diff_weight_pieces",
     "iiv_emit_stream", "iiv_emit_chunk", "iiv_frames_to_memory_maps",
 ]
 
@@ -135,6 +136,8 @@ def lib():
     L.iiv_split_table_entries.restype = sz
     L.iiv_check_split_diff_table.argtypes = [i32, vp, vp, vp, vp]
     L.iiv_build_narrow_store_table.argtypes = [i32, vp, vp, vp, vp, vp]
+    if hasattr(L, "iiv_check_diff_weight_pieces") or "IIV_LIB" not in os.environ:   # (IIV_LIB: A/B runs against older builds, tools/ab_libs.sh)
+        L.iiv_check_diff_weight_pieces.argtypes = [i32, vp, vp, vp, vp]
     L.iiv_split_table_entries.argtypes = [i32, i32]
     L.iiv_encoder_check.argtypes = [vp, C.POINTER(i32), vp]
     L.iiv_encoder_profile.argtypes = [vp, i32]
@@ -253,6 +256,15 @@ def check_split_diff_table(mode, dm, table):
     dm = np.ascontiguousarray(dm, dtype=np.int32).reshape(256)
     n = C.c_ulonglong(0)
     check(lib().iiv_check_split_diff_table(mode, hptr(dm), dptr(table), C.byref(n), stream_ptr()))
+    return int(n.value)
+
+
+def check_diff_weight_pieces(mode, dm, table):
+    """Entries of the full symmetric table that differ from the sum of pixel-pair terms the DHGR prologue
+    evaluates instead of the recurrence (include/iivision.h: iiv_check_diff_weight_pieces)."""
+    dm = np.ascontiguousarray(dm, dtype=np.int32).reshape(256)
+    n = C.c_ulonglong(0)
+    check(lib().iiv_check_diff_weight_pieces(mode, hptr(dm), dptr(table), C.byref(n), stream_ptr()))
     return int(n.value)
 
 
