@@ -44,6 +44,7 @@ for _p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "ii-vision_amd
 OPS_PER_FRAME = 490                # 14700 Hz / 30 fps (video.py:31-33)
 BYTES_PER_OPCODE = 534             # 256 x 2 B gathers + 6 B out + 2 x 8 B packed RMW
 BYTES_PER_PROLOGUE = 147456        # 2 x 32 KiB packed + 16 KiB gathers + 64 KiB priority r/w
+BYTES_PER_FRAME = {"DHGR": 657e3, "HGR": 409e3}   # (1 + 490/292) calls + 490 opcodes / 1 call + 490 opcodes
 GATHER_CEILING_GLOADS_HGR = 995.0    # tools/gather_ceiling D 14336 HGR (3.61 ms per launch of 490 opcodes)
 GATHER_CEILING_GLOADS = 1184.2   # tools/gather_ceiling.hip, variant D (profiles/r02l_gather_ceiling.txt)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
@@ -97,6 +98,7 @@ def parse_args(argv=None):
                     help="NTSC (main.py's default) or IIGS = the //gs RGB palette of BASELINE config 5")
     ap.add_argument("--coherent", action="store_true", help="S-coh input instead of S-iid")
     ap.add_argument("--img", action="store_true", help="S-img input (dithered moving bars) instead of S-iid")
+    ap.add_argument("--img-distinct", type=int, default=0, help="with --img: render this many distinct clips and tile them over the streams (0 = all distinct)")
     ap.add_argument("--static", action="store_true",
                     help="S-static input: converging content -- every frame is the previous one with 2 %% of its bytes redrawn "
                          "(with --repeat N, every drawn frame is shown N times): the work list runs dry, the re-queued bag "
@@ -246,7 +248,15 @@ class GpuBackend:
     def make_clips(self, S, n_frames, seed):
         a = self.args
         if a.img:
-            self.fm, self.fa = self.sb.synth_frames_img(S, n_frames, self.dhgr, seed=seed)
+            # (the generator renders every frame of every clip as a (S, 192, 560) field: a bounded number of distinct clips,
+            # tiled over the streams -- each stream still has its own RNG seeds, i.e. its own tie-breaking)
+            distinct = min(S, getattr(a, "img_distinct", 0) or S)
+            fm, fa = self.sb.synth_frames_img(distinct, n_frames, self.dhgr, seed=seed)
+            if distinct < S:
+                reps = -(-S // distinct)
+                fm = fm.repeat((reps, 1, 1, 1))[:S].contiguous()
+                fa = fa.repeat((reps, 1, 1, 1))[:S].contiguous() if fa is not None else None
+            self.fm, self.fa = fm, fa
         else:
             self.fm, self.fa = self.sb.synth_frames_torch(S, n_frames, self.dhgr, seed=seed, coherent=a.coherent or a.static,
                                                           keep=0.98 if a.static else 0.9, repeat=a.repeat if a.static else 1)
@@ -288,6 +298,10 @@ class GpuBackend:
 
     def profile_read(self):
         return self.batch.enc.profile_read()
+
+    def launch_forms(self):
+        """greedy launches of the timed region by kernel form (iiv_encoder_launch_forms)"""
+        return self.batch.enc.launch_forms()
 
     def input_stats(self):
         """(share of the steps the nonces decided, form of the one-wave kernel the encoder has settled on) -- the encoder
@@ -331,7 +345,12 @@ def main(argv=None, backend_cls=None):
     n_gpus = max(world, 1)
     dhgr = args.mode == "DHGR"
     F = args.frames_per_step
-    n_frames = args.steps * F          # resident clip length = the timed region (warm-up wraps, GpuBackend.step)
+    # resident clip length = the timed region: the warm-up runs on its first frames and the timed steps wrap around (every
+    # frame encoded exactly once in the timed region).  Frame 0 after the last frame is an UNRELATED picture, which is what
+    # S-iid and S-img frames are to each other anyway; for S-coh / S-static that wrap would put one complete redraw into the
+    # timed region, so those clips are as long as warm-up + timed region and never wrap.
+    wraps = not (args.coherent or args.static)
+    n_frames = args.steps * F if wraps else (args.steps + args.warmup) * F
     S = args.streams
     if S <= 0:
         per_clip = n_frames * 8192 * (2 if dhgr else 1) + 260 * 1024 + F * OPS_PER_FRAME * 6   # frames + stream state + opcodes
@@ -397,10 +416,16 @@ def main(argv=None, backend_cls=None):
                 "real_opcodes_per_stream_and_launch": round(be.batch.enc.real_opcodes_per_launch, 1)}
                if hasattr(be, "input_stats") and be.uses_wave_kernel() else {}),
             "frames_per_step": F,
+            "resident_clip_frames": n_frames,
+            "clip_wraps_in_timed_region": bool(wraps and args.warmup > 0),
             "opcodes_per_frame": OPS_PER_FRAME,
             "parallelism": "%d GPU x %d independent streams, no collective" % (n_gpus, S),
         },
         "opcodes_per_s": fps * OPS_PER_FRAME,
+        # SURVEY 8(d)'s whole-pipeline figure: frames/s x algorithmic bytes per frame (prologue calls + opcodes) against the HBM peak
+        "pipeline_roofline": {"bound": "hbm", "bytes_per_frame": BYTES_PER_FRAME[args.mode],
+                              "achieved": fps / n_gpus * BYTES_PER_FRAME[args.mode] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": fps / n_gpus * BYTES_PER_FRAME[args.mode] / 1e9 / HBM_PEAK_GBS, "per": "GPU"},
         "diff_weights": "table-gather" if args.dw_table or args.dw == "table" else args.dw,
         "table_build_s": t_tab,
     }
@@ -430,6 +455,8 @@ def main(argv=None, backend_cls=None):
             out["dropin"] = _dropin_video(args)
             if dhgr and not args.joint and not args.fourth:   # SURVEY 8(d) M1 "plus HGR frames/s": a short HGR leg with its own tables and clips
                 out["hgr"] = _hgr_leg(be, args, local_rank, world)
+                if not args.img:   # picture-like input (S-img): what the product encodes, and the slowest input -- its own short leg
+                    out["img"] = _hgr_leg(be, args, local_rank, world, steps=4, mode="DHGR", img=True)
                 out["fourth_offset"] = _hgr_leg(be, args, local_rank, world, steps=4, mode="DHGR", fourth=True)
 
         print(json.dumps(out))
@@ -533,33 +560,31 @@ def _roofline_objects(be, args, prof, op_count, seg_count, S, elapsed, live_ceil
         "avg_launch_ms": g_ms / g_n,
         "launches": prof["greedy_launches"],
         "lookups_per_s": float(op_count) * S * 256 / (g_ms * 1e-3) if g_ms > 0 else 0.0,
+        # HBM bytes the counters saw (committed run) per launch / this run's launch time, against the peak: how busy HBM really is
+        "traffic_frac": (traffic / (g_ms / g_n * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and g_ms > 0) else None,
+        "launches_by_form": be.launch_forms() if hasattr(be, "launch_forms") else None,
     }
     if getattr(args, "static", False):
         out["roofline"]["note"] = ("S-static: most opcodes are out-of-work padding (video.py:249-251), written 64 at a time without "
                                    "any scoring; they are counted at 534 B like real opcodes here, so achieved / frac overstate the kernel")
     if be.uses_wave_kernel():
-        # The bound that actually holds this kernel is not HBM but the L1's rate for divergent loads.
-        # Its yardstick is a measurement, not a datasheet figure: tools/gather_ceiling.hip runs the
-        # kernel's access pattern (a streamed 1 KiB row + 8 divergent table loads per opcode, narrow
-        # form: 2-byte slices + 1 lane in 64 into the dense table) with no arithmetic at all.
+        # A measured yardstick beside the datasheet one: tools/gather_ceiling.hip runs a step's ACCESS PATTERN -- a streamed
+        # 1 KiB row + 8 divergent 2-byte table loads per opcode -- with no arithmetic at all.  It is a reference pattern, not a
+        # ceiling (the kernel's LDS-shared form does some of those loads from LDS and can exceed it): no `peak`, no `frac`.
         loads = float(op_count) * S * 512 / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
         form = be.input_stats()[1] if hasattr(be, "input_stats") else "plain"   # what the encoder settled on for this input
-        hgr_shared = args.mode == "HGR" and form == "shared"
-        peak, src = _gather_ceiling_live(S, args.mode, hgr_shared) if live_ceiling else (None, None)
-        if peak is None and args.mode == "HGR":
-            peak, src = GATHER_CEILING_GLOADS_HGR, "tools/gather_ceiling D 14336 HGR, a run on an MI355X committed as a constant, not this run"
-        if peak is None:
-            peak, src = GATHER_CEILING_GLOADS, ("profiles/r02l_gather_ceiling.txt, variant D at 12288 waves (0.972 ms per "
-                                                "launch): a committed microbenchmark run on an MI355X, not this run")
-        out["roofline_access_pattern"] = {
-            "kernel": "greedy_wave_kernel", "bound": "l1 divergent loads",
-            "achieved": loads, "peak": peak, "unit": "G table loads/s", "frac": loads / peak, "peak_source": src,
-            "kernel_form": form,
+        ref, src = _gather_ceiling_live(S, args.mode, False) if live_ceiling else (None, None)
+        if ref is None:
+            ref, src = ((GATHER_CEILING_GLOADS_HGR, "tools/gather_ceiling D 14336 HGR, a run on an MI355X committed as a constant, not this run")
+                        if args.mode == "HGR" else
+                        (GATHER_CEILING_GLOADS, "profiles/r02l_gather_ceiling.txt, variant D at 12288 waves: a committed microbenchmark run, not this run"))
+        out["access_pattern_reference"] = {
+            "kernel": "greedy_wave_kernel", "kernel_form": form, "unit": "G table loads/s",
+            "kernel_loads_per_s": loads, "reference_pattern_loads_per_s": ref, "kernel_over_reference": loads / ref,
+            "reference_source": src,
+            "note": "the reference is the step's bare access pattern with every load served by the L1 / TA (no arithmetic); it is a "
+                    "measured yardstick, not an upper bound",
         }
-        if form == "shared" and args.mode != "HGR":
-            out["roofline_access_pattern"]["note"] = ("the kernel ran its LDS-shared form (four of the eight table loads per opcode come from "
-                                                      "LDS); the ceiling quoted is that of the plain form's pattern (variant D: all eight from "
-                                                      "the L1), measured in this run -- variant E's is ~25 % higher (profiles/r03_gather_ceiling.txt)")
     pro_bytes = float(seg_count) * S * BYTES_PER_PROLOGUE
     out["roofline_prologue"] = {
         "kernel": "prologue_kernel",
@@ -570,11 +595,12 @@ def _roofline_objects(be, args, prof, op_count, seg_count, S, elapsed, live_ceil
         "avg_launch_ms": p_ms / p_n,
         "launches": prof["prologue_launches"],
     }
+    out["roofline_prologue"]["frac"] = out["roofline_prologue"]["achieved"] / HBM_PEAK_GBS
     out["kernel_time_share"] = {"greedy": g_ms / (1000 * elapsed), "prologue": p_ms / (1000 * elapsed)}
     return out
 
 
-def _hgr_leg(be, args, local_rank, world, steps=6, warmup=1, mode="HGR", fourth=False):
+def _hgr_leg(be, args, local_rank, world, steps=6, warmup=1, mode="HGR", fourth=False, img=False):
     """HGR frames/s (BASELINE config 3's workload) in the default line: the DHGR leg's clips and tables are
     released, HGR tables are built and `steps` x 50 frames of as many HGR S-iid clips are encoded the same way.
     (mode="DHGR", fourth=True: the same short leg for f4's fourth offset per opcode -- not the reference's stream.)"""
@@ -589,6 +615,7 @@ def _hgr_leg(be, args, local_rank, world, steps=6, warmup=1, mode="HGR", fourth=
     be.torch.cuda.empty_cache()
     a2 = copy.copy(args)
     a2.mode, a2.steps, a2.warmup, a2.fourth = mode, steps, warmup, fourth
+    a2.img, a2.coherent, a2.static, a2.img_distinct = img, False, False, 2048
     h = GpuBackend(a2, local_rank, world)
     h.build_tables()
     n_frames = steps * a2.frames_per_step
@@ -598,8 +625,14 @@ def _hgr_leg(be, args, local_rank, world, steps=6, warmup=1, mode="HGR", fourth=
     fps = steps * a2.frames_per_step * S / leg["elapsed"]
     out = {"metric": "%s frames transcoded/sec" % mode, "value": fps, "unit": "frames/s", "steps": steps, "warmup": warmup,
            "ms_per_step": 1000.0 * leg["elapsed"] / steps,
-           "workload": "%s NTSC palette S-iid synthetic clips, %d independent clips x %d frames, Movie.encode "
-                       "control flow (490 opcodes/frame)" % (mode, S, n_frames)}
+           "workload": "%s NTSC palette S-%s synthetic clips, %d independent clips x %d frames, Movie.encode "
+                       "control flow (490 opcodes/frame)%s" % (mode, "img" if img else "iid", S, n_frames,
+                                                                " (2048 distinct picture-like clips tiled over the streams, every "
+                                                                "stream with its own RNG seeds)" if img and S > 2048 else "")}
+    if h.uses_wave_kernel():
+        share, form = h.input_stats()
+        out["nonce_decided_share_of_steps"] = round(share, 4)
+        out["greedy_form"] = form
     if fourth:
         o = leg["first_ops"].cpu().numpy().reshape(-1, 6)[:, 2:6]
         o.sort(axis=1)

@@ -101,6 +101,7 @@ struct Encoder {
     std::vector<int> ev_class;  // class of interval i = events [2i, 2i+1]
     double ms[2];
     int64_t launches[2];
+    int64_t form_launches[4];   // greedy launches since profiling was switched on: one-wave plain / LDS-shared, team, workgroup
 };
 
 static void seed_by_array(uint32_t mt[624], const uint32_t *key, int n)
@@ -251,6 +252,7 @@ int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, c
     e->profiling = 0;
     e->ms[0] = e->ms[1] = 0;
     e->launches[0] = e->launches[1] = 0;
+    e->form_launches[0] = e->form_launches[1] = e->form_launches[2] = e->form_launches[3] = 0;
     uint32_t *d_rng0 = nullptr;
     int rc = IIV_OK;
     do {
@@ -602,8 +604,26 @@ int encoder_profile(Encoder *e, int enable)
         e->ev_class.clear();
         e->ms[0] = e->ms[1] = 0;
         e->launches[0] = e->launches[1] = 0;
+        e->form_launches[0] = e->form_launches[1] = e->form_launches[2] = e->form_launches[3] = 0;
     }
     return IIV_OK;
+}
+
+int encoder_launch_forms(Encoder *e, int64_t counts[4])
+{
+    if (!e || !counts) return set_error(IIV_ERR_INVALID, "launch_forms: bad argument");
+    for (int k = 0; k < 4; k++) counts[k] = e->form_launches[k];
+    return IIV_OK;
+}
+
+// do the kernels' tie statistics decide anything for this encoder?  (only a batch that fills the GPU with the one-wave
+// kernel in its automatic form choice: a single-clip Video, a forced form, the team and the workgroup kernel ignore them,
+// and their launches should not pay for counters, a reduction launch and a copy per call)
+static bool tie_stats_wanted(const Encoder *e)
+{
+    return e->d_left && e->nt.exact && (e->greedy_mode == IIV_GREEDY_AUTO || e->greedy_mode == IIV_GREEDY_WAVE) &&
+           e->content_choice == IIV_CONTENT_TARGET &&
+           e->n_streams >= (e->mode == kHGR ? kSharedHgrMinStreams : kSharedDhgrMinStreams);
 }
 
 // the form of the one-wave kernel the next launch of a full batch runs (launch_round)
@@ -780,7 +800,7 @@ static void tie_stats_poll(Encoder *e)
 // ... and ask for the counters as this call leaves them (asynchronous; one copy in flight at a time)
 static int tie_stats_request(Encoder *e, hipStream_t st)
 {
-    if (!e->d_tie_stats || e->tie_copy_pending) return IIV_OK;
+    if (!e->d_tie_stats || e->tie_copy_pending || !tie_stats_wanted(e)) return IIV_OK;
     IIV_HIP(hipMemsetAsync(e->d_tie_stats, 0, 3 * sizeof(unsigned long long), st));
     const int blocks = e->n_streams < 64 * 256 ? (e->n_streams + 255) / 256 : 64;
     hipLaunchKernelGGL(tie_stats_kernel, dim3(blocks), dim3(256), 0, st, e->d_states, e->n_streams, e->d_tie_stats);
@@ -828,14 +848,17 @@ static int launch_round(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux,
                      // kernels have reported input on which the plain form is the faster one (kTieHeavyPercent; until they
                      // have reported: HGR shared, DHGR plain -- the better guess for each)
                      shared_form_now(e),
-                     d_queue, e->fourth_offset != 0, e->d_tie_stats != nullptr};
+                     d_queue, e->fourth_offset != 0, e->d_tie_stats != nullptr && tie_stats_wanted(e)};
         int rc = use_team ? launch_greedy_team(e->mode, a, st) : launch_greedy_wave(e->mode, a, st);
         if (rc) return rc;
+        if (e->profiling)   // (what launch_greedy_wave runs: the shared form needs one bank per round and the stream counter)
+            e->form_launches[use_team ? 2 : (a.shared && a.uniform_bank >= 0 && a.queue && a.lds_pad == 0) ? 1 : 0]++;
     } else {
         const WorkgroupArgs wa{e->d_states, d_main, d_aux, n_frames, e->n_streams, d_round, seg_stride, e->d_store, e->d_left_t,
                                e->d_right_t, d_ops, ops_stride};
         int wrc = launch_greedy_workgroup(e->mode, e->content_choice == IIV_CONTENT_JOINT, wa, st);
         if (wrc) return wrc;
+        if (e->profiling) e->form_launches[3]++;
     }
     if (e->profiling) { int prc = prof_end(e, slot, st); if (prc) return prc; }
     return IIV_OK;
@@ -1073,6 +1096,12 @@ int iiv_encoder_profile_read(iiv_encoder *enc, double ms[2], int64_t launches[2]
 {
     if (!enc) return iiv::set_error(IIV_ERR_INVALID, "null encoder");
     return iiv::encoder_profile_read(enc->impl, ms, launches);
+}
+
+int iiv_encoder_launch_forms(iiv_encoder *enc, int64_t counts[4])
+{
+    if (!enc) return iiv::set_error(IIV_ERR_INVALID, "null encoder");
+    return iiv::encoder_launch_forms(enc->impl, counts);
 }
 
 int iiv_encoder_input_stats(iiv_encoder *enc, double stats[2], int *form)

@@ -43,6 +43,7 @@ SYMBOLS = [
     "iiv_encoder_get_video_brief",
     "iiv_encode", "iiv_encode_streams",
     "iiv_encoder_check", "iiv_encoder_profile", "iiv_encoder_profile_read", "iiv_encoder_input_stats",
+    "iiv_encoder_launch_forms",
     "iiv_build_split_store_table", "iiv_split_table_entries", "iiv_check_split_diff_table",
     "iiv_build_narrow_store_table",
     "iiv_check_diff_weight_pieces",
@@ -148,7 +149,11 @@ def lib():
     L.iiv_emit_chunk.argtypes = [i32, i32, C.c_long, C.c_long, vp, sz, vp, sz, i32, vp, C.c_uint16, vp, sz,
                                  C.POINTER(sz), C.POINTER(sz), vp, vp]
     L.iiv_frames_to_memory_maps.argtypes = [i32, vp, i32, vp, i32, vp, vp, vp]
+    if hasattr(L, "iiv_encoder_launch_forms") or "IIV_LIB" not in os.environ:
+        L.iiv_encoder_launch_forms.argtypes = [vp, C.POINTER(C.c_int64)]
     for name in SYMBOLS:
+        if "IIV_LIB" in os.environ and name in ("iiv_encoder_launch_forms", "iiv_check_diff_weight_pieces") and not hasattr(L, name):
+            continue   # (an older build under IIV_LIB: tools/ab_libs.sh)
         getattr(L, name)  # AttributeError if the library lacks a declared symbol
     _lib = L
     return L
@@ -376,6 +381,11 @@ class Encoder:
         check(lib().iiv_encoder_create(mode, dptr(table), dptr(store_table), dmp, self.n_streams, C.byref(h)))
         self._h = h
 
+    @property
+    def handle(self):
+        """The iiv_encoder* as an int: what torch.ops.iivision.encode / encode_streams take (torch_ops.py)."""
+        return int(self._h.value)
+
     def set_greedy_kernel(self, wave_per_stream):
         """True: one wave per stream; False: one 256-thread workgroup; "team": eight waves per stream;
         "shared" / "plain": one wave per stream with / without the bank's L1 table half shared in LDS by
@@ -536,6 +546,14 @@ class Encoder:
         n = (C.c_int64 * 2)()
         check(lib().iiv_encoder_profile_read(self._h, ms, n))
         return {"prologue_ms": ms[0], "greedy_ms": ms[1], "prologue_launches": n[0], "greedy_launches": n[1]}
+
+    def launch_forms(self):
+        """Greedy launches since profile(True) by kernel: {"plain", "shared", "team", "workgroup"} (iiv_encoder_launch_forms)."""
+        if not hasattr(lib(), "iiv_encoder_launch_forms"):   # (an older build under IIV_LIB, tools/ab_libs.sh)
+            return None
+        c = (C.c_int64 * 4)()
+        check(lib().iiv_encoder_launch_forms(self._h, c))
+        return {"plain": int(c[0]), "shared": int(c[1]), "team": int(c[2]), "workgroup": int(c[3])}
 
     def input_stats(self):
         """(share of the steps the nonces decided, as the kernels reported it for an earlier call; the form of the one-wave

@@ -193,13 +193,17 @@ def synth_frames_img(n_streams, n_frames, dhgr, seed, device="cuda"):
 class StreamBatch:
     """S independent video.Video encoders advanced in lock step on one GPU."""
 
-    def __init__(self, mode, table, store_table, n_streams, seeds=None, dm=None, joint_content=False, fourth_offset=False, **clock_kw):
+    def __init__(self, mode, table, store_table, n_streams, seeds=None, dm=None, joint_content=False, fourth_offset=False,
+                 use_torch_ops=True, **clock_kw):
         """joint_content=True: the content byte of every step is chosen jointly with its extra
         offsets (reference README.md:212-215, include/iivision.h IIV_CONTENT_JOINT) -- better
         pictures per opcode, NOT the reference's opcode stream.  fourth_offset=True: every opcode stores at
         up to four distinct offsets instead of three and a repeat (IIV_OPT_FOURTH_OFFSET) -- likewise."""
         self.mode = mode
         self.n_streams = int(n_streams)
+        # the launches go through torch.ops.iivision.encode (torch_ops.py: the C ABI registered as PyTorch custom operators);
+        # use_torch_ops=False calls the same C entry point through ctypes directly -- same kernels, same bytes (tests)
+        self.use_torch_ops = bool(use_torch_ops)
         self.enc = native.Encoder(mode, table, store_table, self.n_streams, dm=dm)
         if joint_content:
             self.enc.set_content_choice(True)
@@ -238,7 +242,12 @@ class StreamBatch:
         frames_*[:, f % clip length] (the returned segments keep the movie's frame numbers)."""
         segs = self.clock.segments(n_video_frames, max_ticks=max_ticks)
         n = int(frames_main.shape[1])
-        ops = self.enc.encode(frames_main, frames_aux, [(f % n, a, r, k) for (f, a, r, k) in segs] if loop else segs, ops_out)
+        plan = [(f % n, a, r, k) for (f, a, r, k) in segs] if loop else segs
+        if self.use_torch_ops:
+            import torch_ops
+            ops = torch_ops.encode_via_op(self.enc, frames_main, frames_aux, plan, ops_out)
+        else:
+            ops = self.enc.encode(frames_main, frames_aux, plan, ops_out)
         return ops, segs
 
     def close(self):

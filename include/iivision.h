@@ -203,9 +203,12 @@ void iiv_encoder_destroy(iiv_encoder *enc);
                                  *   off a queue and share a part of the narrow split store table in LDS -- DHGR: eight streams,
                                  *   both L1 halves of their bank (four of a step's eight table loads become ds_read_u16; needs
                                  *   every stream of a launch on the same bank); HGR: sixteen streams, the even bytes' L1 half
-                                 *   (two of eight).  Same output.  HGR's step is bound by its table loads and gains 6.5 %:
-                                 *   WAVE / AUTO use this form for HGR from 4096 streams on.  DHGR's step is bound by
-                                 *   instruction issue and gains nothing: there it runs only on request */
+                                 *   (two of eight).  Same output.  WAVE / AUTO choose between this form and the plain one
+                                 *   themselves, by what the kernels report about the input: batches that fill the GPU (>= 2048
+                                 *   DHGR / 4096 HGR streams) run the shared form unless the nonces decide more than 30 % of the
+                                 *   steps (picture-like input: the plain form's 28 waves per CU hide the exact-nonce path
+                                 *   better) or the streams emit fewer than 96 real opcodes per launch; until the first report
+                                 *   HGR starts shared, DHGR plain (iiv_encoder_input_stats).  This value forces the form */
 #define IIV_GREEDY_WAVE_PLAIN 5  /*   WAVE with every table load from the L1 / L2, never the LDS-shared form */
 #define IIV_OPT_PREFIX_SORT 3    /* 1 (default): when a generator's opcode budget B is known
                                  * (another restart follows in the same iiv_encode call) and
@@ -353,6 +356,10 @@ int iiv_encoder_profile_read(iiv_encoder *enc, double ms[2], int64_t launches[2]
  * mostly out of work: the shared form's per-workgroup table copy is not repaid).  IIV_OPT_GREEDY_KERNEL = WAVE_SHARED /
  * WAVE_PLAIN overrule it. */
 int iiv_encoder_input_stats(iiv_encoder *enc, double stats[2], int *form);
+/* Greedy launches since iiv_encoder_profile(enc, 1), by the kernel that ran them: counts[0] = one wave per stream (plain),
+ * [1] = its LDS-shared form, [2] = eight waves per stream (team), [3] = one 256-thread workgroup per stream.  (The form is
+ * chosen per launch: bench.py reports how many timed launches ran each.) */
+int iiv_encoder_launch_forms(iiv_encoder *enc, int64_t counts[4]);
 
 /* ==== f2: byte emission of the opcode stream (".a2m") ====================== */
 

@@ -54,3 +54,20 @@ def test_product_does_not_import_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dp, fn), errors="replace").read()
                 assert "import oracle" not in txt and "liboracle" not in txt and "iiv_oracle.h" not in txt, fn
+
+
+def test_torch_custom_operators_are_registered_over_the_c_abi(native):
+    """north_star: "hand-written HIP kernels via PyTorch-ROCm custom ops".  torch_ops.py registers the C ABI's hot entry
+    points as torch.ops.iivision.*; registration needs no GPU, running them does (no CPU implementation)."""
+    import torch
+    import torch_ops
+    assert set(torch_ops.NAMES) == {"cie2000_matrix", "build_table", "build_store_table", "encode", "encode_streams",
+                                    "emit_chunk", "frames_to_memory_maps"}
+    for name in torch_ops.NAMES:
+        op = getattr(torch.ops.iivision, name)
+        assert "iivision::" + name in str(op.default._schema)
+    # the launch operators mutate their output buffer and return nothing: no hidden allocation, no hidden copy
+    assert "ops_out" in str(torch.ops.iivision.encode.default._schema) and "-> ()" in str(torch.ops.iivision.encode.default._schema)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            torch.ops.iivision.cie2000_matrix(torch.zeros((16, 3), dtype=torch.uint8))

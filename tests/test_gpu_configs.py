@@ -88,7 +88,8 @@ def test_thousand_frame_clips(native, O, oracle_tables, device_tables, mode):
     """BASELINE configs 3 / 4 at their full length: 1000-frame Movie-paced clips (490 000 opcodes each, ~2 680
     generators and ~1 680 bank flips in DHGR), 50-frame driver steps with generators continued across calls --
     every opcode, the final screens, priorities and both RNG positions against the oracle.  The two clips go through
-    the one-wave kernel of the big batches (DHGR: its LDS-shared form) and through the eight-waves-per-clip team kernel."""
+    the one-wave kernel of the big batches in both its forms (plain and LDS-shared) and through the eight-waves-per-clip
+    team kernel."""
     import concurrent.futures
     import torch
     n, nf = 2, 1000
@@ -99,7 +100,7 @@ def test_thousand_frame_clips(native, O, oracle_tables, device_tables, mode):
     otab = oracle_tables.get(mode, 5)
     fmd, fad = fm.cuda(), (fa.cuda() if fa is not None else None)
     runs = {}
-    for kernel in (("shared", "team") if mode == 1 else (True, "shared", "team")):   # (the plain one-wave form at this length: HGR)
+    for kernel in ("plain", "shared", "team"):   # both one-wave forms (picture-like batches are dispatched to the plain one) and the team kernel
         b = stream_batch.StreamBatch(mode, t, s, n, seeds=seeds, dm=device_tables.dm[(mode, 5)])
         b.enc.set_greedy_kernel(kernel)
         got, segs = [], []

@@ -1,0 +1,85 @@
+"""torch.ops.iivision.* (ii-vision_amd/transcoder/torch_ops.py): the C ABI's hot entry points registered as PyTorch custom
+operators -- what BASELINE.json's north_star names as the calling convention.  Same kernels, same bytes as the ctypes
+path; the golden runs are the reference's own recorded opcode streams."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_operators_are_registered_and_run_the_golden_encode(native, O, device_tables, golden):
+    import torch
+    import torch_ops
+    from test_gpu_encode import _seed_states, _tags
+    for name in torch_ops.NAMES:
+        assert hasattr(torch.ops.iivision, name), name
+    g3 = golden.g3_encode_runs
+    for tag in _tags(g3)[:6]:
+        mode, pal, sp, sn = (int(x) for x in g3[tag + "/meta"])
+        frames, sched, want = g3[tag + "/frames"], g3[tag + "/schedule"], g3[tag + "/ops"]
+        table, store = device_tables.get(mode, pal)
+        fm = torch.from_numpy(np.ascontiguousarray(frames[None, :, 0])).cuda()
+        fa = torch.from_numpy(np.ascontiguousarray(frames[None, :, 1])).cuda() if mode == 1 else None
+        segs = [(int(f), int(a), 1, int(k)) for (f, a, k) in sched]
+        py, npw = _seed_states(O, sp, sn)
+        outs = []
+        for via_op in (True, False):
+            enc = native.Encoder(mode, table, store, 1, dm=device_tables.dm[(mode, pal)])
+            enc.set_state(native.STATE_RNG_PY, py)
+            enc.set_state(native.STATE_RNG_NP, npw)
+            ops = torch_ops.encode_via_op(enc, fm, fa, segs) if via_op else enc.encode(fm, fa, segs)
+            enc.check()
+            outs.append(ops.cpu().numpy()[0])
+            enc.close()
+        assert np.array_equal(outs[0], outs[1]), tag
+        assert np.array_equal(outs[0], want), tag      # the reference's own recorded opcode stream
+
+
+def test_stream_batch_goes_through_the_operators(native, device_tables):
+    """StreamBatch's launches are torch.ops.iivision.encode calls; the ctypes path gives the same opcodes."""
+    import torch
+    import stream_batch
+    table, store = device_tables.get(1, 5)
+    fm, fa = stream_batch.synth_frames_torch(4, 3, True, seed=11)
+    outs = []
+    for use in (True, False):
+        b = stream_batch.StreamBatch(1, table, store, 4, seeds=[(i + 1, i + 1) for i in range(4)], dm=device_tables.dm[(1, 5)],
+                                     use_torch_ops=use)
+        ops, segs = b.encode_frames(fm, fa, 3)
+        b.enc.check()
+        outs.append(ops.cpu().numpy())
+        b.close()
+    assert np.array_equal(outs[0], outs[1])
+    # per-stream schedules through encode_streams
+    import torch_ops
+    enc = native.Encoder(1, table, store, 2, dm=device_tables.dm[(1, 5)])
+    sched = [[(0, 0, 1, 100), (0, 1, 1, 50)], [(1, 1, 1, 70)]]
+    ref, totals = enc.encode_streams(fm[:2], fa[:2], sched)
+    enc.check()
+    enc2 = native.Encoder(1, table, store, 2, dm=device_tables.dm[(1, 5)])
+    flat = torch.tensor([list(g) for s in sched for g in s], dtype=torch.int32)
+    begin = torch.tensor([0, 2, 3], dtype=torch.int32)
+    out = torch.zeros_like(ref)
+    torch.ops.iivision.encode_streams(enc2.handle, fm[:2], fa[:2], flat, begin, out)
+    enc2.check()
+    assert bool((out == ref).all())
+    enc.close()
+    enc2.close()
+
+
+def test_table_and_ingest_operators(native, O):
+    import torch
+    import torch_ops  # noqa: F401
+    rgb = torch.from_numpy(O.PALETTE_RGB[5])
+    f, dm = torch.ops.iivision.cie2000_matrix(rgb)
+    f0, dm0 = native.cie2000_matrix(O.PALETTE_RGB[5])
+    assert np.array_equal(dm.numpy(), dm0) and np.array_equal(f.numpy(), f0)
+    t = torch.ops.iivision.build_table(1, dm, True)
+    assert bool((t == native.build_table(1, dm0, True)).all())
+    s = torch.ops.iivision.build_store_table(1, dm)
+    assert bool((s == native.build_store_table(1, dm0)).all())
+    img = torch.randint(0, 256, (2, 192, 280, 3), dtype=torch.uint8, device="cuda")
+    main, aux = torch.ops.iivision.frames_to_memory_maps(1, rgb, img, 32)
+    m0, a0 = native.frames_to_memory_maps(1, O.PALETTE_RGB[5], img, 32)
+    assert bool((main == m0).all()) and bool((aux == a0).all())
