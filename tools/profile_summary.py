@@ -31,10 +31,21 @@ def run(cmd, cwd):
 
 
 def short(name):
-    for k in ("greedy_wave_kernel", "greedy_lds_kernel", "greedy_team_kernel", "greedy_kernel", "prologue_kernel", "table_kernel", "store_kernel"):
-        if k in name:
-            return k + ("<DHGR>" if "<1" in name else "<HGR>" if "<0" in name else "")
-    return None
+    """`void iiv::greedy_wave_kernel<1, 8, false>(...)` -> `greedy_wave_kernel<1, 8, false>`: the template arguments stay, so that
+    the one-wave kernel's two forms (W = 1: plain; W = 8 / 16: LDS-shared) and its fourth-offset variants keep their own counters
+    -- pmc_latest.json must hold the form that ran, not a mixture.  First argument: 1 = DHGR, 0 = HGR."""
+    import re
+    m = re.search(r"(greedy_wave_kernel|greedy_team_kernel|greedy_kernel|prologue_kernel|table_kernel|store_kernel)(<[^>]*>)?", name)
+    if not m:
+        return None
+    return m.group(1) + (m.group(2) or "")
+
+
+def mode_of(key):
+    """'DHGR' / 'HGR' of a key made by short(), from its first template argument."""
+    import re
+    m = re.search(r"<\s*(\d)", key)
+    return None if not m else ("DHGR" if m.group(1) == "1" else "HGR")
 
 
 def main():
@@ -93,7 +104,7 @@ def main():
     except Exception:
         latest = {}
     for mode in ("DHGR", "HGR"):
-        ks = [k for k in agg if k.startswith("greedy") and k.endswith("<%s>" % mode) and "FETCH_SIZE" in agg[k]]
+        ks = [k for k in agg if k.startswith("greedy") and mode_of(k) == mode and "FETCH_SIZE" in agg[k]]
         if not ks or not streams:
             continue
         main_k = max(ks, key=lambda k: len(cnt[k]["FETCH_SIZE"]))
@@ -103,6 +114,8 @@ def main():
         latest[mode] = {
             "source": "tools/profile_summary.py (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
             "kernel": main_k,
+            "kernel_note": "template arguments: <mode (1 = DHGR), streams per workgroup (1 = plain form, 8 / 16 = LDS-shared form), fourth offset>; "
+                           "the instantiation with the most dispatches in the profiled run",
             "bench_args": bench_args,
             "streams": streams,
             "fetch_size_kib_per_launch_raw": fetch,
