@@ -6,6 +6,8 @@
 
 #include "iiv_device.h"
 
+#include <type_traits>
+
 namespace iiv {
 
 constexpr int kPushedCap = 24576;  // >= 3 pushes (two, or three with the fourth-offset option) x 7680 non-hole bytes
@@ -244,6 +246,84 @@ __device__ static inline void mt_twist_wave(const uint32_t *__restrict__ src, ui
             dst[227 + j] = b[g];
         }
         if (g < 2 || (g == 2 && j < 170)) dst[454 + j] = c[g];
+    }
+    wave_lds_sync();
+}
+
+// Blocks 1 .. n_blocks of the stream behind block 0 (`blk0`, 624 words in LDS), written to gen[0 .. n_blocks), by ONE wave that
+// keeps the latest block in REGISTERS: lane l holds words l + 64 g of each third -- A: words 0..226, B: 227..453,
+// C: 454..623 -- so that every operand of the next block is either the lane's own register (old[i], and new[i - 227] as in
+// mt_twist_wave), its neighbour lane's (old[i + 1]: a wave-wide DPP shift by one lane, the last lane patched from the next
+// register) or a fixed rotation of the lanes (old[i + 397] = chain j + 170 of B for j < 57, chain j - 57 of C beyond: two
+// rotations, by 42 and by 7 lanes: five ds_bpermute).  A block is then ONE trip through the LDS crossbar and no LDS memory
+// read at all (its words are still written out for the nonce lookups, but nothing waits for those writes); the form that
+// re-read every block from LDS took one wave ~1.1 k cycles per block beside fifteen waves whose gathers queue in front
+// of its reads -- 14 k cycles for the thirteen blocks of a prologue call, more than the other waves need to score.
+__device__ static inline void mt_generate_wave(const uint32_t *__restrict__ blk0, uint32_t *__restrict__ gen, int n_blocks, int lane)
+{
+    auto mix = [](uint32_t x, uint32_t y) -> uint32_t {   // iiv_device.h: mt_mix
+        const uint32_t v = (x & 0x80000000u) | (y & 0x7fffffffu);
+        return (v >> 1) ^ ((uint32_t)__builtin_amdgcn_sbfe(y, 0, 1) & 0x9908b0dfu);
+    };
+    // value of the next chain: lane l gets lane l + 1's `v`; lane `last` (63, or the third's last chain) gets `next0` (a scalar)
+    auto up1 = [&](uint32_t v, uint32_t next0, auto last) -> uint32_t {
+        uint32_t s = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);   // wave_shl:1
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(s) : "s"(next0), "n"(decltype(last)::value));
+        return s;
+    };
+    auto lane0 = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, 0); };
+    auto rot = [](uint32_t v, int addr) -> uint32_t { return (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v); };
+    uint32_t A[4], B[4], C[3];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const int j = lane + 64 * g;
+        A[g] = B[g] = 0;
+        if (g < 3 || j < 227) {
+            A[g] = blk0[j];
+            B[g] = blk0[227 + j];
+        }
+        if (g < 3) {
+            C[g] = 0;
+            if (g < 2 || j < 170) C[g] = blk0[454 + j];
+        }
+    }
+    const int addr7 = ((lane + 7) & 63) << 2, addr42 = ((lane + 42) & 63) << 2;
+    const bool lt22 = lane < 22, lt57 = lane < 57;
+    for (int k = 0; k < n_blocks; k++) {
+        uint32_t *dst = gen + k * 624;
+        // old[j + 397]: chain j + 170 of B (j < 57), chain j - 57 of C (beyond)
+        const uint32_t rb2 = rot(B[2], addr42), rb3 = rot(B[3], addr42);
+        const uint32_t rc0 = rot(C[0], addr7), rc1 = rot(C[1], addr7), rc2 = rot(C[2], addr7);
+        uint32_t X[4];
+        X[0] = lt22 ? rb2 : lt57 ? rb3 : rc0;
+        X[1] = lt57 ? rc0 : rc1;
+        X[2] = lt57 ? rc1 : rc2;
+        X[3] = rc2;
+        uint32_t nA[4], nB[4], nC[3];
+        // first third: new[j] = old[j + 397] ^ mix(old[j], old[j + 1]); old[227] is B's chain 0
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            nA[g] = X[g] ^ mix(A[g], g < 3 ? up1(A[g], lane0(A[g < 3 ? g + 1 : 0]), std::integral_constant<int, 63>{}) : up1(A[g], lane0(B[0]), std::integral_constant<int, 34>{}));
+        // second third: new[227 + j] = new[j] ^ mix(old[227 + j], old[228 + j]); old[454] is C's chain 0
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            nB[g] = nA[g] ^ mix(B[g], g < 3 ? up1(B[g], lane0(B[g < 3 ? g + 1 : 0]), std::integral_constant<int, 63>{}) : up1(B[g], lane0(C[0]), std::integral_constant<int, 34>{}));
+        // third third: new[454 + j] = new[227 + j] ^ mix(old[454 + j], old[455 + j]); "old[624]" is the new word 0
+#pragma unroll
+        for (int g = 0; g < 3; g++)
+            nC[g] = nB[g] ^ mix(C[g], g < 2 ? up1(C[g], lane0(C[g < 2 ? g + 1 : 0]), std::integral_constant<int, 63>{}) : up1(C[g], lane0(nA[0]), std::integral_constant<int, 41>{}));
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int j = lane + 64 * g;
+            if (g < 3 || j < 227) {
+                dst[j] = nA[g];
+                dst[227 + j] = nB[g];
+            }
+            if (g < 2 || (g == 2 && j < 170)) dst[454 + j] = nC[g];
+            A[g] = nA[g];
+            B[g] = nB[g];
+            if (g < 3) C[g] = nC[g];
+        }
     }
     wave_lds_sync();
 }
