@@ -520,16 +520,33 @@ def _gather_ceiling_live(S, mode="DHGR", shared=False):
     return None, None
 
 
-def _pmc_traffic(mode, S):
+def _input_kind(args):
+    """The synthetic input of a leg as the counter file names it: "iid", "img", or another kind (no counter run)."""
+    if getattr(args, "static", False):
+        return "static"
+    if getattr(args, "img", False):
+        return "img"
+    if getattr(args, "coherent", False):
+        return "coherent"
+    return "iid"
+
+
+def _pmc_traffic(mode, S, kind="iid", fourth=False):
     """HBM bytes per greedy kernel launch from the committed rocprofv3 PMC summary
     (profiles/pmc_latest.json) and where that number comes from -- it is NOT measured in this run.
-    The file holds bytes per launch AND PER STREAM for each mode (tools/profile_summary.py); the figure
-    reported here is that times this run's stream count, so that it compares with
-    algorithmic_bytes_per_launch on the same mode and the same number of streams."""
+    The file holds bytes per launch AND PER STREAM for each mode and input kind it was collected on ("DHGR", "HGR":
+    S-iid; "DHGR:img": S-img; tools/profile_summary.py); the figure reported here is that times this run's stream
+    count, so that it compares with algorithmic_bytes_per_launch on the same mode, input and number of streams.
+    A leg on an input (or with an option) no counter run was made for reports null, not another input's bytes."""
     p = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    key = mode if kind == "iid" else "%s:%s" % (mode, kind)
     try:
         with open(p) as f:
-            d = json.load(f)[mode]
+            allkeys = json.load(f)
+        if fourth or key not in allkeys:
+            return None, "profiles/pmc_latest.json holds no counter run for %s%s (it has: %s)" % (
+                key, " with the fourth offset" if fourth else "", ", ".join(sorted(allkeys)))
+        d = allkeys[key]
         return d["greedy_hbm_bytes_per_launch_per_stream"] * S, \
             "profiles/pmc_latest.json (%s at %d streams, bench args %s; per-stream bytes x %d streams): a committed " \
             "counter run, not this run" % (d.get("kernel", "?"), d.get("streams", 0), " ".join(d.get("bench_args", [])), S)
@@ -545,7 +562,7 @@ def _roofline_objects(be, args, prof, op_count, seg_count, S, elapsed, live_ceil
     p_ms, p_n = prof["prologue_ms"], max(prof["prologue_launches"], 1)
     greedy_bytes = float(op_count) * S * BYTES_PER_OPCODE       # all launches of the timed region
     achieved = greedy_bytes / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
-    traffic, traffic_source = _pmc_traffic(args.mode, S)
+    traffic, traffic_source = _pmc_traffic(args.mode, S, _input_kind(args), getattr(args, "fourth", False))
     out["roofline"] = {
         "kernel": "greedy_wave_kernel" if be.uses_wave_kernel() else "greedy_kernel",
         "bound": "hbm",

@@ -99,7 +99,7 @@ def main():
     latest_path = os.path.join(out, "pmc_latest.json")
     try:
         latest = json.load(open(latest_path))
-        if "DHGR" not in latest and "HGR" not in latest:
+        if not any(k.split(":")[0] in ("DHGR", "HGR") for k in latest):
             latest = {}
     except Exception:
         latest = {}
@@ -111,7 +111,9 @@ def main():
         a = agg[main_k]
         fetch = a["FETCH_SIZE"] / max(len(cnt[main_k]["FETCH_SIZE"]), 1)
         write = a["WRITE_SIZE"] / max(len(cnt[main_k]["WRITE_SIZE"]), 1)
-        latest[mode] = {
+        # the key names mode and synthetic input: "DHGR" / "HGR" are S-iid, "DHGR:img" is S-img (bench._pmc_traffic)
+        kind = "img" if "--img" in bench_args else "coherent" if "--coherent" in bench_args else "static" if "--static" in bench_args else "iid"
+        latest[mode if kind == "iid" else "%s:%s" % (mode, kind)] = {
             "source": "tools/profile_summary.py (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
             "kernel": main_k,
             "kernel_note": "template arguments: <mode (1 = DHGR), streams per workgroup (1 = plain form, 8 / 16 = LDS-shared form), fourth offset>; "
