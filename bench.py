@@ -141,6 +141,12 @@ def _resolve_backend(spec):
     return getattr(importlib.import_module(mod), name)
 
 
+# IIV_BENCH_REHEARSE_ON_ONE_GPU=1: every rank binds GPU 0 and the process group is gloo (RCCL refuses two ranks on one
+# device).  It exists to run the launcher and the whole multi-rank control flow on a 1-GPU box -- real kernels, real
+# processes, the ranks sharing the one GPU -- and says so in the line; its value is not a multi-GPU measurement.
+REHEARSE = os.environ.get("IIV_BENCH_REHEARSE_ON_ONE_GPU") == "1"
+
+
 def visible_gpus():
     """Devices this process could bind ranks to.  torch.cuda.device_count() does not initialise the HIP runtime on
     this image (nothing here may: the launcher below starts children, and a process that has touched the GPU must
@@ -160,7 +166,7 @@ def launch_ranks(args, argv):
     import subprocess
     n = int(args.gpus)
     backend = _resolve_backend(args.backend)
-    if getattr(backend, "is_gpu", True):
+    if getattr(backend, "is_gpu", True) and not REHEARSE:
         have = visible_gpus()
         if have < n:
             sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible to this process\n" % (n, have))
@@ -220,14 +226,16 @@ class GpuBackend:
         import _iiv_native as native
         import stream_batch
         self.torch, self.native, self.sb = torch, native, stream_batch
-        torch.cuda.set_device(local_rank if world > 1 else 0)
+        torch.cuda.set_device(local_rank if world > 1 and not REHEARSE else 0)
         self.device = torch.device("cuda", torch.cuda.current_device())
+        if REHEARSE:
+            self.dist_backend, self.coll_device = "gloo", torch.device("cpu")
         self.args = args
         self.mode = native.DHGR if args.mode == "DHGR" else native.HGR
         self.dhgr = self.mode == native.DHGR
 
     def dist_kwargs(self):
-        return {"device_id": self.device}
+        return {} if REHEARSE else {"device_id": self.device}
 
     def free_bytes(self):
         return self.torch.cuda.mem_get_info()[0]
@@ -330,7 +338,7 @@ def main(argv=None, backend_cls=None):
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (the launcher's rank count and --gpus must agree)" % (args.gpus, world))
     be = backend_cls(args, local_rank, world)
-    if getattr(be, "is_gpu", True) and world > 1 and visible_gpus() <= local_rank:
+    if getattr(be, "is_gpu", True) and world > 1 and not REHEARSE and visible_gpus() <= local_rank:
         raise SystemExit("bench.py: rank %d has no GPU %d (%d visible)" % (rank, local_rank, visible_gpus()))
     # the process group exists for N > 1 only; IIV_BENCH_FORCE_DIST=1 creates it for one rank too, so that
     # the RCCL initialisation, the barrier and the two scalar reductions can be exercised on a 1-GPU box
@@ -343,6 +351,7 @@ def main(argv=None, backend_cls=None):
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(be.dist_backend, **be.dist_kwargs())
     n_gpus = max(world, 1)
+    cdev = getattr(be, "coll_device", be.device)   # where the three scalars that cross ranks live
     dhgr = args.mode == "DHGR"
     F = args.frames_per_step
     # resident clip length = the timed region: the warm-up runs on its first frames and the timed steps wrap around (every
@@ -359,7 +368,7 @@ def main(argv=None, backend_cls=None):
         S = next((c for c in (14336, 12288, 6144, 3072, 1536) if c * per_clip + (3 << 30) <= 0.88 * be.free_bytes()), 1536)
         if use_dist:   # every rank runs the same number of clips
             import torch
-            t = torch.tensor([S], dtype=torch.int64, device=be.device)
+            t = torch.tensor([S], dtype=torch.int64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             S = int(t.item())
 
@@ -375,10 +384,10 @@ def main(argv=None, backend_cls=None):
 
     leg = timed_leg(be, args.steps, args.warmup, barrier)
     first_ops, op_count, seg_count, prof = leg["first_ops"], leg["op_count"], leg["seg_count"], leg["prof"]
-    rank_elapsed = all_ranks(leg["elapsed"], be.device, world, use_dist)   # (one float per rank: what the line's per-rank rates come from)
-    seed_lo = all_ranks(float(seeds[0][0]), be.device, world, use_dist)     # first / last stream seed of every rank: disjoint ranges
-    seed_hi = all_ranks(float(seeds[-1][0]), be.device, world, use_dist)
-    elapsed = max_over_ranks(leg["elapsed"], be.device, world, use_dist)
+    rank_elapsed = all_ranks(leg["elapsed"], cdev, world, use_dist)   # (one float per rank: what the line's per-rank rates come from)
+    seed_lo = all_ranks(float(seeds[0][0]), cdev, world, use_dist)     # first / last stream seed of every rank: disjoint ranges
+    seed_hi = all_ranks(float(seeds[-1][0]), cdev, world, use_dist)
+    elapsed = max_over_ranks(leg["elapsed"], cdev, world, use_dist)
 
     frames_done = args.steps * F * S * n_gpus
     fps = frames_done / elapsed
@@ -419,7 +428,8 @@ def main(argv=None, backend_cls=None):
             "resident_clip_frames": n_frames,
             "clip_wraps_in_timed_region": bool(wraps and args.warmup > 0),
             "opcodes_per_frame": OPS_PER_FRAME,
-            "parallelism": "%d GPU x %d independent streams, no collective" % (n_gpus, S),
+            "parallelism": ("REHEARSAL: %d ranks sharing ONE GPU (IIV_BENCH_REHEARSE_ON_ONE_GPU), %d streams each -- not a multi-GPU measurement"
+                            if REHEARSE and world > 1 else "%d GPU x %d independent streams, no collective") % (n_gpus, S),
         },
         "opcodes_per_s": fps * OPS_PER_FRAME,
         # SURVEY 8(d)'s whole-pipeline figure: frames/s x algorithmic bytes per frame (prologue calls + opcodes) against the HBM peak
