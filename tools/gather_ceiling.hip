@@ -193,6 +193,60 @@ __global__ __launch_bounds__(64 * W) void pattern_shared_l1_hgr_kernel(const uin
     sink[stream * 64 + lane] = acc;
 }
 
+// Variant G: the store value as a sum of FOUR pixel-group terms (DESIGN 3.10 applied to the store table: groups of 2 / 3 / 3 / 2
+// pixels depend on 5 / 7 / 7 / 6 target dots and 2 / 5 / 6 / 3 content bits -- 128 + 4096 + 8192 + 512 entries per offset
+// class, 25.3 KiB, both classes of a bank 50.5 KiB), all of it in LDS, shared by the W one-wave streams of one workgroup
+// per CU: sixteen ds_read_u16 per lane and opcode, no divergent global load at all.  Layout [content part][target field], so
+// that a step's lanes (one content, 64 fields) spread over the banks.
+template <int W>
+__global__ __launch_bounds__(64 * W) void pattern_groups_lds_kernel(const uint16_t *__restrict__ tab, const uint4 *__restrict__ rows,
+                                                                    int n_ops, int n_streams, uint32_t *__restrict__ sink)
+{
+    extern __shared__ uint32_t lds[];   // [0, 12928 u32): the two classes' tables; the rest: per-stream padding
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int kClass = 128 + 4096 + 8192 + 512;   // u16 entries per class
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(tab);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds);
+        for (int i = threadIdx.x; i < 2 * kClass * 2 / 16; i += 64 * W) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int stream = blockIdx.x * W + wave;
+    if (stream >= n_streams) return;
+    const unsigned char *t8 = reinterpret_cast<const unsigned char *>(lds);
+    const uint4 *my = rows + (size_t)stream * n_ops * 64 + lane;
+    uint32_t acc = 0, h = stream * 2654435761u + 977u;
+    uint4 next = my[0];
+    for (int op = 0; op < n_ops; op++) {
+        const uint4 row = next;
+        if (op + 1 < n_ops) next = my[(size_t)(op + 1) * 64];
+        h = h * 1664525u + 1013904223u;
+        const uint32_t c = (h >> 16) & 127u;
+        // scalar byte offsets of this content's slices: class base + group base + content part << field bits, times 2
+        uint32_t sa[2], sb[2], sc[2], sd[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const uint32_t cls = (uint32_t)k * kClass;
+            sa[k] = __builtin_amdgcn_readfirstlane(2u * (cls + ((c & 3u) << 5)));
+            sb[k] = __builtin_amdgcn_readfirstlane(2u * (cls + 128u + ((c & 31u) << 7)));
+            sc[k] = __builtin_amdgcn_readfirstlane(2u * (cls + 128u + 4096u + (((c >> 1) & 63u) << 7)));
+            sd[k] = __builtin_amdgcn_readfirstlane(2u * (cls + 128u + 4096u + 8192u + ((c >> 4) << 6)));
+        }
+        const uint32_t w[4] = {row.x, row.y, row.z, row.w};
+        uint32_t v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int k = r & 1;
+            const uint32_t fa = __builtin_amdgcn_ubfe(w[r], 0, 5), fb = __builtin_amdgcn_ubfe(w[r], 1, 7), fc = __builtin_amdgcn_ubfe(w[r], 4, 7),
+                           fd = __builtin_amdgcn_ubfe(w[r], 7, 6);
+            v[r] = *reinterpret_cast<const uint16_t *>(t8 + (fa * 2 + sa[k])) + *reinterpret_cast<const uint16_t *>(t8 + (fb * 2 + sb[k])) +
+                   *reinterpret_cast<const uint16_t *>(t8 + (fc * 2 + sc[k])) + *reinterpret_cast<const uint16_t *>(t8 + (fd * 2 + sd[k]));
+        }
+        acc += v[0] ^ v[1] ^ v[2] ^ v[3];
+    }
+    sink[stream * 64 + lane] = acc;
+}
+
 // Variant B: four 8-byte gathers (as if both halves of a byte's value sat side by side in one
 // 6 KiB slice per opcode): what a layout that serves a byte with ONE load would buy.
 __global__ __launch_bounds__(64) void pattern_x2_kernel(const uint2 *__restrict__ both, const uint4 *__restrict__ rows,
@@ -338,7 +392,7 @@ int main(int argc, char **argv)
     const size_t nl = 4 * 32 * 256, nr = 4 * 64 * 512;
     uint32_t *left, *right, *sink;
     uint4 *rows;
-    for (int waves : {7168, 12288}) {
+    for (int waves : {7168, 14336}) {
         const size_t n_rows = (size_t)waves * n_ops * 64;
         (void)hipMalloc(&left, nl * 4);
         (void)hipMalloc(&right, nr * 4);
@@ -450,6 +504,23 @@ int main(int argc, char **argv)
                     hipLaunchKernelGGL(pattern_u16_rare_kernel<false>, dim3(waves), dim3(64), 10240, 0, (const uint16_t *)left,
                                        (const uint16_t *)right, dense2, rows, n_ops, sink);
                 });
+                {
+                    uint16_t *gt;
+                    const size_t gbytes = (size_t)2 * (128 + 4096 + 8192 + 512) * 2;
+                    (void)hipMalloc(&gt, gbytes);
+                    (void)hipMemset(gt, 1, gbytes);
+                    (void)hipFuncSetAttribute((const void *)pattern_groups_lds_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    (void)hipFuncSetAttribute((const void *)pattern_groups_lds_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    time("G: four pixel-group tables in LDS (50.5 KiB), W=16, 1 wg/CU, no gathers", [&] {
+                        hipLaunchKernelGGL(pattern_groups_lds_kernel<16>, dim3((waves + 15) / 16), dim3(1024), (int)gbytes + 16 * 5824, 0, gt, rows, n_ops,
+                                           waves, sink);
+                    });
+                    time("G: the same, W=12 (12 waves/CU)", [&] {
+                        hipLaunchKernelGGL(pattern_groups_lds_kernel<12>, dim3((waves + 11) / 12), dim3(768), (int)gbytes + 12 * 5824, 0, gt, rows, n_ops,
+                                           waves, sink);
+                    });
+                    (void)hipFree(gt);
+                }
                 (void)hipFree(dense2);
             }
             (void)hipFree(both);
