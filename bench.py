@@ -48,6 +48,7 @@ BYTES_PER_FRAME = {"DHGR": 657e3, "HGR": 409e3}   # (1 + 490/292
 GATHER_CEILING_GLOADS_HGR = 995.0    # tools/gather_ceiling D 14336 HGR (3.61 ms per launch of 490 opcodes)
 GATHER_CEILING_GLOADS = 1184.2   # tools/gather_ceiling.hip, variant D (profiles/r02l_gather_ceiling.txt)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_MEASURED_COPY_GBS = 4610.0     # the same run: torch copy_ of 4 GiB, read + write bytes per second
 HBM_MEASURED_READ_GBS = 5990.0     # tools/hbm_copy_bench.py on the same box (profiles/r01f_hbm_copy.txt); copy 4610, write 6900
 PALETTE_IDS = {"NTSC": 5, "IIGS": 0}   # palette.py:18-23
 
@@ -541,7 +542,7 @@ def _input_kind(args):
     return "iid"
 
 
-def _pmc_traffic(mode, S, kind="iid", fourth=False):
+def _pmc_traffic(mode, S, kind="iid", fourth=False, field="greedy_hbm_bytes_per_launch_per_stream", kernel_field="kernel"):
     """HBM bytes per greedy kernel launch from the committed rocprofv3 PMC summary
     (profiles/pmc_latest.json) and where that number comes from -- it is NOT measured in this run.
     The file holds bytes per launch AND PER STREAM for each mode and input kind it was collected on ("DHGR", "HGR":
@@ -557,9 +558,9 @@ def _pmc_traffic(mode, S, kind="iid", fourth=False):
             return None, "profiles/pmc_latest.json holds no counter run for %s%s (it has: %s)" % (
                 key, " with the fourth offset" if fourth else "", ", ".join(sorted(allkeys)))
         d = allkeys[key]
-        return d["greedy_hbm_bytes_per_launch_per_stream"] * S, \
+        return d[field] * S, \
             "profiles/pmc_latest.json (%s at %d streams, bench args %s; per-stream bytes x %d streams): a committed " \
-            "counter run, not this run" % (d.get("kernel", "?"), d.get("streams", 0), " ".join(d.get("bench_args", [])), S)
+            "counter run, not this run" % (d.get(kernel_field, "?"), d.get("streams", 0), " ".join(d.get("bench_args", [])), S)
     except Exception:
         return None, None
 
@@ -623,6 +624,16 @@ def _roofline_objects(be, args, prof, op_count, seg_count, S, elapsed, live_ceil
         "launches": prof["prologue_launches"],
     }
     out["roofline_prologue"]["frac"] = out["roofline_prologue"]["achieved"] / HBM_PEAK_GBS
+    # what the counters saw of it (committed run), and the yardstick that fits a kernel whose traffic is half reads, half
+    # writes: the box's measured copy rate (torch copy_ of 4 GiB: read + write bytes per second), not its nominal peak
+    p_traffic, p_src = _pmc_traffic(args.mode, S, _input_kind(args), getattr(args, "fourth", False),
+                                    "prologue_hbm_bytes_per_launch_per_stream", "prologue_kernel")
+    out["roofline_prologue"].update({
+        "algorithmic_bytes_per_launch": pro_bytes / p_n, "traffic": p_traffic, "traffic_source": p_src,
+        "traffic_frac": (p_traffic / (p_ms / p_n * 1e-3) / 1e9 / HBM_PEAK_GBS) if (p_traffic and p_ms > 0) else None,
+        "peak_measured_copy": HBM_MEASURED_COPY_GBS,
+        "traffic_over_measured_copy": (p_traffic / (p_ms / p_n * 1e-3) / 1e9 / HBM_MEASURED_COPY_GBS) if (p_traffic and p_ms > 0) else None,
+    })
     out["kernel_time_share"] = {"greedy": g_ms / (1000 * elapsed), "prologue": p_ms / (1000 * elapsed)}
     return out
 

@@ -127,6 +127,16 @@ def main():
             "greedy_hbm_bytes_per_launch": (2 * fetch + write) * 1024,
             "greedy_hbm_bytes_per_launch_per_stream": (2 * fetch + write) * 1024 / streams,
         }
+        # the prologue kernel of the same run (same correction: its reads are wide coalesced ones)
+        pk = [k for k in agg if k.startswith("prologue") and mode_of(k) == mode and "FETCH_SIZE" in agg[k]]
+        if pk:
+            pm = max(pk, key=lambda k: len(cnt[k]["FETCH_SIZE"]))
+            pf = agg[pm]["FETCH_SIZE"] / max(len(cnt[pm]["FETCH_SIZE"]), 1)
+            pw = agg[pm]["WRITE_SIZE"] / max(len(cnt[pm]["WRITE_SIZE"]), 1)
+            key = mode if kind == "iid" else "%s:%s" % (mode, kind)
+            latest[key].update({"prologue_kernel": pm, "prologue_fetch_size_kib_per_launch_raw": pf,
+                                "prologue_write_size_kib_per_launch_raw": pw,
+                                "prologue_hbm_bytes_per_launch_per_stream": (2 * pf + pw) * 1024 / streams})
     json.dump(latest, open(latest_path, "w"), indent=1)
 
 if __name__ == "__main__":
