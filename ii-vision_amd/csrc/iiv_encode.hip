@@ -149,6 +149,31 @@ __global__ __launch_bounds__(256) void init_states_kernel(StreamState *__restric
 }
 static_assert(sizeof(StreamState) % 8 == 0, "StreamState is cleared 8 bytes at a time");
 
+// The priorities as the host sees them (int32, StreamState::up) from the kernels' 16-bit copy, and back (iiv_stream.h):
+// one workgroup per stream, before the host reads / after it has written them.
+__global__ __launch_bounds__(256) void materialise_up_kernel(StreamState *__restrict__ states)
+{
+    StreamState &S = states[blockIdx.x];
+    for (int i = threadIdx.x; i < 2 * 8192; i += 256) {
+        const uint32_t v = S.up16[i >> 13][i & 8191];
+        if (v != kUpBig) S.up[i >> 13][i & 8191] = (int32_t)v;
+    }
+}
+__global__ __launch_bounds__(256) void compact_up_kernel(StreamState *__restrict__ states)
+{
+    StreamState &S = states[blockIdx.x];
+    for (int i = threadIdx.x; i < 2 * 8192; i += 256) {
+        const uint32_t u = (uint32_t)S.up[i >> 13][i & 8191];
+        S.up16[i >> 13][i & 8191] = (uint16_t)(u < kUpBig ? u : kUpBig);
+    }
+}
+static int materialise_up(Encoder *e, int s0, int n)
+{
+    hipLaunchKernelGGL(materialise_up_kernel, dim3(n), dim3(256), 0, 0, e->d_states + s0);
+    int rc = hip_check(hipGetLastError(), "materialise_up_kernel launch");
+    return rc ? rc : hip_check(hipDeviceSynchronize(), "materialise_up sync");
+}
+
 __global__ __launch_bounds__(256) void max_u16_kernel(const uint16_t *__restrict__ v, size_t n, uint32_t *__restrict__ result)
 {
     uint32_t mx = 0;
@@ -440,6 +465,8 @@ int encoder_get_state(Encoder *e, int s, int what, void *buf, size_t bytes)
     bool writable;
     if (state_item(e->mode, what, off, want, writable)) return set_error(IIV_ERR_INVALID, "get_state: unknown item %d", what);
     if (bytes != want) return set_error(IIV_ERR_INVALID, "get_state: item %d is %zu bytes, got %zu", what, want, bytes);
+    if (what == IIV_STATE_UP_MAIN || what == IIV_STATE_UP_AUX)
+        if (int rc = materialise_up(e, s, 1)) return rc;
     IIV_HIP(hipMemcpy(buf, base + off, bytes, hipMemcpyDeviceToHost));
     return IIV_OK;
 }
@@ -468,7 +495,14 @@ int encoder_set_state(Encoder *e, int s0, int n, int what, const void *buf, size
     if (state_item(e->mode, what, off, want, writable) || !writable)
         return set_error(IIV_ERR_INVALID, "set_state: item %d is not settable", what);
     if (bytes != want) return set_error(IIV_ERR_INVALID, "set_state: item %d is %zu bytes, got %zu", what, want, bytes);
+    if (what == IIV_STATE_UP_MAIN || what == IIV_STATE_UP_AUX)   // (compact_up_kernel rewrites BOTH banks' 16-bit copies from up[])
+        if (int rc = materialise_up(e, s0, n)) return rc;
     IIV_HIP(hipMemcpy2D(base + off, pitch, buf, bytes, bytes, (size_t)n, hipMemcpyHostToDevice));
+    if (what == IIV_STATE_UP_MAIN || what == IIV_STATE_UP_AUX) {
+        hipLaunchKernelGGL(compact_up_kernel, dim3(n), dim3(256), 0, 0, e->d_states + s0);
+        if (int rc = hip_check(hipGetLastError(), "compact_up_kernel launch")) return rc;
+        return hip_check(hipDeviceSynchronize(), "compact_up sync");
+    }
     return IIV_OK;
 }
 
@@ -483,6 +517,7 @@ int encoder_get_video_state(Encoder *e, int s, iiv_video_state *out)
     uint8_t *base = reinterpret_cast<uint8_t *>(e->d_states + s);
     IIV_HIP(hipDeviceSynchronize());
     int rc = pack(e->mode, 1, base + offsetof(StreamState, mem[0]), base + offsetof(StreamState, mem[1]), e->d_packed, 0);
+    if (!rc) rc = materialise_up(e, s, 1);
     if (rc) return rc;
     IIV_HIP(hipMemcpy(out->mem_main, base, 2 * 8192 + 2 * 8192 * 4, hipMemcpyDeviceToHost));   // mem[2] | up[2]
     uint32_t rng[1250];
@@ -506,7 +541,7 @@ __global__ __launch_bounds__(256) void brief_kernel(const StreamState *__restric
     int h[2] = {0, 0};
     for (int b = 0; b < 2; b++)
         for (int i = tid; i < 8192; i += 256) {
-            a[b] += S->up[b][i];
+            a[b] += up_value(*S, b, i);
             if (is_hole(i & 255) && S->mem[b][i] != 0) h[b]++;
         }
     for (int b = 0; b < 2; b++) {
@@ -559,7 +594,9 @@ int encoder_set_video_state(Encoder *e, int s, const iiv_video_state *in)
     rng[1249] = in->rng_np[624];
     IIV_HIP(hipMemcpy(base + offsetof(StreamState, mt_py), rng, sizeof(rng), hipMemcpyHostToDevice));
     IIV_HIP(hipMemcpy(base + offsetof(StreamState, out_of_work), in->out_of_work, 8, hipMemcpyHostToDevice));
-    return IIV_OK;
+    hipLaunchKernelGGL(compact_up_kernel, dim3(1), dim3(256), 0, 0, e->d_states + s);   // (both banks' priorities were just written)
+    if (int rc = hip_check(hipGetLastError(), "compact_up_kernel launch")) return rc;
+    return hip_check(hipDeviceSynchronize(), "compact_up sync");
 }
 
 static int prof_begin(Encoder *e, int cls, hipStream_t st, size_t &slot)

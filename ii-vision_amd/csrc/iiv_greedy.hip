@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
     const uint32_t r1_d = nt.right_off + ((uint32_t)o_d << (T::kRightCBits + T::kRightRowBits + 1));
     // this stream's state as a raw buffer, for the stores of a step
     const __amdgpu_buffer_rsrc_t rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void *)&S, 0, (int)sizeof(StreamState), 0x00020000);
-    const int up_off = (int)offsetof(StreamState, up) + is_aux * 8192 * 4, mem_off = (int)offsetof(StreamState, mem) + is_aux * 8192;
+    const int up_off = (int)offsetof(StreamState, up16) + is_aux * 8192 * 2, mem_off = (int)offsetof(StreamState, mem) + is_aux * 8192;
     // the allocation as a raw buffer (no bounds: every offset formed below lies inside it by construction)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)nt.base, 0, 0x7fffffff, 0x00020000);
     const uint8_t *tgt_frames = (MODE == kDHGR && is_aux ? frames_aux : frames_main) +
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
             // (buffer stores into this stream's state: field offsets in scalar registers instead of
             // 64-bit pointers added per lane)
             const int loc = p * 256 + off;
-            __builtin_amdgcn_raw_buffer_store_b32(val, rsrc_s, loc * 4, up_off, 0);   // byte_pair_difference == store-table value (screen.py:383-398)
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)val, rsrc_s, loc * 2, up_off, 0);   // byte_pair_difference == store-table value (screen.py:383-398); <= 2047: the 16-bit copy
             __builtin_amdgcn_raw_buffer_store_b8((unsigned char)c, rsrc_s, loc, mem_off, 0);
             if (val == 0) {
                 atomicAnd(&nz[p * 8 + (off >> 5)], ~(1u << (off & 31)));

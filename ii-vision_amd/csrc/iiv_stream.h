@@ -37,7 +37,7 @@ constexpr int kMaxValue = 2047;  // every table value and diff weight must fit 1
 
 struct StreamState {
     uint8_t mem[2][8192];     // [is_aux] Video.memory_map / aux_memory_map
-    int32_t up[2][8192];      // [is_aux] Video.update_priority / aux_update_priority
+    int32_t up[2][8192];      // [is_aux] Video.update_priority / aux_update_priority -- as the HOST sees it; the kernels' copy is up16 (below)
     uint32_t wd[8192];        // live generator: see above
     uint32_t order[8192];     // sorted initial entries: page << 8 | offset | target content << 16
     uint32_t nzbits[256];     // bit = update_priority != 0 (as left by the last launch)
@@ -56,7 +56,19 @@ struct StreamState {
     // decided, real (not padding) opcodes, launches that emitted something
     unsigned long long stat_exact, stat_ops, stat_runs;
     unsigned long long stamps[32];  // diagnostic builds only (-DIIV_STAMPS): prologue s_memtime stamps [0,16), greedy phase cycles [16,24)
+    // What the kernels read and write of the priorities: 16 bits per byte, kUpBig = "the value is in up[]" (negative, or
+    // >= 65535: priorities grow by a diff weight per call while a byte waits).  The prologue adds a diff weight to EVERY
+    // priority in EVERY call (video.py:115-116): as int32 that is 64 of the ~142 KB a call moves through HBM, and the call is
+    // within 15 % of what this box's HBM copies.  up[] is exact wherever up16 says kUpBig and is brought up to
+    // date everywhere before the host looks (iiv_encode.hip: materialise_up_kernel / compact_up_kernel).
+    uint16_t up16[2][8192];
 };
+constexpr uint32_t kUpBig = 0xffffu;
+__device__ inline int32_t up_value(const StreamState &S, int b, int i)
+{
+    const uint32_t v = S.up16[b][i];
+    return v == kUpBig ? S.up[b][i] : (int32_t)v;
+}
 
 enum { kErrNone = 0, kErrHoles = 1, kErrNegative = 2, kErrPaletteBit = 3, kErrPushedOverflow = 4, kErrNoGenerator = 5, kErrGuard = 6, kErrSortBudget = 7, kErrBankMix = 8 };
 

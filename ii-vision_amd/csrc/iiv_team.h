@@ -136,7 +136,7 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
     const uint8_t *tgt_frames = (MODE == kDHGR && is_aux ? frames_aux : frames_main) +
                                 ((size_t)blockIdx.x * n_frames + frame) * 8192;
     const uint4 *wd_rows = reinterpret_cast<const uint4 *>(wd_lds);
-    int32_t *up = S.up[is_aux];
+    uint16_t *up = S.up16[is_aux];   // (the kernels' 16-bit copy of the priorities: a store value is <= 2047)
     uint8_t *mem = S.mem[is_aux];
     const int wsel = lane >> 3;          // this lane's word inside a page's 8 bitmap words
     const int sh0 = (4 * lane) & 31;     // its 4 bits inside that word
@@ -337,7 +337,7 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
         if (lane < 1 + kSlots) {
             const int off = lane == 0 ? x : lane == 1 ? y1e : lane == 2 ? y2e : y3e;
             const uint32_t val = lane == 0 ? 0u : lane == 1 ? v1 : lane == 2 ? v2 : v3;
-            up[p * 256 + off] = (int32_t)val;
+            up[p * 256 + off] = (uint16_t)val;
             mem[p * 256 + off] = (uint8_t)c;
             if (val == 0) {
                 atomicAnd(&nz[p * 8 + (off >> 5)], ~(1u << (off & 31)));

@@ -391,12 +391,12 @@ __global__ __launch_bounds__(256) void greedy_kernel(StreamState *__restrict__ s
                 // error the chosen byte leaves: then the location stays live for a later pop of a stale bag entry, as in the
                 // oracle's definition, video.py:130)
                 dwf[p * 256 + x] = (JOINT && joint_res) ? (uint16_t)0x8000u : (uint16_t)0;
-                S.up[is_aux][p * 256 + x] = JOINT ? (int32_t)joint_res : 0;
+                S.up16[is_aux][p * 256 + x] = JOINT ? (uint16_t)joint_res : (uint16_t)0;   // (store values are <= 2047: the 16-bit copy)
                 S.mem[is_aux][p * 256 + x] = (uint8_t)c;
             }
             if (y == y1 || y == y2) {
                 const int second = (y == y2) ? 1 : 0;
-                S.up[is_aux][p * 256 + y] = (int32_t)nd;  // byte_pair_difference == nd[y] (screen.py:383-398)
+                S.up16[is_aux][p * 256 + y] = (uint16_t)nd;  // byte_pair_difference == nd[y] (screen.py:383-398)
                 S.mem[is_aux][p * 256 + y] = (uint8_t)c;
                 dwf[p * 256 + y] = (uint16_t)((w & 0x7fffu) | (nd ? 0x8000u : 0u));
                 if (nd) {

@@ -104,6 +104,10 @@ def test_priorities_beyond_16_bits(native, O, oracle_tables, device_tables):
     64-bit keys must still order it, and the prefix selection must bucket it."""
     rng = np.random.default_rng(2)
     big = rng.integers(0, 300000, (32, 256)).astype(np.int32)
+    # (the kernels keep a 16-bit copy whose largest value means "see the 32-bit array": values at and around that boundary,
+    # and ones a single diff weight carries across it)
+    big[3, :12] = [65533, 65534, 65535, 65536, 65537, 65535 - 2047, 65535 - 300, 65535 - 1, 131071, 131072, 1, 0]
+    big[17, 100:110] = np.arange(65530, 65540)
     big[:, HOLES] = 0
     fr = rng.integers(0, 128, (1, 1, 2, 32, 256), dtype=np.uint8)
     fr[..., HOLES] = 0
