@@ -363,7 +363,7 @@ def main(argv=None, backend_cls=None):
     n_frames = args.steps * F if wraps else (args.steps + args.warmup) * F
     S = args.streams
     if S <= 0:
-        per_clip = n_frames * 8192 * (2 if dhgr else 1) + 260 * 1024 + F * OPS_PER_FRAME * 6   # frames + stream state + opcodes
+        per_clip = n_frames * 8192 * (2 if dhgr else 1) + 300 * 1024 + F * OPS_PER_FRAME * 6   # frames + stream state (292 KB) + opcodes
         # 7168 one-wave streams are resident at a time (28 per CU): 14336 = two full rounds per launch
         # (+2 % over 12288, whose second round is 71 % full); it needs 246 of a free MI355X's 287 GiB
         S = next((c for c in (14336, 12288, 6144, 3072, 1536) if c * per_clip + (3 << 30) <= 0.88 * be.free_bytes()), 1536)
