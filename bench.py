@@ -48,8 +48,11 @@ BYTES_PER_FRAME = {"DHGR": 657e3, "HGR": 409e3}   # (1 + 490/292
 GATHER_CEILING_GLOADS_HGR = 995.0    # tools/gather_ceiling D 14336 HGR (3.61 ms per launch of 490 opcodes)
 GATHER_CEILING_GLOADS = 1184.2   # tools/gather_ceiling.hip, variant D (profiles/r02l_gather_ceiling.txt)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
-HBM_MEASURED_COPY_GBS = 4610.0     # the same run: torch copy_ of 4 GiB, read + write bytes per second
-HBM_MEASURED_READ_GBS = 5990.0     # tools/hbm_copy_bench.py on the same box (profiles/r01f_hbm_copy.txt); copy 4610, write 6900
+# What an MI355X box of this pool streams, best of tools/hbm_stream.hip's launch shapes (profiles/r04_hbm_stream.txt; 4 GiB,
+# 16 B per lane): copy = read + write bytes per second.  (torch's own kernels, profiles/r01f_hbm_copy.txt: copy 4610, read
+# 5990, fill 6900.)
+HBM_MEASURED_COPY_GBS = 5560.0
+HBM_MEASURED_READ_GBS = 7070.0
 PALETTE_IDS = {"NTSC": 5, "IIGS": 0}   # palette.py:18-23
 
 
@@ -625,7 +628,7 @@ def _roofline_objects(be, args, prof, op_count, seg_count, S, elapsed, live_ceil
     }
     out["roofline_prologue"]["frac"] = out["roofline_prologue"]["achieved"] / HBM_PEAK_GBS
     # what the counters saw of it (committed run), and the yardstick that fits a kernel whose traffic is half reads, half
-    # writes: the box's measured copy rate (torch copy_ of 4 GiB: read + write bytes per second), not its nominal peak
+    # writes: the box's measured copy rate (a streaming copy kernel, read + write bytes per second), not its nominal peak
     p_traffic, p_src = _pmc_traffic(args.mode, S, _input_kind(args), getattr(args, "fourth", False),
                                     "prologue_hbm_bytes_per_launch_per_stream", "prologue_kernel")
     out["roofline_prologue"].update({
