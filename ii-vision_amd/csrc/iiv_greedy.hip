@@ -56,6 +56,12 @@ namespace iiv {
 #ifndef IIV_SHARED_W
 #define IIV_SHARED_W 8
 #endif
+#ifndef IIV_TAKE_CHECK_PLAIN
+#define IIV_TAKE_CHECK_PLAIN 1
+#endif
+#ifndef IIV_TAKE_CHECK_SHARED
+#define IIV_TAKE_CHECK_SHARED 0   // 1: the LDS-shared form also tests an entry's live bit when it takes it off the window (see take())
+#endif
 #ifndef IIV_SHARED_W_HGR
 #define IIV_SHARED_W_HGR 16
 #endif
@@ -391,10 +397,11 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
     // One greedy step on list entry e = page << 8 | offset | content << 16 with what was loaded
     // for it.  Returns false if the entry's priority is gone (video.py:130: nothing happens);
     // otherwise an opcode is emitted or err is set.
-    auto step = [&](auto track, uint32_t e, const Loaded &L) -> bool {
+    // (nzw, pdw: this lane's words of the page's two bitmaps, read by the caller as early as the previous step's updates allow --
+    // the step's first decision hangs on them, and an LDS round trip at its start is a stall at raised priority)
+    auto step = [&](auto track, uint32_t e, const Loaded &L, uint32_t nzw, uint32_t pdw) -> bool {
         const int p = (e >> 8) & 31, x = e & 255;
         const uint32_t c = (e >> 16) & 0xffu;  // video.py:134
-        uint32_t nzw = nz[p * 8 + wsel], pdw = pdone[p * 8 + wsel];
         const uint32_t xword = (uint32_t)__builtin_amdgcn_readlane((int)nzw, (x >> 5) * 8);
         if (!((xword >> (x & 31)) & 1u)) return false;
         if (MODE == kDHGR && c >= 0x80) {  // video.py:137
@@ -592,9 +599,14 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
                 // byte exactly, video.py:159-170): it would cost a full pipeline slot -- row, eight table
                 // loads, a step that finds it dead.  On image-like input that is 0.6 slots per opcode
                 // (tools/greedy_phases.py); one LDS word per entry taken avoids them.
-                const uint32_t loc = e & 0x1fffu;
-                const uint32_t w = IIV_SGPR(nz[loc >> 5]);
-                if (!((w >> (loc & 31)) & 1u)) continue;
+                // (The LDS-shared form runs on input whose steps the nonces rarely decide -- iiv_encode.hip: shared_form_now --
+                // and there hardly an entry dies in that interval (S-iid: none, S-coh / S-static: IIV_TAKE_CHECK_SHARED=1 measured);
+                // a take is on every step's critical path and the round trip costs that form 4 %: it does without.)
+                if constexpr ((W == 1 && IIV_TAKE_CHECK_PLAIN) || (W > 1 && IIV_TAKE_CHECK_SHARED)) {
+                    const uint32_t loc = e & 0x1fffu;
+                    const uint32_t w = IIV_SGPR(nz[loc >> 5]);
+                    if (!((w >> (loc & 31)) & 1u)) continue;
+                }
                 next_head = win_base + (int)(e >> 24) + 1;
                 return e | 0x80000000u;  // (bit 31 marks a real entry: page 0 / offset 0 / content 0 is a valid one)
             }
@@ -637,6 +649,8 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
             asm volatile("" : "+v"(row.x), "+v"(row.y), "+v"(row.z), "+v"(row.w));   // (the row's arrival, timed on its own)
             IIV_PHASE(3);
 #endif
+            // A's bitmap words (the previous step's updates are in program order behind us; nothing up to step() changes them)
+            const uint32_t nzA = nz[((eA >> 8) & 31) * 8 + wsel], pdA = pdone[((eA >> 8) & 31) * 8 + wsel];
             gather8(row, eB >> 16 & 0xffu, nxt);
             // every use of the old row is scheduled before the new one is requested, so that the
             // load can land in the same registers (otherwise: a copy, and a wait in front of it)
@@ -656,7 +670,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
             // issuing loads is a cycle its own next loads start later (+1 % DHGR, +1.2 % HGR; raising the load issue
             // instead costs HGR 5 %).
             __builtin_amdgcn_s_setprio(IIV_STEP_PRIO);
-            (void)step(std::false_type{}, eA, cur);
+            (void)step(std::false_type{}, eA, cur, nzA, pdA);
             __builtin_amdgcn_s_setprio(0);
             IIV_PHASE(2);   // wait for the table words, score, apply
             head = hA;
@@ -745,7 +759,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
             gather8(w, c, L);
             twist_now();
             push_f1 = push_f2 = push_f3 = 0;
-            (void)step(std::true_type{}, e, L);
+            (void)step(std::true_type{}, e, L, nz[((e >> 8) & 31) * 8 + wsel], pdone[((e >> 8) & 31) * 8 + wsel]);
             // the sub-bag's new minimum, then what this step pushed
             uint32_t mk = rk[0], mi = ridx[0];
 #pragma unroll
