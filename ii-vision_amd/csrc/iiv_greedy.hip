@@ -211,7 +211,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
     // after a block switch only words 0..255 of the current block are in place until twist_now()
     bool twist_pending = false;
     auto twist_now = [&]() {
-        if (twist_pending) {
+        if (__builtin_expect(twist_pending, 0)) {
             gen_rest();
             gen_ahead();
             twist_pending = false;
@@ -330,11 +330,11 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
         const uint32_t v1 = nd1, v2 = nd2, v3 = FOUR ? nd3 : 0u;   // (a missing winner's value is 0: step() leaves it so)
         const int y1e = y1 >= 0 ? y1 : x, y2e = y2 >= 0 ? y2 : x, y3e = (FOUR && y3 >= 0) ? y3 : x;   // video.py:185-186
         const int f1 = v1 ? 1 : 0, f2 = v2 ? 1 : 0, f3 = v3 ? 1 : 0;
-        if (n_pushed + f1 + f2 + f3 > kPushedCap) {
+        if (__builtin_expect(n_pushed + f1 + f2 + f3 > kPushedCap, 0)) {
             err = kErrPushedOverflow;
             return;
         }
-        if (mt_idx + C + (FOUR ? 3 : 2) >= 256) twist_now();
+        if (__builtin_expect(twist_pending && mt_idx + C + (FOUR ? 3 : 2) >= 256, 0)) twist_now();
         // lanes 0..2 = (x, 0), (y1e, v1), (y2e, v2): three scalars written into lanes of one register each
         // (a `lane == k ? a : b` chain compiles to selects on loop-invariant lane masks, which the
         // allocator then spills and reloads on every step)
@@ -383,8 +383,8 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
         draws += (uint32_t)(C + f1 + f2 + f3);
         n_pushed += f1 + f2 + f3;
         done++;
-        if (done - ob_base == 64) flush_ops();
-        if (mt_idx >= 624) {
+        if (__builtin_expect(done - ob_base == 64, 0)) flush_ops();
+        if (__builtin_expect(mt_idx >= 624, 0)) {
             // the next block becomes the current one: its head moves down now, the rest of it
             // and the new head are generated later, while table loads are in flight
             // (twist_now), at the latest before a step reads past word 255
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
         const int p = (e >> 8) & 31, x = e & 255;
         const uint32_t c = (e >> 16) & 0xffu;  // video.py:134
         const uint32_t xword = (uint32_t)__builtin_amdgcn_readlane((int)nzw, (x >> 5) * 8);
-        if (!((xword >> (x & 31)) & 1u)) return false;
+        if (__builtin_expect(!((xword >> (x & 31)) & 1u), 0)) return false;
         if (MODE == kDHGR && c >= 0x80) {  // video.py:137
             err = kErrPaletteBit;
             return true;
@@ -460,14 +460,14 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
                 n2 += (int)__popcll(__ballot(((uint32_t)(ke[r] ^ K) >> kWdDwShift) == 0u));
             return n2 > 1;
         };
-        if (K1 < 0) {
+        if (__builtin_expect(K1 < 0, 1)) {
             y1 = K1 & 255;
             nd1 = nd_in(K1);
             // (the lane that held a winner moves its next key up)
             const bool hit1 = k1 == K1;
             const int c1 = hit1 ? k2 : k1;
             const int K2 = wave_min_i32(c1);
-            if (K2 < 0) {
+            if (__builtin_expect(K2 < 0, 1)) {
                 y2 = K2 & 255;
                 nd2 = nd_in(K2);
                 tie = (K1 >> kWdDwShift) == (K2 >> kWdDwShift);
@@ -494,7 +494,8 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
             if (n1 <= 2) n_ties_small++;
         }
 #endif
-        if (tie) {
+        // (the LDS-shared form is dispatched to input whose steps the nonces rarely decide: lay the exact path out of line there)
+        if (W > 1 ? __builtin_expect(tie, 0) : tie) {
             // the reference's (delta, nonce, offset) heap order with every candidate's nonce
             // materialised: one random.getrandbits(8) per candidate in ascending offset
             // (video.py:290-293)
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
         // next live entry, or 0 when the list is used up; *next_head = list position after it
         auto take = [&](int &next_head) -> uint32_t {
             for (;;) {
-                while (qi >= n_dense) {
+                while (__builtin_expect(qi >= n_dense, 0)) {
                     if (win_end >= n_sorted) return 0u;
                     refill();
                 }
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
             const uint32_t eD = (active && eC) ? take(hD) : 0u;
             row = row_of(eD);
             IIV_PHASE(0);   // wait for the row, issue eight table loads, take an entry, request its row
-            if (!active) return false;
+            if (__builtin_expect(!active, 0)) return false;
             twist_now();  // (the MT19937 block generation hides behind the loads)
             IIV_PHASE(1);   // MT19937 block generation
 #ifdef IIV_STAMPS
@@ -680,7 +681,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
             hB = hC;
             eC = eD;
             hC = hD;
-            if (--guard < 0) err = kErrGuard;
+            if (__builtin_expect(--guard < 0, 0)) err = kErrGuard;
             return eA && done < n_ops && !err;
         };
         if (eA && done < n_ops) {
