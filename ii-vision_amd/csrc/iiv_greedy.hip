@@ -585,6 +585,9 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
             // the others fill the lanes behind them
             const int dst = v ? prefix_popc(mask) : n_dense + prefix_popc(~mask);
             dense_e = (uint32_t)__builtin_amdgcn_ds_permute(dst << 2, (int)((e & 0x00ffffffu) | ((uint32_t)lane << 24)));
+            // (the permute's result is waited for HERE, once per window: left pending, the compiler puts an lgkmcnt(0) in front of
+            // every take's v_readlane of this register -- behind the table reads a half-iteration has just issued)
+            asm volatile("" : "+v"(dense_e));
             win_base = start;
             win_end = start + 64 < n_sorted ? start + 64 : n_sorted;
         };
