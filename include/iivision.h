@@ -248,7 +248,9 @@ void iiv_encoder_destroy(iiv_encoder *enc);
                                   * one-wave kernel; needs dm at creation); not together with IIV_CONTENT_JOINT. */
 int iiv_encoder_set_option(iiv_encoder *enc, int option, int value);
 
-/* state items, per stream */
+/* state items, per stream.  (The priorities are int32 here, as in the reference; the kernels work on a 16-bit copy of them --
+ * 65535 = "see the int32 entry" -- which get_state / get_video_state bring into the int32 arrays before they copy and
+ * set_state / set_video_state refill afterwards: DESIGN.md 5, StreamState::up16.) */
 #define IIV_STATE_MEM_MAIN 0 /* Video.memory_map.page_offset        u8  [32][256] */
 #define IIV_STATE_MEM_AUX 1  /* Video.aux_memory_map.page_offset    u8  [32][256] */
 #define IIV_STATE_UP_MAIN 2  /* Video.update_priority               i32 [32][256] */
