@@ -324,6 +324,23 @@ class GpuBackend:
         return self.args.greedy != "workgroup" and not self.args.joint
 
 
+class _QuietStdout:
+    """The driver reads ONE JSON line from stdout; what libraries write there at C level (RCCL's version banner, gloo's
+    connection notice) goes to stderr: file descriptor 1 points at stderr while the bench runs and is put back for the line."""
+
+    def __init__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def restore(self):
+        if self.saved is not None:
+            sys.stdout.flush()
+            os.dup2(self.saved, 1)
+            os.close(self.saved)
+            self.saved = None
+
+
 def main(argv=None, backend_cls=None):
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and backend_cls is None:
@@ -334,6 +351,14 @@ def main(argv=None, backend_cls=None):
         return None
     if backend_cls is None:
         backend_cls = _resolve_backend(args.backend)
+    quiet = _QuietStdout()
+    try:
+        return _run(args, backend_cls, quiet)
+    finally:
+        quiet.restore()
+
+
+def _run(args, backend_cls, quiet):
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
@@ -473,7 +498,9 @@ def main(argv=None, backend_cls=None):
                     out["img"] = _hgr_leg(be, args, local_rank, world, steps=4, mode="DHGR", img=True)
                 out["fourth_offset"] = _hgr_leg(be, args, local_rank, world, steps=4, mode="DHGR", fourth=True)
 
+        quiet.restore()
         print(json.dumps(out))
+        sys.stdout.flush()
     if use_dist:
         dist.destroy_process_group()
     return out
