@@ -130,6 +130,10 @@ def parse_args(argv=None):
                     help="(default unless --no-extras) also time encode -> .a2m byte emission -> pinned host "
                          "memory, end to end; kept as a flag for older command lines")
     ap.add_argument("--no-emit", action="store_true", help="skip the end-to-end emission leg")
+    ap.add_argument("--dist-backend", choices=["gloo", "nccl"], default=os.environ.get("IIV_BENCH_DIST_BACKEND", "gloo"),
+                    help="process group of an N > 1 run.  The path has NO collective (north_star: 'no RCCL'): the group only carries "
+                         "the barriers around the timed region and three scalars (MIN clip count, MAX elapsed, per-rank figures), "
+                         "which run on CPU tensors over gloo by default; 'nccl' (= RCCL) puts the same three scalars on the device")
     ap.add_argument("--backend", default=os.environ.get("IIV_BENCH_BACKEND", ""),
                     help="tests only: 'module:Class' standing in for GpuBackend (tests/bench_standin.py runs main() "
                          "without a device; the product path has no CPU fallback)")
@@ -152,11 +156,26 @@ REHEARSE = os.environ.get("IIV_BENCH_REHEARSE_ON_ONE_GPU") == "1"
 
 
 def visible_gpus():
-    """Devices this process could bind ranks to.  torch.cuda.device_count() does not initialise the HIP runtime on
-    this image (nothing here may: the launcher below starts children, and a process that has touched the GPU must
-    not)."""
-    import torch
-    return int(torch.cuda.device_count())
+    """GPUs this process could bind ranks to, counted WITHOUT the HIP runtime (the launcher below starts children, and a
+    process that has touched the GPU must not): the *_VISIBLE_DEVICES lists if set, else the GPU nodes of the KFD
+    topology in sysfs.  None = unknown (no refusal is based on it; a rank without a device fails by itself)."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    import glob
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    n = 0
+    for f in nodes:
+        try:
+            props = dict(l.split()[:2] for l in open(f) if len(l.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:   # (CPU nodes have none)
+                n += 1
+        except Exception:
+            return None
+    return n
 
 
 def launch_ranks(args, argv):
@@ -167,18 +186,30 @@ def launch_ranks(args, argv):
     `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` would give them -- forwards rank 0's
     single JSON line, and exits non-zero if any rank fails (the others are then terminated by pid)."""
     import socket
-    import subprocess
     n = int(args.gpus)
     backend = _resolve_backend(args.backend)
     if getattr(backend, "is_gpu", True) and not REHEARSE:
         have = visible_gpus()
-        if have < n:
+        if have is not None and have < n:
             sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible to this process\n" % (n, have))
             return 2
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     cmd = [sys.executable, os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+    # (the rendezvous port is found by binding port 0 and closing the socket: another process can take it before rank 0
+    # listens on it -- a run whose ranks fail within the first minute is started once more on a fresh port)
+    for attempt in (0, 1):
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        t_start = time.time()
+        rc = _run_ranks(cmd, n, port)
+        if rc == 0 or attempt == 1 or time.time() - t_start > 60.0:
+            return rc
+        sys.stderr.write("bench.py: ranks failed within %.0f s of their start; once more on a fresh rendezvous port\n" % (time.time() - t_start))
+    return rc
+
+
+def _run_ranks(cmd, n, port):
+    import subprocess
     import tempfile
     procs = []
     with tempfile.TemporaryFile("w+") as out0:
@@ -222,7 +253,7 @@ class GpuBackend:
     """Everything bench.main() does on the device.  tests/test_multiprocess_gloo.py runs main() with
     a CPU stand-in for this class, so that the multi-rank control flow is executed before hardware sees it."""
 
-    dist_backend = "nccl"
+    dist_backend = "gloo"
     is_gpu = True
 
     def __init__(self, args, local_rank, world):
@@ -230,16 +261,23 @@ class GpuBackend:
         import _iiv_native as native
         import stream_batch
         self.torch, self.native, self.sb = torch, native, stream_batch
+        if world > 1 and not REHEARSE:
+            have = visible_gpus()   # (in front of set_device, which would raise first with a less helpful message)
+            if have is not None and have <= local_rank:
+                raise SystemExit("bench.py: rank %s has no GPU %d (%d visible)" % (os.environ.get("RANK", "?"), local_rank, have))
         torch.cuda.set_device(local_rank if world > 1 and not REHEARSE else 0)
         self.device = torch.device("cuda", torch.cuda.current_device())
-        if REHEARSE:
-            self.dist_backend, self.coll_device = "gloo", torch.device("cpu")
+        # The path has no collective: what crosses ranks is two barriers and three scalars.  They live on CPU tensors over
+        # gloo unless --dist-backend nccl asks for RCCL (which two ranks sharing one device, the rehearsal, cannot use).
+        self.dist_backend = "gloo" if REHEARSE else getattr(args, "dist_backend", "gloo")
+        if self.dist_backend == "gloo":
+            self.coll_device = torch.device("cpu")
         self.args = args
         self.mode = native.DHGR if args.mode == "DHGR" else native.HGR
         self.dhgr = self.mode == native.DHGR
 
     def dist_kwargs(self):
-        return {} if REHEARSE else {"device_id": self.device}
+        return {"device_id": self.device} if self.dist_backend == "nccl" else {}
 
     def free_bytes(self):
         return self.torch.cuda.mem_get_info()[0]
@@ -299,8 +337,9 @@ class GpuBackend:
         return segs
 
     def first_ops(self, segs):
-        """Clip 0's opcodes of the step just run (Encoder.encode returns the rows as they were packed)."""
-        return self.last_ops[0].clone()
+        """The opcodes of the step just run for the clips the oracle re-encodes afterwards -- the first, the middle and the
+        last stream of the batch (Encoder.encode returns the rows as they were packed): {stream: (n, 6) tensor}."""
+        return {s: self.last_ops[s].clone() for s in sorted({0, self.S // 2, self.S - 1})}
 
     def check(self):
         self.batch.enc.check()
@@ -367,10 +406,8 @@ def _run(args, backend_cls, quiet):
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (the launcher's rank count and --gpus must agree)" % (args.gpus, world))
     be = backend_cls(args, local_rank, world)
-    if getattr(be, "is_gpu", True) and world > 1 and not REHEARSE and visible_gpus() <= local_rank:
-        raise SystemExit("bench.py: rank %d has no GPU %d (%d visible)" % (rank, local_rank, visible_gpus()))
     # the process group exists for N > 1 only; IIV_BENCH_FORCE_DIST=1 creates it for one rank too, so that
-    # the RCCL initialisation, the barrier and the two scalar reductions can be exercised on a 1-GPU box
+    # the process-group initialisation (gloo, or RCCL with --dist-backend nccl), the barrier and the scalar reductions can be exercised on a 1-GPU box
     # (python -m torch.distributed.run --nproc-per-node 1 ... bench.py)
     use_dist = world > 1 or os.environ.get("IIV_BENCH_FORCE_DIST") == "1"
     if use_dist:
@@ -479,7 +516,7 @@ def _run(args, backend_cls, quiet):
                 out["emit"] = _emit_end_to_end(be, args, fps)
             out["make_data_tables_s"] = _make_data_tables_seconds()
         if not args.no_cpu_baseline and n_gpus == 1 and be.is_gpu:
-            out["cpu_baseline"] = _cpu_baseline(be, seeds[0], args, ops_check=(first_ops.cpu().numpy(), F))
+            out["cpu_baseline"] = _cpu_baseline(be, seeds, args, ops_check=({s: t.cpu().numpy() for s, t in first_ops.items()}, F))
             out["cpu_baseline_all_cores"] = _cpu_baseline_all_cores(be, seeds, args)
             port_fps = out["cpu_baseline"]["value"]
             out["vs_reference_python"] = _vs_reference(args.mode, fps, port_fps)
@@ -595,6 +632,19 @@ def _pmc_traffic(mode, S, kind="iid", fourth=False, field="greedy_hbm_bytes_per_
         return None, None
 
 
+def _pmc_issue(mode, kind="iid", fourth=False):
+    """The `issue` object of the committed counter run for this mode / input (tools/profile_summary.py: issue_of): what the SQ
+    counters say binds the greedy kernel -- instructions per opcode and wave, instructions per clock and SIMD, vector-pipe
+    busy fraction, waves per SIMD.  None when no counter run of this mode / input / option is committed."""
+    key = mode if kind == "iid" else "%s:%s" % (mode, kind)
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            d = json.load(f)
+        return None if fourth else d.get(key, {}).get("issue")
+    except Exception:
+        return None
+
+
 def _roofline_objects(be, args, prof, op_count, seg_count, S, elapsed, live_ceiling):
     """roofline (greedy kernel, dominant), roofline_access_pattern, roofline_prologue, kernel_time_share of one
     timed leg, from the HIP events the library records around its launches on the launch stream."""
@@ -604,9 +654,16 @@ def _roofline_objects(be, args, prof, op_count, seg_count, S, elapsed, live_ceil
     greedy_bytes = float(op_count) * S * BYTES_PER_OPCODE       # all launches of the timed region
     achieved = greedy_bytes / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
     traffic, traffic_source = _pmc_traffic(args.mode, S, _input_kind(args), getattr(args, "fourth", False))
+    issue = _pmc_issue(args.mode, _input_kind(args), getattr(args, "fourth", False)) if be.uses_wave_kernel() else None
     out["roofline"] = {
         "kernel": "greedy_wave_kernel" if be.uses_wave_kernel() else "greedy_kernel",
-        "bound": "hbm",
+        # What binds the kernel is NOT the quantity the HBM fraction below measures: a step is a chain of dependent wave
+        # reductions and scalar bookkeeping at 4-7 waves per SIMD (`issue`: instructions per clock and SIMD well below 1, the
+        # vector pipe a third busy, HBM -- `traffic_frac` -- under 0.4).  achieved / peak / frac stay the SURVEY 8(d) HBM
+        # figure (algorithmic bytes over launch time), the contract's yardstick for the path.
+        "bound": "latency",
+        "frac_is": "algorithmic HBM bytes per launch / launch time / the 8 TB/s peak (SURVEY 8d) -- the contract's yardstick, not the binding resource",
+        "issue": issue,
         "achieved": achieved,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
@@ -653,7 +710,9 @@ def _roofline_objects(be, args, prof, op_count, seg_count, S, elapsed, live_ceil
         "avg_launch_ms": p_ms / p_n,
         "launches": prof["prologue_launches"],
     }
-    out["roofline_prologue"]["frac"] = out["roofline_prologue"]["achieved"] / HBM_PEAK_GBS
+    # (frac below = the counters' real HBM traffic over the peak; the SURVEY 8(d) per-call figure, which the kernel no longer
+    # moves -- 16-bit priorities, recomputed diff weights -- is kept beside it as algorithmic_frac)
+    out["roofline_prologue"]["algorithmic_frac"] = out["roofline_prologue"]["achieved"] / HBM_PEAK_GBS
     # what the counters saw of it (committed run), and the yardstick that fits a kernel whose traffic is half reads, half
     # writes: the box's measured copy rate (a streaming copy kernel, read + write bytes per second), not its nominal peak
     p_traffic, p_src = _pmc_traffic(args.mode, S, _input_kind(args), getattr(args, "fourth", False),
@@ -664,6 +723,15 @@ def _roofline_objects(be, args, prof, op_count, seg_count, S, elapsed, live_ceil
         "peak_measured_copy": HBM_MEASURED_COPY_GBS,
         "traffic_over_measured_copy": (p_traffic / (p_ms / p_n * 1e-3) / 1e9 / HBM_MEASURED_COPY_GBS) if (p_traffic and p_ms > 0) else None,
     })
+    rp = out["roofline_prologue"]
+    rp["algorithmic_achieved"] = rp["achieved"]
+    if rp["traffic_frac"] is not None:
+        rp["achieved"] = rp["traffic"] / (p_ms / p_n * 1e-3) / 1e9
+        rp["frac"] = rp["traffic_frac"]
+        rp["frac_is"] = "HBM bytes per launch seen by the counters (committed run: traffic_source) / this run's launch time / the 8 TB/s peak"
+    else:
+        rp["frac"] = rp["algorithmic_frac"]
+        rp["frac_is"] = "SURVEY 8(d) algorithmic bytes per call / launch time / peak (no committed counter run for this mode / input)"
     out["kernel_time_share"] = {"greedy": g_ms / (1000 * elapsed), "prologue": p_ms / (1000 * elapsed)}
     return out
 
@@ -702,7 +770,7 @@ def _hgr_leg(be, args, local_rank, world, steps=6, warmup=1, mode="HGR", fourth=
         out["nonce_decided_share_of_steps"] = round(share, 4)
         out["greedy_form"] = form
     if fourth:
-        o = leg["first_ops"].cpu().numpy().reshape(-1, 6)[:, 2:6]
+        o = leg["first_ops"][0].cpu().numpy().reshape(-1, 6)[:, 2:6]
         o.sort(axis=1)
         out["distinct_offsets_per_opcode"] = float(((o[:, 1:] != o[:, :-1]).sum(axis=1) + 1).mean())
         out["note"] = ("IIV_OPT_FOURTH_OFFSET: up to three extra offsets per opcode instead of the reference's two and a copy of "
@@ -902,36 +970,48 @@ def _emit_end_to_end(be, args, resident_fps):
                     "double-buffered; %d steps" % args.steps}
 
 
-def _cpu_baseline(be, seed, args, ops_check):
-    """Oracle (single-thread C port of video.py/screen.py) on stream 0's first frames."""
+def _cpu_baseline(be, seeds, args, ops_check):
+    """Oracle (single-thread C port of video.py/screen.py) on stream 0's first frames -- the timed sample -- and, as the
+    checker, on the first step's frames of every stream whose GPU opcodes `ops_check` holds (first / middle / last stream
+    of the batch: the 14336-stream launches of the persistent workgroups, sampled across the queue)."""
     import numpy as np
     import oracle as O
     import stream_batch
     fm, fa = be.fm, be.fa
     n = min(args.cpu_frames, fm.shape[1])
-    main = fm[0, :n].cpu().numpy()
-    aux = fa[0, :n].cpu().numpy() if fa is not None else None
     _, dm = O.cie2000_matrix(O.PALETTE_RGB[PALETTE_IDS[args.palette]])
     tab = O.build_table(be.mode, dm, symmetric=True)   # untimed, like the GPU's table build
-    v = O.Video(be.mode, tab, seed_py=seed[0], seed_np=seed[1])
-    v.set_joint(args.joint)
-    v.set_fourth_offset(args.fourth)
-    segs = stream_batch.MovieClock(be.dhgr).segments(n)
-    t0 = time.perf_counter()
-    got = []
-    for (fr, ia, restart, k) in segs:
-        if restart:
-            v.encode_frame(main[fr], aux[fr] if aux is not None else None, ia)
-        got.append(v.next(k))
-    dt = time.perf_counter() - t0
+
+    def encode(stream, n_fr):
+        main = fm[stream, :n_fr].cpu().numpy()
+        aux = fa[stream, :n_fr].cpu().numpy() if fa is not None else None
+        v = O.Video(be.mode, tab, seed_py=seeds[stream][0], seed_np=seeds[stream][1])
+        v.set_joint(args.joint)
+        v.set_fourth_offset(args.fourth)
+        segs = stream_batch.MovieClock(be.dhgr).segments(n_fr)
+        t0 = time.perf_counter()
+        got = []
+        for (fr, ia, restart, k) in segs:
+            if restart:
+                v.encode_frame(main[fr], aux[fr] if aux is not None else None, ia)
+            got.append(v.next(k))
+        return np.concatenate(got), time.perf_counter() - t0
+
+    cpu0, dt = encode(0, n)
     parity = None
     if ops_check is not None:
-        # the oracle as the checker: the GPU's opcode stream of this clip's first frames, bit for bit
-        gpu_ops, nf = ops_check
-        cpu_ops = np.concatenate(got)[: gpu_ops.shape[0]]
-        parity = {"stream": 0, "frames": int(min(nf, n)), "opcodes": int(cpu_ops.shape[0]),
-                  "equal": bool(cpu_ops.shape == gpu_ops[: cpu_ops.shape[0]].shape
-                                and (cpu_ops == gpu_ops[: cpu_ops.shape[0]]).all())}
+        # the oracle as the checker: the GPU's opcode streams of these clips' first frames, bit for bit
+        gpu, nf = ops_check
+        nf = int(min(nf, n))
+        per = []
+        for stream in sorted(gpu):
+            g = gpu[stream]
+            c = cpu0 if stream == 0 else encode(stream, nf)[0]
+            c = c[: g.shape[0]]
+            per.append({"stream": int(stream), "opcodes": int(c.shape[0]),
+                        "equal": bool(c.shape == g[: c.shape[0]].shape and (c == g[: c.shape[0]]).all())})
+        parity = {"streams": [p_["stream"] for p_ in per], "frames": nf, "opcodes": int(sum(p_["opcodes"] for p_ in per)),
+                  "equal": all(p_["equal"] for p_ in per), "per_stream": per}
     return {
         "parity_vs_oracle": parity,
         "value": n / dt,

@@ -886,10 +886,10 @@ static int launch_round(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux,
                      // have reported: HGR shared, DHGR plain -- the better guess for each)
                      shared_form_now(e),
                      d_queue, e->fourth_offset != 0, e->d_tie_stats != nullptr && tie_stats_wanted(e)};
-        int rc = use_team ? launch_greedy_team(e->mode, a, st) : launch_greedy_wave(e->mode, a, st);
+        int form = 0;   // what launch_greedy_wave ran: 0 plain, 1 LDS-shared (it needs one bank per round and the stream counter)
+        int rc = use_team ? launch_greedy_team(e->mode, a, st) : launch_greedy_wave(e->mode, a, st, &form);
         if (rc) return rc;
-        if (e->profiling)   // (what launch_greedy_wave runs: the shared form needs one bank per round and the stream counter)
-            e->form_launches[use_team ? 2 : (a.shared && a.uniform_bank >= 0 && a.queue && a.lds_pad == 0) ? 1 : 0]++;
+        if (e->profiling) e->form_launches[use_team ? 2 : form]++;
     } else {
         const WorkgroupArgs wa{e->d_states, d_main, d_aux, n_frames, e->n_streams, d_round, seg_stride, e->d_store, e->d_left_t,
                                e->d_right_t, d_ops, ops_stride};
@@ -1061,6 +1061,14 @@ int iiv_encoder_set_option(iiv_encoder *enc, int option, int value)
 {
     if (!enc) return iiv::set_error(IIV_ERR_INVALID, "null encoder");
     return iiv::encoder_set_option(enc->impl, option, value);
+}
+
+int iiv_encoder_info(iiv_encoder *enc, int *mode, int *n_streams)
+{
+    if (!enc || !enc->impl) return iiv::set_error(IIV_ERR_INVALID, "iiv_encoder_info: null encoder");
+    if (mode) *mode = enc->impl->mode;
+    if (n_streams) *n_streams = enc->impl->n_streams;
+    return IIV_OK;
 }
 
 int iiv_encoder_get_state(iiv_encoder *enc, int stream_index, int what, void *host_buf, size_t bytes)

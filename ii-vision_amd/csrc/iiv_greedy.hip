@@ -880,10 +880,11 @@ template <int MODE, bool FOUR> static int launch_shared(const GreedyArgs &a, hip
     return IIV_OK;
 }
 
-int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st)
+int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st, int *form_out)
 {
     // (the shared form needs every stream of the round on one bank -- always so in HGR -- and the host's stream counter)
     const bool shared = a.shared && a.uniform_bank >= 0 && a.queue && a.lds_pad == 0;
+    if (form_out) *form_out = shared ? 1 : 0;
     int rc = IIV_OK;
     if (shared && a.fourth)
         rc = mode == kDHGR ? launch_shared<kDHGR, true>(a, st) : launch_shared<kHGR, true>(a, st);

@@ -359,7 +359,7 @@ struct GreedyArgs {
     bool count_stats;        // the one-wave kernel adds to the streams' stat_* fields
 };
 
-int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st);   // iiv_greedy.hip
+int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st, int *form_out = nullptr);   // iiv_greedy.hip; *form_out: 0 plain form launched, 1 LDS-shared
 int launch_greedy_team(int mode, const GreedyArgs &a, hipStream_t st);   // iiv_team.hip
 
 

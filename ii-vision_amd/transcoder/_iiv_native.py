@@ -37,7 +37,7 @@ SYMBOLS = [
     "iiv_cie2000_matrix", "iiv_delta_e_cie2000", "iiv_pixel_strings", "iiv_build_table", "iiv_build_store_table",
     "iiv_symmetrise_table", "iiv_store_table_from_table",
     "iiv_pack", "iiv_diff_weights", "iiv_compute_delta_pages",
-    "iiv_encoder_create", "iiv_encoder_destroy", "iiv_encoder_set_option",
+    "iiv_encoder_create", "iiv_encoder_destroy", "iiv_encoder_set_option", "iiv_encoder_info",
     "iiv_encoder_snapshot", "iiv_encoder_rollback", "iiv_encoder_get_state", "iiv_encoder_set_state",
     "iiv_encoder_set_state_range", "iiv_encoder_get_video_state", "iiv_encoder_set_video_state",
     "iiv_encoder_get_video_brief",
@@ -121,6 +121,8 @@ def lib():
     L.iiv_compute_delta_pages.argtypes = [i32, vp, i32, vp, vp, vp, vp, i32, vp, vp]
     L.iiv_encoder_create.argtypes = [i32, vp, vp, vp, i32, C.POINTER(vp)]
     L.iiv_encoder_set_option.argtypes = [vp, i32, i32]
+    if hasattr(L, "iiv_encoder_info") or "IIV_LIB" not in os.environ:
+        L.iiv_encoder_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.iiv_encoder_snapshot.argtypes = [vp, vp]
     L.iiv_encoder_rollback.argtypes = [vp, vp]
     L.iiv_encoder_destroy.argtypes = [vp]
@@ -152,7 +154,7 @@ def lib():
     if hasattr(L, "iiv_encoder_launch_forms") or "IIV_LIB" not in os.environ:
         L.iiv_encoder_launch_forms.argtypes = [vp, C.POINTER(C.c_int64)]
     for name in SYMBOLS:
-        if "IIV_LIB" in os.environ and name in ("iiv_encoder_launch_forms", "iiv_check_diff_weight_pieces") and not hasattr(L, name):
+        if "IIV_LIB" in os.environ and name in ("iiv_encoder_launch_forms", "iiv_check_diff_weight_pieces", "iiv_encoder_info") and not hasattr(L, name):
             continue   # (an older build under IIV_LIB: tools/ab_libs.sh)
         getattr(L, name)  # AttributeError if the library lacks a declared symbol
     _lib = L
@@ -362,6 +364,50 @@ def compute_delta_pages(mode, table, tgt_packed, pages, contents, dw_rows, is_au
 
 # ---- P3 -------------------------------------------------------------------------
 
+def encoder_info(handle):
+    """(mode, n_streams) of the encoder behind an iiv_encoder* (iiv_encoder_info): what its callers' buffers must be sized for."""
+    mode, n = C.c_int(-1), C.c_int(0)
+    check(lib().iiv_encoder_info(handle if isinstance(handle, C.c_void_p) else C.c_void_p(int(handle)), C.byref(mode), C.byref(n)))
+    return mode.value, n.value
+
+
+def validate_frames(handle, frames_main, frames_aux):
+    """iiv_encode / iiv_encode_streams read n_streams x n_frames x 8192 bytes of every bank whatever the caller's tensors
+    hold: refuse anything else here instead of letting a kernel read out of bounds.  Returns (n_streams, n_frames)."""
+    torch = _torch()
+    mode, n_streams = encoder_info(handle)
+
+    def one(t, name):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()):
+            raise ValueError("%s must be a contiguous CUDA uint8 tensor (n_streams, n_frames, 32, 256)" % name)
+        if t.dim() != 4 or tuple(t.shape[2:]) != (32, 256):
+            raise ValueError("%s has shape %s, not (n_streams, n_frames, 32, 256)" % (name, tuple(t.shape)))
+        if int(t.shape[0]) != n_streams:
+            raise ValueError("%s holds %d streams, the encoder was created for %d" % (name, int(t.shape[0]), n_streams))
+
+    one(frames_main, "frames_main")
+    n_frames = int(frames_main.shape[1])
+    if n_frames <= 0:
+        raise ValueError("frames_main holds no frame")
+    if mode == DHGR:
+        if frames_aux is None:
+            raise ValueError("DHGR needs frames_aux")
+        one(frames_aux, "frames_aux")
+        if int(frames_aux.shape[1]) != n_frames:
+            raise ValueError("frames_aux holds %d frames per stream, frames_main %d" % (int(frames_aux.shape[1]), n_frames))
+    elif frames_aux is not None:
+        one(frames_aux, "frames_aux")   # (HGR ignores it; a tensor of the wrong kind is still a caller's mistake)
+    return n_streams, n_frames
+
+
+def validate_ops_out(ops_out, need_bytes):
+    torch = _torch()
+    if not (isinstance(ops_out, torch.Tensor) and ops_out.is_cuda and ops_out.dtype == torch.uint8 and ops_out.is_contiguous()):
+        raise ValueError("ops_out must be a contiguous CUDA uint8 tensor")
+    if ops_out.numel() < need_bytes:
+        raise ValueError("ops_out holds %d bytes, this call writes %d (n_streams * total opcodes * 6)" % (ops_out.numel(), need_bytes))
+
+
 class Encoder:
     """n_streams independent video.Video states resident on the GPU."""
 
@@ -485,9 +531,9 @@ class Encoder:
         """Per-stream schedules: schedules[s] = list of (frame, is_aux, restart, n_ops) of stream s.
         Returns (ops tensor (n_streams, max total, 6), per-stream totals).  Asynchronous."""
         torch = _torch()
-        n_frames = frames_main.shape[1]
-        assert frames_main.shape[0] == self.n_streams and frames_main.is_contiguous()
-        assert len(schedules) == self.n_streams
+        _, n_frames = validate_frames(self._h, frames_main, frames_aux)
+        if len(schedules) != self.n_streams:
+            raise ValueError("%d schedules for %d streams" % (len(schedules), self.n_streams))
         flat = [g for sch in schedules for g in sch]
         segs = (Segment * max(len(flat), 1))(*[Segment(int(f), int(a), int(r), int(k)) for (f, a, r, k) in flat])
         begin = np.zeros(self.n_streams + 1, dtype=np.int32)
@@ -496,7 +542,9 @@ class Encoder:
         width = max(max(totals), 1)
         if ops_out is None:
             ops_out = torch.zeros((self.n_streams, width, 6), dtype=torch.uint8, device="cuda")
-        assert ops_out.is_contiguous() and ops_out.shape[0] == self.n_streams
+        if ops_out.dim() != 3 or int(ops_out.shape[0]) != self.n_streams or int(ops_out.shape[2]) != 6 or int(ops_out.shape[1]) < width:
+            raise ValueError("ops_out has shape %s, this call needs (%d, >= %d, 6)" % (tuple(ops_out.shape), self.n_streams, width))
+        validate_ops_out(ops_out, self.n_streams * width * 6)
         stride = ops_out.shape[1] * 6
         check(lib().iiv_encode_streams(self._h, dptr(frames_main), dptr(frames_aux), int(n_frames), segs,
                                        begin.ctypes.data_as(C.POINTER(C.c_int32)), dptr(ops_out), stride, stream_ptr()))
@@ -507,9 +555,8 @@ class Encoder:
         (frame, is_aux, restart, n_ops).  Returns the CUDA uint8 tensor
         (n_streams, total_ops, 6).  Asynchronous."""
         torch = _torch()
-        n_frames = frames_main.shape[1]
-        assert frames_main.shape[0] == self.n_streams and frames_main.is_contiguous()
-        segs = (Segment * len(segments))(*[Segment(int(f), int(a), int(r), int(k)) for (f, a, r, k) in segments])
+        _, n_frames = validate_frames(self._h, frames_main, frames_aux)
+        segs = (Segment * max(len(segments), 1))(*[Segment(int(f), int(a), int(r), int(k)) for (f, a, r, k) in segments])
         total = sum(int(s[3]) for s in segments)
         need = self.n_streams * total * 6
         if ops_out is None:
@@ -518,11 +565,7 @@ class Encoder:
             # iiv_encode packs stream s at byte s * total * 6 whatever the shape of the caller's buffer: a
             # pre-allocated buffer may be larger than this call needs (calls of a Movie-paced driver differ
             # in their opcode count), never smaller -- that would be a device write out of bounds
-            if not (ops_out.is_cuda and ops_out.dtype == torch.uint8 and ops_out.is_contiguous()):
-                raise ValueError("ops_out must be a contiguous CUDA uint8 tensor")
-            if ops_out.numel() < need:
-                raise ValueError("ops_out holds %d bytes, this call writes %d (n_streams * total opcodes * 6)"
-                                 % (ops_out.numel(), need))
+            validate_ops_out(ops_out, need)
         check(lib().iiv_encode(self._h, dptr(frames_main), dptr(frames_aux), int(n_frames), segs, len(segments),
                                dptr(ops_out), stream_ptr()))
         # the rows as they were written: (n_streams, total, 6) over the front of the buffer

@@ -61,15 +61,11 @@ def build_store_table(mode: int, dm: Tensor) -> Tensor:
 
 @torch.library.custom_op("iivision::encode", mutates_args=("ops_out",), device_types="cuda")
 def encode(handle: int, frames_main: Tensor, frames_aux: Optional[Tensor], segments: Tensor, ops_out: Tensor) -> None:
+    # (the stream count is the ENCODER's -- iiv_encode reads and writes that many streams whatever the tensors hold)
+    n_streams, n_frames = native.validate_frames(handle, frames_main, frames_aux)
     segs, s = _segments_struct(segments)
-    n_streams, n_frames = int(frames_main.shape[0]), int(frames_main.shape[1])
     total = int(s[:, 3].sum()) if s.shape[0] else 0
-    if not (frames_main.is_cuda and frames_main.dtype == torch.uint8 and frames_main.is_contiguous()):
-        raise ValueError("frames_main must be a contiguous CUDA uint8 tensor (n_streams, n_frames, 32, 256)")
-    if not (ops_out.is_cuda and ops_out.dtype == torch.uint8 and ops_out.is_contiguous()):
-        raise ValueError("ops_out must be a contiguous CUDA uint8 tensor")
-    if ops_out.numel() < n_streams * total * 6:
-        raise ValueError("ops_out holds %d bytes, this call writes %d" % (ops_out.numel(), n_streams * total * 6))
+    native.validate_ops_out(ops_out, n_streams * total * 6)
     native.check(native.lib().iiv_encode(native.C.c_void_p(handle), native.dptr(frames_main), native.dptr(frames_aux), n_frames,
                                          segs, int(s.shape[0]), native.dptr(ops_out), native.stream_ptr()))
 
@@ -77,12 +73,19 @@ def encode(handle: int, frames_main: Tensor, frames_aux: Optional[Tensor], segme
 @torch.library.custom_op("iivision::encode_streams", mutates_args=("ops_out",), device_types="cuda")
 def encode_streams(handle: int, frames_main: Tensor, frames_aux: Optional[Tensor], segments: Tensor, seg_begin: Tensor,
                    ops_out: Tensor) -> None:
-    segs, _ = _segments_struct(segments)
-    begin = seg_begin.detach().to("cpu", torch.int32).contiguous()
-    if not (ops_out.is_cuda and ops_out.dtype == torch.uint8 and ops_out.is_contiguous() and ops_out.dim() == 3):
-        raise ValueError("ops_out must be a contiguous CUDA uint8 tensor (n_streams, max opcodes, 6)")
+    n_streams, n_frames = native.validate_frames(handle, frames_main, frames_aux)
+    segs, s = _segments_struct(segments)
+    begin = seg_begin.detach().to("cpu", torch.int32).contiguous().view(-1)
+    if int(begin.numel()) != n_streams + 1:
+        raise ValueError("seg_begin holds %d entries, the encoder's %d streams need %d" % (int(begin.numel()), n_streams, n_streams + 1))
+    b = begin.numpy()
+    if int(b[0]) < 0 or (np.diff(b) < 0).any() or int(b[-1]) > int(s.shape[0]):
+        raise ValueError("seg_begin must ascend from >= 0 to <= the number of segments (%d)" % int(s.shape[0]))
+    if ops_out.dim() != 3 or int(ops_out.shape[0]) != n_streams or int(ops_out.shape[2]) != 6:
+        raise ValueError("ops_out has shape %s, not (%d streams, max opcodes, 6)" % (tuple(ops_out.shape), n_streams))
+    native.validate_ops_out(ops_out, n_streams * int(ops_out.shape[1]) * 6)
     native.check(native.lib().iiv_encode_streams(native.C.c_void_p(handle), native.dptr(frames_main), native.dptr(frames_aux),
-                                                 int(frames_main.shape[1]), segs,
+                                                 n_frames, segs,
                                                  native.C.cast(begin.data_ptr(), native.C.POINTER(native.C.c_int32)),
                                                  native.dptr(ops_out), int(ops_out.shape[1]) * 6, native.stream_ptr()))
 
@@ -104,6 +107,8 @@ def encode_via_op(enc, frames_main, frames_aux, segments, ops_out=None):
     returns the (n_streams, total, 6) view of the rows as they were written."""
     total = sum(int(s[3]) for s in segments)
     need = enc.n_streams * total * 6
+    if int(frames_main.shape[0]) != enc.n_streams:
+        raise ValueError("frames_main holds %d streams, the encoder was created for %d" % (int(frames_main.shape[0]), enc.n_streams))
     if ops_out is None:
         ops_out = torch.empty((enc.n_streams, total, 6), dtype=torch.uint8, device="cuda")
     seg_t = torch.tensor([[int(v) for v in s] for s in segments], dtype=torch.int32).view(-1, 4)

@@ -248,6 +248,11 @@ void iiv_encoder_destroy(iiv_encoder *enc);
                                   * one-wave kernel; needs dm at creation); not together with IIV_CONTENT_JOINT. */
 int iiv_encoder_set_option(iiv_encoder *enc, int option, int value);
 
+/* The mode and stream count an encoder was created with (what a caller's frame / output buffers must be sized for:
+ * iiv_encode reads and writes n_streams streams whatever the caller's tensors hold -- the host bindings validate
+ * their arguments against this; the reference's Video has one stream and one mode, video.py:21-36). */
+int iiv_encoder_info(iiv_encoder *enc, int *mode, int *n_streams);
+
 /* state items, per stream.  (The priorities are int32 here, as in the reference; the kernels work on a 16-bit copy of them --
  * 65535 = "see the int32 entry" -- which get_state / get_video_state bring into the int32 arrays before they copy and
  * set_state / set_video_state refill afterwards: DESIGN.md 5, StreamState::up16.) */

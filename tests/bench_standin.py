@@ -52,7 +52,7 @@ class CpuStandIn:
         return self.clock.segments(self.args.frames_per_step)
 
     def first_ops(self, segs):
-        return torch.zeros((sum(s[3] for s in segs), 6), dtype=torch.uint8)
+        return {0: torch.zeros((sum(s[3] for s in segs), 6), dtype=torch.uint8)}
 
     def check(self):
         self.log["checks"] += 1

@@ -83,3 +83,49 @@ def test_table_and_ingest_operators(native, O):
     main, aux = torch.ops.iivision.frames_to_memory_maps(1, rgb, img, 32)
     m0, a0 = native.frames_to_memory_maps(1, O.PALETTE_RGB[5], img, 32)
     assert bool((main == m0).all()) and bool((aux == a0).all())
+
+
+def test_mismatched_batches_raise_instead_of_launching(native, device_tables):
+    """iiv_encode reads and writes the ENCODER's stream count whatever the caller's tensors hold: frames or
+    outputs sized for another batch, a missing / short / non-uint8 aux bank, a short seg_begin must be refused by the
+    operators and by the ctypes path before anything is launched."""
+    import torch
+    import torch_ops
+    import stream_batch
+    table, store = device_tables.get(1, 5)
+    fm, fa = stream_batch.synth_frames_torch(4, 2, True, seed=3)
+    enc = native.Encoder(1, table, store, 4, dm=device_tables.dm[(1, 5)])
+    assert native.encoder_info(enc.handle) == (1, 4)
+    segs = [(0, 0, 1, 20)]
+    seg_t = torch.tensor(segs, dtype=torch.int32)
+    good_out = torch.empty((4, 20, 6), dtype=torch.uint8, device="cuda")
+
+    def refused(fn):
+        with pytest.raises((ValueError, RuntimeError)):
+            fn()
+
+    # fewer streams than the encoder has: frames, then outputs
+    refused(lambda: torch.ops.iivision.encode(enc.handle, fm[:2].contiguous(), fa[:2].contiguous(), seg_t, good_out))
+    refused(lambda: torch.ops.iivision.encode(enc.handle, fm, fa, seg_t, good_out[:2].contiguous()))
+    refused(lambda: torch_ops.encode_via_op(enc, fm[:2].contiguous(), fa[:2].contiguous(), segs))
+    refused(lambda: enc.encode(fm[:2].contiguous(), fa[:2].contiguous(), segs))
+    # the aux bank: missing, fewer frames, wrong dtype, not contiguous, on the host
+    refused(lambda: torch.ops.iivision.encode(enc.handle, fm, None, seg_t, good_out))
+    refused(lambda: torch.ops.iivision.encode(enc.handle, fm, fa[:, :1].contiguous(), seg_t, good_out))
+    refused(lambda: torch.ops.iivision.encode(enc.handle, fm, fa.to(torch.int8), seg_t, good_out))
+    refused(lambda: torch.ops.iivision.encode(enc.handle, fm, fa.transpose(2, 3), seg_t, good_out))
+    refused(lambda: enc.encode(fm, fa.cpu(), segs))
+    # encode_streams: seg_begin too short, outputs for fewer streams / narrower than the longest schedule
+    sched_t = torch.tensor([(0, 0, 1, 20)] * 4, dtype=torch.int32)
+    refused(lambda: torch.ops.iivision.encode_streams(enc.handle, fm, fa, sched_t, torch.tensor([0, 1, 2], dtype=torch.int32), good_out))
+    refused(lambda: torch.ops.iivision.encode_streams(enc.handle, fm, fa, sched_t, torch.arange(5, dtype=torch.int32), good_out[:3].contiguous()))
+    refused(lambda: enc.encode_streams(fm, fa, [[(0, 0, 1, 20)]] * 4, ops_out=torch.empty((4, 10, 6), dtype=torch.uint8, device="cuda")))
+    # ... and the well-formed calls still run, and agree
+    torch.ops.iivision.encode(enc.handle, fm, fa, seg_t, good_out)
+    enc.check()
+    enc2 = native.Encoder(1, table, store, 4, dm=device_tables.dm[(1, 5)])
+    ref = enc2.encode(fm, fa, segs)
+    enc2.check()
+    assert torch.equal(good_out, ref)
+    enc.close()
+    enc2.close()

@@ -62,8 +62,16 @@ def main():
     if bench_line:
         open(os.path.join(out, "bench_under_rocprof.json"), "w").write(bench_line + "\n")
     f = glob.glob(tmp + "/stats/*/*kernel_stats.csv")
+    avg_ns = {}   # short kernel name -> average duration of its launches in the --stats run
     if f:
         rows = list(csv.reader(open(f[0])))
+        try:
+            i_name, i_avg = rows[0].index("Name"), rows[0].index("AverageNs")
+            for r in rows[1:]:
+                if short(r[i_name]):
+                    avg_ns[short(r[i_name])] = float(r[i_avg])
+        except ValueError:
+            pass
         with open(os.path.join(out, "kernel_stats.csv"), "w") as g:
             w = csv.writer(g)
             w.writerow(rows[0])
@@ -91,11 +99,42 @@ def main():
             g.write("\n")
     # HBM bytes per greedy launch and PER STREAM, per mode, merged into OUTDIR/pmc_latest.json (bench.py multiplies
     # by its own stream count, so roofline.traffic and algorithmic_bytes_per_launch share mode and streams)
-    streams = None
+    streams, ops_per_launch = None, None
     try:
-        streams = int(json.loads(bench_line)["config"]["streams_per_gpu"])
+        bj = json.loads(bench_line)
+        streams = int(bj["config"]["streams_per_gpu"])
+        ops_per_launch = bj["roofline"]["algorithmic_bytes_per_launch"] / streams / 534.0   # opcodes per stream and greedy launch (bench.BYTES_PER_OPCODE)
     except Exception:
         pass
+
+    def per_dispatch(k, c):
+        return agg[k][c] / max(len(cnt[k][c]), 1) if c in agg[k] else None
+
+    def issue_of(k):
+        """What the SQ counters say binds the kernel: instructions per opcode and wave, instructions per
+        clock and SIMD, how busy the vector pipe is, waves resident per SIMD.  One wave per stream; 256 CUs x 4 SIMDs; a wave64
+        vector instruction occupies its SIMD-32 for 2 clocks (MI355X_MICROARCH.md, constants table); shader clock 2.4 GHz."""
+        valu, salu = per_dispatch(k, "SQ_INSTS_VALU"), per_dispatch(k, "SQ_INSTS_SALU")
+        if valu is None or salu is None or not streams or not ops_per_launch or k not in avg_ns:
+            return None
+        other = sum(per_dispatch(k, c) or 0.0 for c in ("SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM"))
+        steps = streams * ops_per_launch
+        clocks = avg_ns[k] * 1e-9 * 2.4e9
+        import re
+        w = int(re.search(r"<\s*\d\s*,\s*(\d+)", k).group(1)) if re.search(r"<\s*\d\s*,\s*(\d+)", k) else 1
+        waves = per_dispatch(k, "SQ_WAVES")
+        return {
+            "source": "tools/profile_summary.py: rocprofv3 --pmc SQ_* passes + --kernel-trace --stats of the same command",
+            "kernel": k, "launch_ms_under_rocprof": avg_ns[k] * 1e-6, "opcodes_per_stream_and_launch": ops_per_launch,
+            "valu_per_opcode_wave": valu / steps, "salu_per_opcode_wave": salu / steps, "other_per_opcode_wave": other / steps,
+            "instr_per_clk_per_simd": (valu + salu + other) / (clocks * 1024.0),
+            "valu_busy_frac": valu * 2.0 / (clocks * 1024.0),
+            "waves_per_dispatch": waves,
+            # persistent workgroups (W > 1): every launched wave is resident; the plain form (W = 1) launches one wave per stream, 28 resident per CU
+            "waves_per_simd": (waves / 1024.0) if (w > 1 and waves) else 7.0,
+            "wait_any_frac_of_wave_cycles": (per_dispatch(k, "SQ_WAIT_ANY") / per_dispatch(k, "SQ_WAVE_CYCLES")) if per_dispatch(k, "SQ_WAVE_CYCLES") and per_dispatch(k, "SQ_WAIT_ANY") is not None else None,
+            "clock_hz_assumed": 2.4e9,
+        }
     latest_path = os.path.join(out, "pmc_latest.json")
     try:
         latest = json.load(open(latest_path))
@@ -126,6 +165,7 @@ def main():
                           "MI355X_MICROARCH.md HBM section; uncalibrated for 2-byte gathers); WRITE_SIZE as reported",
             "greedy_hbm_bytes_per_launch": (2 * fetch + write) * 1024,
             "greedy_hbm_bytes_per_launch_per_stream": (2 * fetch + write) * 1024 / streams,
+            "issue": issue_of(main_k),
         }
         # the prologue kernel of the same run (same correction: its reads are wide coalesced ones)
         pk = [k for k in agg if k.startswith("prologue") and mode_of(k) == mode and "FETCH_SIZE" in agg[k]]

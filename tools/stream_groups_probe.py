@@ -26,7 +26,7 @@ for G in groups:
         else:
             fm, fa = stream_batch.synth_frames_torch(per, n_clip, True, seed=5 + g)
         b = stream_batch.StreamBatch(mode, table, store, per, seeds=[(g * per + i + 1, g * per + i + 1) for i in range(per)], dm=dm)
-        b.enc.set_greedy_kernel(True)
+        b.enc.set_greedy_kernel(os.environ.get("IIV_PROBE_GREEDY") or True)
         batches.append(b)
         frames.append((fm, fa))
         streams.append(torch.cuda.Stream())
