@@ -110,6 +110,9 @@ def parse_args(argv=None):
     ap.add_argument("--repeat", type=int, default=1, help="with --static: show every drawn frame this many times")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip make_data_tables / single-stream (profiling runs)")
+    ap.add_argument("--extras", default="all",
+                    help="comma list of the extra legs to run beside the timed region (default all): single_stream, emit, "
+                         "make_data_tables, ingest, dropin, hgr, img, fourth_offset -- for iterating on one of them")
     ap.add_argument("--cpu-frames", type=int, default=600, help="frames of stream 0 the CPU baseline encodes")
     ap.add_argument("--cpu-frames-all", type=int, default=60, help="frames per stream of the all-cores CPU baseline")
     ap.add_argument("--dw", choices=["split", "recurrence", "table"], default="recurrence",
@@ -510,11 +513,14 @@ def _run(args, backend_cls, quiet):
         out.update(_roofline_objects(be, args, prof, op_count, seg_count, S, elapsed,
                                      live_ceiling=be.is_gpu and not args.no_extras))
         port_fps = None
+        want = (lambda name: True) if args.extras == "all" else (lambda name, _w=set(args.extras.split(",")): name in _w)
         if n_gpus == 1 and not args.no_extras and be.is_gpu:
-            out["single_stream"] = _single_stream(be, args)
-            if not args.no_emit:   # the same steps with the bytes leaving the device (PCIe-inclusive; never `value`)
+            if want("single_stream"):
+                out["single_stream"] = _single_stream(be, args)
+            if not args.no_emit and want("emit"):   # the same steps with the bytes leaving the device (PCIe-inclusive; never `value`)
                 out["emit"] = _emit_end_to_end(be, args, fps)
-            out["make_data_tables_s"] = _make_data_tables_seconds()
+            if want("make_data_tables"):
+                out["make_data_tables_s"] = _make_data_tables_seconds()
         if not args.no_cpu_baseline and n_gpus == 1 and be.is_gpu:
             out["cpu_baseline"] = _cpu_baseline(be, seeds, args, ops_check=({s: t.cpu().numpy() for s, t in first_ops.items()}, F))
             out["cpu_baseline_all_cores"] = _cpu_baseline_all_cores(be, seeds, args)
@@ -527,13 +533,21 @@ def _run(args, backend_cls, quiet):
                 out["single_stream"]["vs_reference_python"] = r and r["value"]
                 out["single_stream"]["note"] = ("one clip alone on one GPU; the >= 1000x target of north_star is met "
                                                 "per GPU only with many independent clips (see value / vs_reference_python)")
+        if n_gpus == 1 and not args.no_extras and be.is_gpu and not args.joint and not args.fourth and not args.no_emit and want("ingest"):
+            try:
+                out["ingest"] = _ingest_and_e2e(be, args, fps, out.get("emit", {}).get("value"))
+            except Exception as e:   # (e.g. not enough free HBM beside other tenants: report, do not fail the line)
+                out["ingest"] = {"value": None, "error": repr(e)}
         if n_gpus == 1 and not args.no_extras and be.is_gpu:
-            out["dropin"] = _dropin_video(args)
+            if want("dropin"):
+                out["dropin"] = _dropin_video(args)
             if dhgr and not args.joint and not args.fourth:   # SURVEY 8(d) M1 "plus HGR frames/s": a short HGR leg with its own tables and clips
-                out["hgr"] = _hgr_leg(be, args, local_rank, world)
-                if not args.img:   # picture-like input (S-img): what the product encodes, and the slowest input -- its own short leg
+                if want("hgr"):
+                    out["hgr"] = _hgr_leg(be, args, local_rank, world)
+                if not args.img and want("img"):   # picture-like input (S-img): what the product encodes, and the slowest input -- its own short leg
                     out["img"] = _hgr_leg(be, args, local_rank, world, steps=4, mode="DHGR", img=True)
-                out["fourth_offset"] = _hgr_leg(be, args, local_rank, world, steps=4, mode="DHGR", fourth=True)
+                if want("fourth_offset"):
+                    out["fourth_offset"] = _hgr_leg(be, args, local_rank, world, steps=4, mode="DHGR", fourth=True)
 
         quiet.restore()
         print(json.dumps(out))
@@ -968,6 +982,153 @@ def _emit_end_to_end(be, args, resident_fps):
             "bytes_to_host": state["bytes"], "d2h_gb_per_s": state["bytes"] / dt / 1e9,
             "what": "iiv_encode -> iiv_emit_chunk (.a2m framing, tick 34) -> hipMemcpyAsync to pinned host memory, "
                     "double-buffered; %d steps" % args.steps}
+
+
+INGEST_BYTES_PER_FRAME = {"DHGR": 192 * 280 * 3 + 2 * 8192, "HGR": 192 * 280 * 3 + 8192}   # 161 KB of RGB in, 8 / 16 KiB of memory maps out
+
+
+def _ingest_and_e2e(be, args, resident_fps, emit_fps):
+    """SURVEY 8(f3) with numbers, and the pipeline from pixels to bytes:
+      ingest   iiv_frames_to_memory_maps alone, as many frames per step as the batch encodes (S x F), ordered dither and error
+               diffusion: frames/s and the fraction of the HBM peak its 161 KB in + 8 / 16 KiB out per frame amount to;
+      e2e      RGB frames -> iiv_frames_to_memory_maps -> iiv_encode -> iiv_emit_chunk -> pinned host memory, every step on
+               fresh frames, the conversion of step k + 1 on a second HIP stream beside the encode of step k.
+    The RGB source is `distinct` synthetic picture-like clips (stream_batch.synth_rgb_torch) tiled over the S streams -- every
+    tile is converted again (S x F conversions per step, nothing cached), every stream keeps its own RNG seeds.  The DHGR
+    leg's clips are released first: the source (K x distinct x F frames of 161 KB) and two (S, F, 32, 256) target buffers per
+    bank take their place."""
+    import gc
+    import numpy as np
+    import torch
+    import palette
+    native = be.native
+    S, F = be.S, args.frames_per_step
+    for name in ("fm", "fa", "ops_buf", "last_ops"):
+        setattr(be, name, None)
+    if getattr(be, "batch", None) is not None:
+        be.batch.close()
+        be.batch = None
+    gc.collect()
+    torch.cuda.empty_cache()
+    K = 4                                  # steps of distinct source frames
+    distinct = min(512, S)
+    pal_rgb = palette.PALETTES[palette.Palette(PALETTE_IDS[args.palette])].rgb_array()
+    rgb = be.sb.synth_rgb_torch(distinct, K * F, seed=data_seed(0) + 5)            # (distinct, K F, 192, 280, 3)
+    rgb = rgb.view(distinct, K, F, 192, 280, 3).transpose(0, 1).contiguous()        # (K, distinct, F, ...): a step's source is contiguous
+    torch.cuda.empty_cache()
+    nb = 2 if be.dhgr else 1
+    bufs = [[torch.empty((S, F, 32, 256), dtype=torch.uint8, device="cuda") for _ in range(nb)] for _ in range(2)]
+
+    def convert(k, j, dither):
+        """step k's frames of every stream into buffer j: one call per tile of `distinct` streams"""
+        src = rgb[k % K].view(distinct * F, 192, 280, 3)
+        for s0 in range(0, S, distinct):
+            n = min(distinct, S - s0)
+            native.frames_to_memory_maps(be.mode, pal_rgb, src[: n * F], dither,
+                                         out=(bufs[j][0][s0:s0 + n], bufs[j][1][s0:s0 + n] if be.dhgr else None))
+
+    out = {"frames_per_step": S * F, "distinct_source_clips": distinct,
+           "bytes_per_frame": INGEST_BYTES_PER_FRAME[args.mode],
+           "what": "iiv_frames_to_memory_maps (replaces the external bmp2dhr, frame_grabber.py:68-115; no reference output exists), "
+                   "%d x %d frames per step, %d distinct synthetic RGB clips tiled over the streams" % (S, F, distinct)}
+    for name, dither in (("ordered", 32), ("diffusion", native.DITHER_DIFFUSION)):
+        convert(0, 0, dither)
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for k in range(K):
+            convert(k, k & 1, dither)
+        ev1.record()
+        torch.cuda.synchronize()
+        dt = ev0.elapsed_time(ev1) * 1e-3
+        fps = K * S * F / dt
+        gbs = fps * INGEST_BYTES_PER_FRAME[args.mode] / 1e9
+        out[name] = {"value": fps, "unit": "frames/s", "ms_per_step": 1e3 * dt / K,
+                     "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                  "peak_measured_copy": HBM_MEASURED_COPY_GBS, "over_measured_copy": gbs / HBM_MEASURED_COPY_GBS},
+                     "vs_encoder_rate": fps / resident_fps}
+
+    def e2e(dither, overlap):
+        rng = np.random.default_rng(0)
+        tick_addr = torch.from_numpy(rng.integers(0x4000, 0x7fff, 1024).astype(np.int16)).cuda()
+        b = be.sb.StreamBatch(be.mode, be.table, be.store, S, seeds=rank_seeds(0, S), dm=be.dm)
+        n_ops = F * OPS_PER_FRAME
+        ops = torch.empty((S, n_ops, 6), dtype=torch.uint8, device="cuda")
+        width = native.emit_chunk_range(be.mode, 0, n_ops)[1] + 16
+        dev = [torch.empty(S * width, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        host = [torch.empty(S * width, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+        copy_stream, ingest_stream = torch.cuda.Stream(), torch.cuda.Stream()
+        done = [torch.cuda.Event(), torch.cuda.Event()]
+        ready = [torch.cuda.Event(), torch.cuda.Event()]
+        converted = [torch.cuda.Event(), torch.cuda.Event()]     # buffer j holds its step's frames
+        encoded = [torch.cuda.Event(), torch.cuda.Event()]       # the encode that read buffer j has finished
+        state = {"first_op": 0, "bytes": 0}
+        main = torch.cuda.current_stream()
+
+        def ingest(k):
+            j = k & 1
+            if overlap:
+                with torch.cuda.stream(ingest_stream):
+                    ingest_stream.wait_event(encoded[j])
+                    convert(k, j, dither)
+                    converted[j].record()
+            else:
+                convert(k, j, dither)
+
+        def step(k):
+            j = k & 1
+            if overlap:
+                main.wait_event(converted[j])
+                if k + 1 <= K:
+                    ingest(k + 1)                                 # the next step's frames, beside this step's encode
+            else:
+                ingest(k)
+            view, segs = b.encode_frames(bufs[j][0], bufs[j][1] if be.dhgr else None, F, ops, loop=True)
+            encoded[j].record()
+            n = sum(s_[3] for s_ in segs)
+            main.wait_event(done[j])
+            nbytes = native.emit_chunk_range(be.mode, state["first_op"], n)[1]
+            o = dev[j][: S * nbytes].view(S, nbytes)
+            native.emit_chunk(be.mode, view, state["first_op"], tick_addr, 0xBA72, o)
+            ready[j].record()
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(ready[j])
+                host[j][: S * nbytes].copy_(dev[j][: S * nbytes], non_blocking=True)
+                done[j].record()
+            state["first_op"] += n
+            state["bytes"] += nbytes * S
+
+        for ev in done + encoded:
+            ev.record()
+        if overlap:
+            ingest(0)
+        step(0)                                                   # warm-up step (its frames are step 0's)
+        torch.cuda.synchronize()
+        state["bytes"] = 0
+        t0 = time.perf_counter()
+        for k in range(1, 1 + K):
+            step(k)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        b.enc.check()
+        share, form = b.enc.input_stats()
+        b.close()
+        fps = K * F * S / dt
+        return {"value": fps, "unit": "frames/s", "ms_per_step": 1e3 * dt / K, "steps": K,
+                "vs_emit": (fps / emit_fps) if emit_fps else None, "vs_resident_only": fps / resident_fps,
+                "d2h_gb_per_s": state["bytes"] / dt / 1e9, "greedy_form": form, "nonce_decided_share_of_steps": round(share, 4)}
+
+    out["e2e"] = e2e(32, True)
+    out["e2e"]["what"] = ("RGB -> iiv_frames_to_memory_maps (ordered dither, amplitude 32) -> iiv_encode -> iiv_emit_chunk -> pinned host "
+                          "memory; the conversion of step k + 1 runs on a second HIP stream beside the encode of step k; "
+                          "vs_emit compares with the `emit` leg's rate on S-iid memory maps -- different content, same pipeline behind the frames")
+    out["e2e_diffusion"] = e2e(native.DITHER_DIFFUSION, True)
+    out["e2e_serial"] = e2e(32, False)
+    out["e2e_serial"]["what"] = "the same with the conversion on the encode's own stream (no overlap)"
+    del rgb, bufs
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
 
 
 def _cpu_baseline(be, seeds, args, ops_check):

@@ -304,20 +304,30 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
         }
     };
 
-    // opcodes emitted but not yet written: opcode ob_base + l sits in lane l of (ob0, ob1)
+    // opcodes emitted but not yet written: opcode ob_base + l sits in lane l of (ob0, ob1) -- as the step has them, its entry
+    // word (page << 8 | x | content << 16) and its extra offsets (y1 | y2 << 8 [| y3 << 16]); the six bytes of
+    // (page + 32, content, x, y1, y2, x) are formed by the 64 lanes at once when the buffer leaves, not by ten scalar
+    // instructions in every step
     uint32_t ob0 = 0, ob1 = 0;
     int ob_base = 0;
     auto flush_ops = [&]() {
         if (lane < done - ob_base) {
             uint8_t *q = out + (size_t)(ob_base + lane) * 6;
-            *reinterpret_cast<u32_a2 *>(q) = ob0;
-            *reinterpret_cast<uint16_t *>(q + 4) = (uint16_t)ob1;
+            const uint32_t pg = (ob0 >> 8) & 31u, xx = ob0 & 255u, cc = (ob0 >> 16) & 255u;
+            *reinterpret_cast<u32_a2 *>(q) = (pg + 32u) | (cc << 8) | (xx << 16) | (ob1 << 24);
+            *reinterpret_cast<uint16_t *>(q + 4) = (uint16_t)(((ob1 >> 8) & 255u) | ((FOUR ? (ob1 >> 16) & 255u : xx) << 8));
         }
         ob_base = done;
     };
 
-    // video.py:140-144, 170-187; screen.py:256-293.  Lanes 0..2 carry (x, y1, y2); a
-    // missing secondary repeats the primary's stores.
+    // video.py:140-144, 170-187; screen.py:256-293.  Lanes 0..2 (FOUR: 0..3) carry (x, y1, y2[, y3]); a missing secondary
+    // repeats the primary's stores.  W1..W3: a winner as `store value << 8 | offset` (0 | x for a missing one).
+    // Round 5: a third of a step's instructions were here.  Nothing below branches on what a LANE holds: a byte whose store
+    // leaves no error clears its priority bit with an LDS AND whose mask is all ones for the others, a byte that is
+    // re-queued stores its entry at an offset that is out of the stream's buffer range for the others (the hardware drops
+    // it) -- no exec juggling, no second code path; the winners travel as one packed word per lane; the opcode's bytes are
+    // formed at flush time (flush_ops); the pushed-entry capacity cannot be exceeded (iiv_stream.h: kPushedCap) and is
+    // checked against a margin with one compare.
     // (phase B keeps per-lane minima of the re-queued bag up to date: `track` hands it the keys a step pushes)
 #ifdef IIV_STAMPS
     int n_ties = 0, n_tie_members = 0, n_ties_small = 0;
@@ -326,58 +336,54 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
     int n_exact = 0;              // steps of this launch that took the exact-nonce path (tie_stats: what the host picks the kernel form by)
     uint32_t pkey_v = 0;          // lanes 1, 2 (FOUR: and 3): the keys pushed by the latest step (track only)
     int push_f1 = 0, push_f2 = 0, push_f3 = 0, push_base = 0;
-    auto apply = [&](auto track, int p, int x, uint32_t c, int y1, uint32_t nd1, int y2, uint32_t nd2, int y3, uint32_t nd3, int C) {
-        const uint32_t v1 = nd1, v2 = nd2, v3 = FOUR ? nd3 : 0u;   // (a missing winner's value is 0: step() leaves it so)
-        const int y1e = y1 >= 0 ? y1 : x, y2e = y2 >= 0 ? y2 : x, y3e = (FOUR && y3 >= 0) ? y3 : x;   // video.py:185-186
-        const int f1 = v1 ? 1 : 0, f2 = v2 ? 1 : 0, f3 = v3 ? 1 : 0;
-        if (__builtin_expect(n_pushed + f1 + f2 + f3 > kPushedCap, 0)) {
+    static_assert(kPushedCap >= 3 * 7680 + 8, "a generator's steps have distinct primaries: <= 7680 steps x <= 3 pushes");
+    auto apply = [&](auto track, uint32_t e, uint32_t W1, uint32_t W2, uint32_t W3, int C) {
+        const int p = (e >> 8) & 31, x = e & 255;
+        const uint32_t c = (e >> 16) & 0xffu;
+        const int f1 = (int)min(W1 >> 8, 1u), f2 = (int)min(W2 >> 8, 1u), f3 = FOUR ? (int)min(W3 >> 8, 1u) : 0;
+        if (__builtin_expect(n_pushed > kPushedCap - 4, 0)) {
             err = kErrPushedOverflow;
             return;
         }
         if (__builtin_expect(twist_pending && mt_idx + C + (FOUR ? 3 : 2) >= 256, 0)) twist_now();
-        // lanes 0..2 = (x, 0), (y1e, v1), (y2e, v2): three scalars written into lanes of one register each
-        // (a `lane == k ? a : b` chain compiles to selects on loop-invariant lane masks, which the
-        // allocator then spills and reloads on every step)
-        uint32_t off_v = (uint32_t)x, val_v = 0u, k_v = 0u;
-        asm("v_writelane_b32 %0, %3, 1\n\tv_writelane_b32 %0, %4, 2\n\t"
-            "v_writelane_b32 %1, %5, 1\n\tv_writelane_b32 %1, %6, 2\n\t"
-            "v_writelane_b32 %2, %7, 2"
-            : "+v"(off_v), "+v"(val_v), "+v"(k_v)
-            : "s"(IIV_SGPR(y1e)), "s"(IIV_SGPR(y2e)), "s"(IIV_SGPR(v1)), "s"(IIV_SGPR(v2)), "s"(IIV_SGPR(f1)));
-        if (FOUR)   // lane 3 = (y3e, v3), its re-queued entry behind those of lanes 1 and 2
-            asm("v_writelane_b32 %0, %3, 3\n\tv_writelane_b32 %1, %4, 3\n\tv_writelane_b32 %2, %5, 3"
-                : "+v"(off_v), "+v"(val_v), "+v"(k_v)
-                : "s"(IIV_SGPR(y3e)), "s"(IIV_SGPR(v3)), "s"(IIV_SGPR(f1 + f2)));
+        // lane 0 = x | 0 << 8, lane 1 = W1, lane 2 = W2 (lane 3 = W3); where a re-queued entry goes: lane 1 slot 0, lane 2
+        // slot f1 (lane 3 slot f1 + f2)
+        // (scalars written into lanes of one register each: a `lane == k ? a : b` chain compiles to selects on
+        // loop-invariant lane masks, which the allocator then spills and reloads on every step)
+        uint32_t w_v = (uint32_t)x, k_v = 0u;
+        asm("v_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %3, 2\n\tv_writelane_b32 %1, %4, 2"
+            : "+v"(w_v), "+v"(k_v)
+            : "s"(IIV_SGPR(W1)), "s"(IIV_SGPR(W2)), "s"(IIV_SGPR(f1)));
+        if (FOUR)
+            asm("v_writelane_b32 %0, %2, 3\n\tv_writelane_b32 %1, %3, 3" : "+v"(w_v), "+v"(k_v) : "s"(IIV_SGPR(W3)), "s"(IIV_SGPR(f1 + f2)));
         int ln = lane;
         asm volatile("" : "+v"(ln));   // (keeps `lane < 3` from becoming one more hoisted, spilled mask)
         if (ln < (FOUR ? 4 : 3)) {
-            const int off = (int)off_v;
-            const uint32_t val = val_v;
-            // (buffer stores into this stream's state: field offsets in scalar registers instead of
-            // 64-bit pointers added per lane)
-            const int loc = p * 256 + off;
-            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)val, rsrc_s, loc * 2, up_off, 0);   // byte_pair_difference == store-table value (screen.py:383-398); <= 2047: the 16-bit copy
-            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)c, rsrc_s, loc, mem_off, 0);
-            if (val == 0) {
-                atomicAnd(&nz[p * 8 + (off >> 5)], ~(1u << (off & 31)));
-            } else {
-                const int k = (int)k_v;
-                const uint32_t nonce = mt_temper(mt[mt_idx + C + k]) >> 24;  // video.py:178
-                const uint32_t pkey = ((2047u - val) << 21) | (nonce << 13) | ((uint32_t)p << 8) | (uint32_t)off;
-                __builtin_amdgcn_raw_buffer_store_b32(pkey, rsrc_s, (n_pushed + k) * 4, (int)offsetof(StreamState, pushed), 0);
-                if (decltype(track)::value) pkey_v = pkey;
-            }
-            atomicOr(&pdone[p * 8 + (x >> 5)], 1u << (x & 31));   // (from all three / four lanes: idempotent)
+            const uint32_t off = w_v & 255u, val = w_v >> 8;
+            // (buffer stores into this stream's state: field offsets in scalar registers instead of 64-bit pointers added per lane)
+            const uint32_t loc = (uint32_t)(p * 256) | off;
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)val, rsrc_s, (int)(loc * 2u), up_off, 0);   // byte_pair_difference == store-table value (screen.py:383-398); <= 2047: the 16-bit copy
+            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)c, rsrc_s, (int)loc, mem_off, 0);
+            // priority 0 -> out of the live set; all ones for a byte that keeps a priority
+            const uint32_t gone_bit = (val == 0u ? 1u : 0u) << (off & 31u);
+            atomicAnd(&nz[loc >> 5], ~gone_bit);
+            atomicOr(&pdone[p * 8 + (x >> 5)], 1u << (x & 31));   // (the primary's diff weight counts as 0 from here on; from all lanes: idempotent)
+            // the re-queued entry (video.py:178), its nonce the next word behind the candidates'; a byte that is not
+            // re-queued aims beyond the buffer
+            const uint32_t nonce = mt_temper(mt[mt_idx + C + (int)k_v]) >> 24;
+            const uint32_t pkey = ((2047u - val) << 21) | (nonce << 13) | loc;
+            const uint32_t slot = val != 0u ? (uint32_t)(n_pushed + (int)k_v) * 4u : 0x7ffffff0u;
+            __builtin_amdgcn_raw_buffer_store_b32(pkey, rsrc_s, (int)slot, (int)offsetof(StreamState, pushed), 0);
+            if (decltype(track)::value) pkey_v = pkey;
         }
-        // the opcode (page + 32, content, x, y1, y2, x) goes into lane (done - ob_base) of a
-        // register pair; 64 of them leave in two coalesced stores
-        const uint32_t w0 = (uint32_t)(p + 32) | (c << 8) | ((uint32_t)x << 16) | ((uint32_t)y1e << 24);
-        const uint32_t w1 = (uint32_t)y2e | ((uint32_t)(FOUR ? y3e : x) << 8);
+        // the opcode: the entry word and the extra offsets go into lane (done - ob_base) of a register pair; 64 of them
+        // leave in two coalesced stores (flush_ops)
+        const uint32_t ys = (W1 & 255u) | ((W2 & 255u) << 8) | (FOUR ? (W3 & 255u) << 16 : 0u);
         const int ob_lane = IIV_SGPR(done - ob_base);
         // (gfx9 VOP3 reads one SGPR only; v_writelane may take its lane select from m0 besides)
         asm("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
             : "+v"(ob0), "+v"(ob1)
-            : "s"(IIV_SGPR(w0)), "s"(ob_lane), "s"(IIV_SGPR(w1)));
+            : "s"(IIV_SGPR(e)), "s"(ob_lane), "s"(IIV_SGPR(ys)));
         if (decltype(track)::value) push_f1 = f1, push_f2 = f2, push_f3 = f3, push_base = n_pushed;
         mt_idx += C + f1 + f2 + f3;
         draws += (uint32_t)(C + f1 + f2 + f3);
@@ -448,37 +454,37 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
         // The exact path below is complete by itself (it orders every eligible byte by (delta, nonce, offset)); the fast
         // path in front of it only pays where ties are rare.  On picture-like input they are the rule (96 % of the
         // steps), so a step that follows a tie goes straight to the exact path.
-        int y1 = -1, y2 = -1, y3 = -1;
-        uint32_t nd1 = 0, nd2 = 0, nd3 = 0;
+        // the winners as `store value << 8 | offset`: bits 0..18 of a fast-path key; a missing one repeats the primary (x, value 0)
+        uint32_t W1 = (uint32_t)x, W2 = (uint32_t)x, W3 = (uint32_t)x;
         bool tie = prev_tie;
-        const int K1 = tie ? 0 : wave_min_i32(k1);
-        // does another eligible byte share the delta of the last winner K?  (then the nonces decide)
+        // does another eligible byte share the delta of the last winner K?  (then the nonces decide.)  x = key ^ K is 0 for K
+        // itself, below 2^20 for a byte with K's delta, and has its sign bit set for a byte that is not eligible: one v_xad_u32
+        // (x - 1) per byte, a minimum, one compare -- no ballots to count
         auto shared_delta = [&](int K) -> bool {
-            int n2 = 0;
+            uint32_t m = ((uint32_t)(ke[0] ^ K)) - 1u;
 #pragma unroll
-            for (int r = 0; r < 4; r++)
-                n2 += (int)__popcll(__ballot(((uint32_t)(ke[r] ^ K) >> kWdDwShift) == 0u));
-            return n2 > 1;
+            for (int r = 1; r < 4; r++) {
+                const uint32_t x1 = ((uint32_t)(ke[r] ^ K)) - 1u;
+                m = x1 < m ? x1 : m;
+            }
+            return __ballot(m < (1u << kWdDwShift) - 1u) != 0ull;
         };
+        // the wave's two smallest eligible keys in one fused-DPP pass (iiv_wave.h)
+        int K1 = k1, K2 = k2;
+        if (!tie) wave_top2_i32(K1, K2); else K1 = K2 = 0;
         if (__builtin_expect(K1 < 0, 1)) {
-            y1 = K1 & 255;
-            nd1 = nd_in(K1);
-            // (the lane that held a winner moves its next key up)
-            const bool hit1 = k1 == K1;
-            const int c1 = hit1 ? k2 : k1;
-            const int K2 = wave_min_i32(c1);
+            W1 = (uint32_t)K1 & 0x7ffffu;
             if (__builtin_expect(K2 < 0, 1)) {
-                y2 = K2 & 255;
-                nd2 = nd_in(K2);
+                W2 = (uint32_t)K2 & 0x7ffffu;
                 tie = (K1 >> kWdDwShift) == (K2 >> kWdDwShift);
                 if constexpr (!FOUR) {
                     if (!tie) tie = shared_delta(K2);
                 } else if (!tie) {
-                    const int n1 = hit1 ? k3 : k2;          // the key behind c1 in its lane
-                    const int K3 = wave_min_i32(c1 == K2 ? n1 : c1);
+                    // the third winner: every lane's smallest key above K2 (a lane may have held K1, K2 or both)
+                    const int c3 = k1 > K2 ? k1 : (k2 > K2 ? k2 : k3);
+                    const int K3 = wave_min_i32(c3);
                     if (K3 < 0) {
-                        y3 = K3 & 255;
-                        nd3 = nd_in(K3);
+                        W3 = (uint32_t)K3 & 0x7ffffu;
                         tie = (K2 >> kWdDwShift) == (K3 >> kWdDwShift) || shared_delta(K3);
                     }
                 }
@@ -527,20 +533,17 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
             const bool thit1 = t1 == T1;
             const int tc1 = thit1 ? t2 : t1;
             const int T2 = wave_min_i32(tc1);
-            y1 = T1 != kNone ? (T1 & 255) : -1;
-            y2 = T2 != kNone ? (T2 & 255) : -1;
-            nd1 = y1 >= 0 ? nd_of(y1) : 0u;
-            nd2 = y2 >= 0 ? nd_of(y2) : 0u;
+            W1 = T1 != kNone ? (nd_of(T1 & 255) << 8) | (uint32_t)(T1 & 255) : (uint32_t)x;
+            W2 = T2 != kNone ? (nd_of(T2 & 255) << 8) | (uint32_t)(T2 & 255) : (uint32_t)x;
             prev_tie = T2 != kNone && (T1 >> 16) == (T2 >> 16);   // (a prediction only: either path is exact)
             if constexpr (FOUR) {
                 const int t3 = thi < tmb ? tmb : thi;
                 const int T3 = wave_min_i32(tc1 == T2 ? (thit1 ? t3 : t2) : tc1);
-                y3 = T3 != kNone ? (T3 & 255) : -1;
-                nd3 = y3 >= 0 ? nd_of(y3) : 0u;
+                W3 = T3 != kNone ? (nd_of(T3 & 255) << 8) | (uint32_t)(T3 & 255) : (uint32_t)x;
                 prev_tie = prev_tie || (T3 != kNone && (T2 >> 16) == (T3 >> 16));
             }
         }
-        apply(track, p, x, c, y1, nd1, y2, nd2, y3, nd3, C);
+        apply(track, e, W1, W2, W3, C);
         return true;
     };
 

@@ -4,203 +4,361 @@
 // (transcoder/frame_grabber.py:68-115; README.md:217-221 wishes for a "direct image
 // encoding").  That tool is not part of the reference's source and is absent here, so this
 // conversion has no reference output to match: it is specified, in integer arithmetic, in
-// include/iivision.h (iiv_frames_to_memory_maps), and the tests hold this kernel to a CPU
+// include/iivision.h (iiv_frames_to_memory_maps), and the tests hold these kernels to a CPU
 // restatement of that specification bit for bit.
 //
-// One thread per screen byte (HGR 40 x 192, DHGR 80 x 192 per frame): it resolves the colour
-// pixels its seven dots belong to (mean of two source pixels + 4x4 ordered dither -> nearest
-// palette colour in weighted integer RGB) and writes the byte at its memory-map position
-// (screen.py:16-69: y_to_base_addr).  Frames are independent; the work is a coalesced read of
-// 161 KB per frame and 8 / 16 KiB of stores: HBM-bound, nothing to tile.
+// Round 5: the conversion is now sized for the encoder's rate (3.4 M frames/s: 550 GB/s of RGB in).
+//   * The nearest palette colour is an arg-min of LINEAR forms: 2 dr^2 + 4 dg^2 + 3 db^2 =
+//     (2 r^2 + 4 g^2 + 3 b^2) + K_c - (4 R_c r + 8 G_c g + 6 B_c b), the first term common to all colours, so
+//     key_c = 16 (K_c - 4 R_c r - 8 G_c g - 6 B_c b) + c is three 24-bit multiply-adds per colour and the
+//     winner (ties to the lower colour value, as the specification says) one signed minimum.
+//   * Ordered dither: one thread per SEVEN colour pixels -- 28 DHGR dots = four screen bytes (aux, main, aux,
+//     main), 14 HGR dots = two bytes with everything their palette-bit decisions need -- so no pixel is
+//     evaluated twice and no thread exchanges anything; its 42 source bytes are eleven aligned dword loads
+//     and a funnel shift, its output two 16-bit stores.  (It was one thread per screen byte: every DHGR pixel
+//     evaluated 1.75 times, every HGR pixel twice for both palette bits.)
+//   * Error diffusion, DHGR: one WAVE per frame instead of 192 threads and a workgroup barrier per pixel step.
+//     Lane l works on rows l, l + 64, l + 128 one after the other, two pixels behind lane l - 1; what a row
+//     hands to the row below -- D(j) = e(j - 1) + 5 e(j) + 3 e(j + 1), final once pixel j + 1 is done --
+//     moves to the next lane by one wave-wide DPP shift per channel exactly one step before it is needed;
+//     only lane 63 -> lane 0 (row 63 -> 64, 127 -> 128) goes through a 16-slot LDS ring.  No barrier, no LDS
+//     traffic in the step, 547 steps per frame instead of 1 286 barrier rounds.  Integer sums commute, so the
+//     schedule changes nothing: bit for bit the oracle's raster-order definition.
+//     (HGR's diffusion keeps the skewed-wavefront workgroup kernel: its palette-bit look-ahead needs four
+//     pixels' accumulators ahead of the row above.)
+//   * No allocation, no synchronisation: the palette's linear forms travel as a kernel argument, the screen
+//     holes are zeroed by a kernel on the same stream.
 #include "iiv_host.h"
+#include "iiv_stream.h"
+#include <stdlib.h>
 
 namespace iiv {
 
-__device__ static inline int y_to_offset(int y)  // y_to_base_addr(y, 0) - 0x2000 (screen.py:16-22)
+__device__ __host__ static inline int y_to_offset(int y)  // y_to_base_addr(y, 0) - 0x2000 (screen.py:16-22)
 {
     return 1024 * (y % 8) + 128 * ((y % 64) / 8) + 40 * (y / 64);
 }
 
-struct IngestPixel {
-    int r, g, b;
+// The palette as the kernels use it (built on the host per call, passed by value).
+struct IngestPalette {
+    int32_t k[16];        // 16 (2 R^2 + 4 G^2 + 3 B^2) + colour value
+    int32_t a[16], b[16], c[16];   // -16 * 4 R, -16 * 8 G, -16 * 6 B
+    uint32_t rgb[16];     // R | G << 8 | B << 16
+    int32_t dither[16];   // ordered-dither offset of (y & 3) * 4 + (k & 3): floor((2 Bayer - 15) * amplitude / 16)
 };
 
-__device__ static inline IngestPixel ingest_pixel(const uint8_t *__restrict__ rgb, int y, int k, int dither)
+static IngestPalette make_palette(const uint8_t pal[48], int dither)
 {
-    constexpr int bayer[16] = {0, 8, 2, 10, 12, 4, 14, 6, 3, 11, 1, 9, 15, 7, 13, 5};
-    const uint8_t *p = rgb + ((size_t)y * 280 + 2 * k) * 3;
-    const int d = ((2 * bayer[(y & 3) * 4 + (k & 3)] - 15) * dither + 16 * 256) / 16 - 256;
-    IngestPixel o;
-    int v = ((int)p[0] + (int)p[3] + 1) / 2 + d;
-    o.r = v < 0 ? 0 : v > 255 ? 255 : v;
-    v = ((int)p[1] + (int)p[4] + 1) / 2 + d;
-    o.g = v < 0 ? 0 : v > 255 ? 255 : v;
-    v = ((int)p[2] + (int)p[5] + 1) / 2 + d;
-    o.b = v < 0 ? 0 : v > 255 ? 255 : v;
-    return o;
+    static const int bayer[16] = {0, 8, 2, 10, 12, 4, 14, 6, 3, 11, 1, 9, 15, 7, 13, 5};
+    IngestPalette p;
+    for (int c = 0; c < 16; c++) {
+        const int R = pal[3 * c], G = pal[3 * c + 1], B = pal[3 * c + 2];
+        p.k[c] = 16 * (2 * R * R + 4 * G * G + 3 * B * B) + c;
+        p.a[c] = -64 * R;
+        p.b[c] = -128 * G;
+        p.c[c] = -96 * B;
+        p.rgb[c] = (uint32_t)R | ((uint32_t)G << 8) | ((uint32_t)B << 16);
+        p.dither[c] = dither == IIV_DITHER_DIFFUSION ? 0 : ((2 * bayer[c] - 15) * dither + 16 * 256) / 16 - 256;
+    }
+    return p;
 }
 
-__device__ static inline int ingest_err(const uint8_t *pal, int c, const IngestPixel &px)
+// key of colour c for the pixel (r, g, b): 16 * (distance - the term common to all colours) + c
+__device__ static inline int ingest_key(const IngestPalette &P, int c, int r, int g, int b)
 {
-    const int dr = px.r - pal[3 * c], dg = px.g - pal[3 * c + 1], db = px.b - pal[3 * c + 2];
-    return 2 * dr * dr + 4 * dg * dg + 3 * db * db;
+    return __mul24(b, P.c[c]) + (__mul24(g, P.b[c]) + (__mul24(r, P.a[c]) + P.k[c]));   // three v_mad_i32_i24
 }
 
+// DHGR: the nearest of the sixteen colours (ties to the lower colour value)
+__device__ static inline int nearest16(const IngestPalette &P, int r, int g, int b)
+{
+    int m = ingest_key(P, 0, r, g, b);
+#pragma unroll
+    for (int c = 1; c < 16; c++) m = min(m, ingest_key(P, c, r, g, b));
+    return m & 15;
+}
+
+// HGR: for both palette bits, (distance term << 2 | pattern) of the nearest of the four colours the bit allows
+// (black 0, violet 3 | blue 6, green 12 | orange 9, white 15; ties to the lower pattern)
+__device__ static inline void nearest4x2(const IngestPalette &P, int r, int g, int b, int &key0, int &key1)
+{
+    const int f0 = ingest_key(P, 0, r, g, b) >> 4, f15 = ingest_key(P, 15, r, g, b) >> 4;   // (>> 4: the colour value leaves, f stays exact)
+    const int f3 = ingest_key(P, 3, r, g, b) >> 4, f12 = ingest_key(P, 12, r, g, b) >> 4;
+    const int f6 = ingest_key(P, 6, r, g, b) >> 4, f9 = ingest_key(P, 9, r, g, b) >> 4;
+    const int b0 = f0 * 4, w3 = f15 * 4 + 3;
+    key0 = min(min(b0, f3 * 4 + 1), min(f12 * 4 + 2, w3));
+    key1 = min(min(b0, f6 * 4 + 1), min(f9 * 4 + 2, w3));
+}
+
+__global__ __launch_bounds__(256) void ingest_holes_kernel(int n_banks, uint8_t *__restrict__ main_mem, uint8_t *__restrict__ aux_mem)
+{
+    // the screen holes of every page (offsets 120..127, 248..255) start as zero, as bmp2dhr's files hold them
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // one 8-byte hole each: 64 per bank
+    if (i >= (size_t)n_banks * 64) return;
+    const size_t bank = i >> 6;
+    const int h = (int)(i & 63);
+    uint8_t *base = (aux_mem && (bank & 1)) ? aux_mem + (bank >> 1) * 8192 : main_mem + (aux_mem ? bank >> 1 : bank) * 8192;
+    *reinterpret_cast<uint2 *>(base + (h >> 1) * 256 + ((h & 1) ? 248 : 120)) = make_uint2(0, 0);
+}
+
+// Ordered dither (or none): thread T of a frame owns colour pixels 7 g .. 7 g + 6 of row y, T = 20 y + g -- the
+// frame's 161 280 source bytes are 3 840 x 42 contiguous bytes in thread order.
 template <int MODE>
-__global__ __launch_bounds__(256) void ingest_kernel(int n, const uint8_t *__restrict__ rgb_frames, int dither,
-                                                     const uint8_t *__restrict__ palette, uint8_t *__restrict__ main_mem,
-                                                     uint8_t *__restrict__ aux_mem)
+__global__ __launch_bounds__(256) void ingest_kernel(int n, const uint8_t *__restrict__ rgb_frames, const IngestPalette P,
+                                                     uint8_t *__restrict__ main_mem, uint8_t *__restrict__ aux_mem)
 {
-    constexpr int BPR = MODE == kDHGR ? 80 : 40;  // screen bytes per row, in dot order
-    __shared__ uint8_t pal[48];
-    if (threadIdx.x < 48) pal[threadIdx.x] = palette[threadIdx.x];
+    __shared__ int dtab[16];
+    if (threadIdx.x < 16) dtab[threadIdx.x] = P.dither[threadIdx.x];
     __syncthreads();
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (size_t)n * 192 * BPR) return;
-    const int j = (int)(idx % BPR), y = (int)((idx / BPR) % 192);
-    const size_t f = idx / ((size_t)BPR * 192);
-    const uint8_t *rgb = rgb_frames + f * (size_t)(192 * 280 * 3);
-    const int base = y_to_offset(y);
+    if (idx >= (size_t)n * 3840) return;
+    const size_t f = idx / 3840;
+    const int T = (int)(idx - f * 3840), y = T / 20, g = T - 20 * y;
+    // 42 bytes at 42 T: aligned dwords from (42 T) & ~3, then a funnel shift by 0 or 16 bits
+    const uint8_t *src = rgb_frames + f * (size_t)(192 * 280 * 3) + (size_t)(42 * T);
+    const uint32_t *w32 = reinterpret_cast<const uint32_t *>(src - ((42 * T) & 2));
+    uint32_t w[11];
+#pragma unroll
+    for (int i = 0; i < 11; i++) w[i] = w32[i];
+    const uint32_t sh = ((uint32_t)(42 * T) & 2u) * 8u;
+    uint32_t q[11];
+#pragma unroll
+    for (int i = 0; i < 10; i++) q[i] = __builtin_amdgcn_alignbit(w[i + 1], w[i], sh);
+    q[10] = w[10] >> sh;
+    auto byte_at = [&](int nb) -> int { return (int)((q[nb >> 2] >> (8 * (nb & 3))) & 255u); };
+    const int drow = (y & 3) * 4;
+    int colour[7], k0[7], k1[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const int d = dtab[drow + ((7 * g + i) & 3)];
+        const int r = min(max(((byte_at(6 * i) + byte_at(6 * i + 3) + 1) >> 1) + d, 0), 255);
+        const int gg = min(max(((byte_at(6 * i + 1) + byte_at(6 * i + 4) + 1) >> 1) + d, 0), 255);
+        const int b = min(max(((byte_at(6 * i + 2) + byte_at(6 * i + 5) + 1) >> 1) + d, 0), 255);
+        if (MODE == kDHGR)
+            colour[i] = nearest16(P, r, gg, b);
+        else
+            nearest4x2(P, r, gg, b, k0[i], k1[i]);
+    }
+    const size_t out = f * 8192 + (size_t)(y_to_offset(y) + 2 * g);
     if (MODE == kDHGR) {
-        // dots 7j .. 7j+6 lie in the quads (7j) >> 2 .. (7j + 6) >> 2 (two or three of them)
-        const int q0 = (7 * j) >> 2, q1 = (7 * j + 6) >> 2;
-        int quad[3] = {0, 0, 0};
-        for (int q = q0; q <= q1; q++) {
-            const IngestPixel px = ingest_pixel(rgb, y, q, dither);
-            int best = 0, be = 0x7fffffff;
-            for (int c = 0; c < 16; c++) {
-                const int e = ingest_err(pal, c, px);
-                if (e < be) {
-                    be = e;
-                    best = c;
-                }
-            }
-            quad[q - q0] = best;
-        }
-        int v = 0;
-        for (int i = 0; i < 7; i++) {
-            const int X = 7 * j + i;
-            v |= ((quad[(X >> 2) - q0] >> (X & 3)) & 1) << i;
-        }
-        // bytes alternate aux, main in dot order (screen.py:822-826)
-        ((j & 1) ? main_mem : aux_mem)[f * 8192 + base + (j >> 1)] = (uint8_t)v;
+        // a colour value IS its pixel's aligned dot quad (colours.py:100-134): 28 dots, seven per byte, aux / main alternating
+        uint32_t dots = 0;
+#pragma unroll
+        for (int i = 0; i < 7; i++) dots |= (uint32_t)colour[i] << (4 * i);
+        const uint32_t b0 = dots & 0x7fu, b1 = (dots >> 7) & 0x7fu, b2 = (dots >> 14) & 0x7fu, b3 = (dots >> 21) & 0x7fu;
+        *reinterpret_cast<uint16_t *>(aux_mem + out) = (uint16_t)(b0 | (b2 << 8));
+        *reinterpret_cast<uint16_t *>(main_mem + out) = (uint16_t)(b1 | (b3 << 8));
     } else {
-        // the colour values a pixel can take under either palette bit, pattern bit 0 = even dot
-        // column (colours.py:18-44): black, violet | blue, green | orange, white
-        constexpr int colour[2][4] = {{0, 3, 12, 15}, {0, 6, 9, 15}};
-        const int k0 = (7 * j) >> 1, k1 = (7 * j + 6) >> 1;  // four pixels touch the byte
-        int pat[2][4], err[2][4];
-        for (int k = k0; k <= k1; k++) {
-            const IngestPixel px = ingest_pixel(rgb, y, k, dither);
-            for (int pb = 0; pb < 2; pb++) {
-                int best = 0, be = 0x7fffffff;
-                for (int q = 0; q < 4; q++) {
-                    const int e = ingest_err(pal, colour[pb][q], px);
-                    if (e < be) {
-                        be = e;
-                        best = q;
-                    }
-                }
-                pat[pb][k - k0] = best;
-                err[pb][k - k0] = be;
-            }
-        }
-        long e0 = 0, e1 = 0;
-        for (int i = 0; i < 7; i++) {
-            e0 += err[0][((7 * j + i) >> 1) - k0];
-            e1 += err[1][((7 * j + i) >> 1) - k0];
-        }
-        const int pb = e1 < e0 ? 1 : 0;
-        int v = pb << 7;
-        for (int i = 0; i < 7; i++) {
-            const int X = 7 * j + i;
-            v |= ((pat[pb][(X >> 1) - k0] >> (X & 1)) & 1) << i;
-        }
-        main_mem[f * 8192 + base + j] = (uint8_t)v;
+        // byte A = dots 0..6 (pixels 0, 0, 1, 1, 2, 2, 3), byte B = dots 7..13 (pixels 3, 4, 4, 5, 5, 6, 6); per byte the palette
+        // bit with the smaller summed nearest-colour error over its seven dots (the term common to all colours cancels)
+        // (sums of seven terms below 2^21 in magnitude: int)
+        const int eA0 = 2 * ((k0[0] >> 2) + (k0[1] >> 2) + (k0[2] >> 2)) + (k0[3] >> 2);
+        const int eA1 = 2 * ((k1[0] >> 2) + (k1[1] >> 2) + (k1[2] >> 2)) + (k1[3] >> 2);
+        const int eB0 = (k0[3] >> 2) + 2 * ((k0[4] >> 2) + (k0[5] >> 2) + (k0[6] >> 2));
+        const int eB1 = (k1[3] >> 2) + 2 * ((k1[4] >> 2) + (k1[5] >> 2) + (k1[6] >> 2));
+        const int pbA = eA1 < eA0 ? 1 : 0, pbB = eB1 < eB0 ? 1 : 0;
+        auto pat = [&](int i, int pb) -> uint32_t { return (uint32_t)((pb ? k1[i] : k0[i]) & 3); };
+        const uint32_t A = pat(0, pbA) | (pat(1, pbA) << 2) | (pat(2, pbA) << 4) | ((pat(3, pbA) & 1u) << 6) | ((uint32_t)pbA << 7);
+        const uint32_t B = (pat(3, pbB) >> 1) | (pat(4, pbB) << 1) | (pat(5, pbB) << 3) | (pat(6, pbB) << 5) | ((uint32_t)pbB << 7);
+        *reinterpret_cast<uint16_t *>(main_mem + out) = (uint16_t)(A | (B << 8));
     }
 }
 
-// dither == IIV_DITHER_DIFFUSION: Floyd-Steinberg error diffusion (include/iivision.h).  A pixel needs the errors of
-// its left neighbour and of three pixels of the row above, so the rows of a frame advance as a skewed wavefront: one
-// thread per row, row y works on pixel t - 6 y at step t (six behind the row above: HGR fixes a screen byte's palette
-// bit from the accumulated error of up to four pixels ahead, which must have received everything the row above
-// sends them), one workgroup barrier per step, 140 + 6 * 191 steps per frame.  The accumulators of a row live in an
-// eight-slot ring in LDS (pixel k in slot k & 7): the row above writes slots k + 5 .. k + 7 while the row itself
-// reads k .. k + 3 and adds to k + 1.
-template <int MODE>
-__global__ __launch_bounds__(192) void ingest_diffusion_kernel(const uint8_t *__restrict__ rgb_frames, const uint8_t *__restrict__ palette,
-                                                               uint8_t *__restrict__ main_mem, uint8_t *__restrict__ aux_mem)
+// dither == IIV_DITHER_DIFFUSION, DHGR: Floyd-Steinberg error diffusion (include/iivision.h), one wave per frame.
+// Step t: lane l is at position u = t - 2 l of its 420-pixel sequence (rows l, l + 64, l + 128, 140 pixels each).
+// All lanes are at pixels of the same parity, so a source load fetches two pixels (12 bytes, three aligned dwords)
+// every other step, two steps ahead of their use.
+constexpr int kDiffWavesPerBlock = 4;
+__global__ __launch_bounds__(64 * kDiffWavesPerBlock) void ingest_diffusion_dhgr_kernel(int n, const uint8_t *__restrict__ rgb_frames, const IngestPalette P,
+                                                                                           uint8_t *__restrict__ main_mem, uint8_t *__restrict__ aux_mem)
+{
+    __shared__ int ring_s[kDiffWavesPerBlock][16][4];   // lane 63's D(j) for lane 0, slot j & 15 (read 13 steps after it is written)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t f = (size_t)blockIdx.x * kDiffWavesPerBlock + wv;
+    if (f >= (size_t)n) return;
+    int (*ring)[4] = ring_s[wv];
+    const uint8_t *frame = rgb_frames + f * (size_t)(192 * 280 * 3);
+    // the palette's RGB in lanes 0..15 of one register: a pixel's chosen colour is looked up with one ds_bpermute
+    const uint32_t pal_v = P.rgb[lane & 15];
+    int u = -2 * lane;          // position in this lane's 420-pixel sequence
+    int k = 0, row = lane;      // pixel and row while 0 <= u < 420
+    int ph = 0, grp = 0;        // k % 7, k / 7
+    int A0 = 0, A1 = 0, A2 = 0;          // 7 e of the pixel to the left (sixteenths)
+    int e1r = 0, e1g = 0, e1b = 0;       // error of the previous pixel of the row, and of the one before
+    int e2r = 0, e2g = 0, e2b = 0;
+    int dr = 0, dg = 0, db = 0;          // D(k) from the row above, received from lane l - 1 at the end of the previous step
+    uint32_t dots = 0;
+    // source words of pixels (k, k + 1) for even k, and the pair requested for two steps later
+    auto src_of = [&](int rw, int kk) -> const uint32_t * {
+        return reinterpret_cast<const uint32_t *>(frame + (size_t)rw * 840 + (size_t)kk * 6);
+    };
+    auto clamp_pos = [&](int uu, int &rw, int &kk) {   // (row, pixel) of sequence position uu, clamped into the frame
+        const int v = uu < 0 ? 0 : uu > 418 ? 418 : uu;   // (418: the last pair of the last row -- a load never runs off the frame)
+        const int qq = v >= 280 ? 2 : v >= 140 ? 1 : 0;
+        rw = lane + 64 * qq;
+        kk = v - 140 * qq;
+    };
+    uint32_t c0, c1, c2, n0, n1, n2;
+    {
+        int rw, kk;
+        clamp_pos(u & ~1, rw, kk);
+        const uint32_t *p = src_of(rw, kk);
+        c0 = p[0], c1 = p[1], c2 = p[2];
+        clamp_pos((u & ~1) + 2, rw, kk);
+        p = src_of(rw, kk);
+        n0 = p[0], n1 = p[1], n2 = p[2];
+    }
+    // one pixel step; (s0, s1): the source bytes r0 g0 b0 r1 g1 b1 of this pixel as two words (low 48 bits used).
+    // Branch-free: every lane computes (inactive lanes on clamped source bytes, results discarded) -- the palette lookup is a
+    // ds_bpermute, which reads 0 from lanes that are switched off, and lanes 0..15 hold the palette.
+    auto step = [&](uint32_t s0, uint32_t s1) {
+        const bool active = u >= 0 && u < 420;
+        const bool flush = u == 420;            // one step behind the last pixel: D(139) of the last row still leaves
+        int ir = dr, ig = dg, ib = db;          // from the row above
+        if (lane == 0) {
+            // rows 64 and 128: what lane 63 emitted 140 positions earlier; row 0: nothing above
+            const int *slot = ring[(u - 140) & 15];
+            const bool has = u >= 140;
+            ir = has ? slot[0] : 0, ig = has ? slot[1] : 0, ib = has ? slot[2] : 0;
+        }
+        const int mr = (int)((s0 & 255u) + ((s0 >> 24) & 255u) + 1u) >> 1;
+        const int mg = (int)(((s0 >> 8) & 255u) + (s1 & 255u) + 1u) >> 1;
+        const int mb = (int)(((s0 >> 16) & 255u) + ((s1 >> 8) & 255u) + 1u) >> 1;
+        const int r = min(max(mr + ((A0 + ir) >> 4), 0), 255);   // (>> 4 of a negative int: floor)
+        const int g = min(max(mg + ((A1 + ig) >> 4), 0), 255);
+        const int b = min(max(mb + ((A2 + ib) >> 4), 0), 255);
+        const int col = nearest16(P, r, g, b);
+        const uint32_t prgb = (uint32_t)__builtin_amdgcn_ds_bpermute(col << 2, (int)pal_v);
+        const int er = active ? r - (int)(prgb & 255u) : 0;
+        const int eg = active ? g - (int)((prgb >> 8) & 255u) : 0;
+        const int eb = active ? b - (int)((prgb >> 16) & 255u) : 0;
+        if (active) {
+            dots |= (uint32_t)col << (4 * ph);
+            if (ph == 6) {
+                const size_t out = f * 8192 + (size_t)(y_to_offset(row) + 2 * grp);
+                const uint32_t b0 = dots & 0x7fu, b1 = (dots >> 7) & 0x7fu, b2 = (dots >> 14) & 0x7fu, b3 = (dots >> 21) & 0x7fu;
+                *reinterpret_cast<uint16_t *>(aux_mem + out) = (uint16_t)(b0 | (b2 << 8));
+                *reinterpret_cast<uint16_t *>(main_mem + out) = (uint16_t)(b1 | (b3 << 8));
+                dots = 0;
+            }
+        }
+        // what the row below receives for its pixel j = k - 1 (j = 139 of the row just finished when k == 0 or at the flush):
+        // D(j) = e(j - 1) + 5 e(j) + 3 e(j + 1), the last term absent behind the end of the row
+        const bool first = k == 0;
+        const int t3r = first ? 0 : 3 * er, t3g = first ? 0 : 3 * eg, t3b = first ? 0 : 3 * eb;   // (er = 0 at the flush: not active)
+        const int outr = e2r + 5 * e1r + t3r, outg = e2g + 5 * e1g + t3g, outb = e2b + 5 * e1b + t3b;
+        if (lane == 63 && ((active && u >= 1) || flush)) {
+            // (slot = position of the emitted D in lane 63's sequence, u - 1: lane 0 reads it 13 steps later as its position - 140)
+            int *slot = ring[(u - 1) & 15];
+            slot[0] = outr, slot[1] = outg, slot[2] = outb;
+        }
+        wave_lds_sync();   // (LDS accesses of one wave execute in order; this keeps the compiler from moving them)
+        // to lane l + 1 (wave_shr:1; lane 0 keeps the 0 it is given, which it never uses)
+        dr = __builtin_amdgcn_update_dpp(0, outr, 0x138, 0xf, 0xf, false);
+        dg = __builtin_amdgcn_update_dpp(0, outg, 0x138, 0xf, 0xf, false);
+        db = __builtin_amdgcn_update_dpp(0, outb, 0x138, 0xf, 0xf, false);
+        if (active) {
+            // the row's own history: at the first pixel of a row the previous row's errors have just left (above)
+            e2r = first ? 0 : e1r, e2g = first ? 0 : e1g, e2b = first ? 0 : e1b;
+            e1r = er, e1g = eg, e1b = eb;
+            A0 = 7 * er, A1 = 7 * eg, A2 = 7 * eb;
+            k++;
+            if (++ph == 7) ph = 0, grp++;
+            if (k == 140) {
+                k = 0, ph = 0, grp = 0;
+                row += 64;
+                A0 = A1 = A2 = 0;
+            }
+        }
+        u++;
+    };
+    // 420 pixels + 126 steps of skew + the flush step of lane 63: u of lane 63 reaches 420 at t = 546
+    for (int t = 0; t < 548; t += 2) {
+        // (u is even here for every lane: t and 2 l are)
+        step(c0, c1);
+        step((c1 >> 16) | (c2 << 16), c2 >> 16);
+        c0 = n0, c1 = n1, c2 = n2;
+        int rw, kk;
+        clamp_pos(u + 2, rw, kk);
+        const uint32_t *p = src_of(rw, kk);
+        n0 = p[0], n1 = p[1], n2 = p[2];
+    }
+}
+
+// dither == IIV_DITHER_DIFFUSION, HGR: a pixel needs the errors of its left neighbour and of three pixels of the row
+// above, and a screen byte's palette bit is fixed from the accumulated error of up to four pixels ahead, which must
+// have received everything the row above sends them: the rows of a frame advance as a skewed wavefront, one thread
+// per row, row y working on pixel t - 6 y at step t, one workgroup barrier per step, 140 + 6 * 191 steps per frame.
+// The accumulators of a row live in an eight-slot ring in LDS (pixel k in slot k & 7): the row above writes slots
+// k + 5 .. k + 7 while the row itself reads k .. k + 3 and adds to k + 1.
+__device__ static inline int ingest_err(const uint8_t *pal, int c, int r, int g, int b)
+{
+    const int dr = r - pal[3 * c], dg = g - pal[3 * c + 1], db = b - pal[3 * c + 2];
+    return 2 * dr * dr + 4 * dg * dg + 3 * db * db;
+}
+
+__global__ __launch_bounds__(192) void ingest_diffusion_hgr_kernel(const uint8_t *__restrict__ rgb_frames, const IngestPalette P,
+                                                                   uint8_t *__restrict__ main_mem)
 {
     constexpr int colour4[2][4] = {{0, 3, 12, 15}, {0, 6, 9, 15}};
     __shared__ int ring[192][8][3];
-    __shared__ uint8_t patt[192][140];   // DHGR: colour value = dot quad; HGR: 2-dot pattern | palette bit << 2
+    __shared__ uint8_t patt[192][140];   // 2-dot pattern | palette bit << 2
     __shared__ uint8_t pal[48];
     const int y = threadIdx.x;
     const size_t f = blockIdx.x;
     const uint8_t *rgb = rgb_frames + f * (size_t)(192 * 280 * 3) + (size_t)y * 280 * 3;
-    if (y < 48) pal[y] = palette[y];
+    if (y < 16) {
+        pal[3 * y] = (uint8_t)(P.rgb[y] & 255u);
+        pal[3 * y + 1] = (uint8_t)((P.rgb[y] >> 8) & 255u);
+        pal[3 * y + 2] = (uint8_t)((P.rgb[y] >> 16) & 255u);
+    }
     for (int i = 0; i < 24; i++) (&ring[y][0][0])[i] = 0;
     __syncthreads();
-    auto value = [&](int k, IngestPixel &o) {
+    auto value = [&](int k, int &r, int &g, int &b) {
         const uint8_t *p = rgb + 6 * k;
         const int *a = ring[y][k & 7];
         int v = ((int)p[0] + (int)p[3] + 1) / 2 + (a[0] >> 4);   // (>> 4 of a negative int: floor)
-        o.r = v < 0 ? 0 : v > 255 ? 255 : v;
+        r = v < 0 ? 0 : v > 255 ? 255 : v;
         v = ((int)p[1] + (int)p[4] + 1) / 2 + (a[1] >> 4);
-        o.g = v < 0 ? 0 : v > 255 ? 255 : v;
+        g = v < 0 ? 0 : v > 255 ? 255 : v;
         v = ((int)p[2] + (int)p[5] + 1) / 2 + (a[2] >> 4);
-        o.b = v < 0 ? 0 : v > 255 ? 255 : v;
+        b = v < 0 ? 0 : v > 255 ? 255 : v;
     };
     int pb = 0;
     for (int t = 0; t < 140 + 6 * 191; t++) {
         const int k = t - 6 * y;
         if (k >= 0 && k < 140) {
-            IngestPixel px;
-            int colour, pattern;
-            if (MODE == kDHGR) {
-                value(k, px);
-                int best = 0, be = 0x7fffffff;
-                for (int c = 0; c < 16; c++) {
-                    const int e = ingest_err(pal, c, px);
-                    if (e < be) {
-                        be = e;
-                        best = c;
+            int r, g, b;
+            if (k == 0 || (2 * k) / 7 != (2 * k - 2) / 7) {   // the first dot of this pixel opens screen byte bb
+                const int bb = (2 * k) / 7;
+                long err0 = 0, err1 = 0;
+                for (int kk = k; kk < 140 && (2 * kk) / 7 == bb; kk++) {
+                    int ur, ug, ub;
+                    value(kk, ur, ug, ub);
+                    const int w = (2 * kk + 1) / 7 == bb ? 2 : 1;
+                    int b0 = 0x7fffffff, b1 = 0x7fffffff;
+                    for (int i = 0; i < 4; i++) {
+                        const int e0 = ingest_err(pal, colour4[0][i], ur, ug, ub), e1 = ingest_err(pal, colour4[1][i], ur, ug, ub);
+                        b0 = e0 < b0 ? e0 : b0;
+                        b1 = e1 < b1 ? e1 : b1;
                     }
+                    err0 += (long)w * b0;
+                    err1 += (long)w * b1;
                 }
-                pattern = colour = best;
-            } else {
-                if (k == 0 || (2 * k) / 7 != (2 * k - 2) / 7) {   // the first dot of this pixel opens screen byte b
-                    const int b = (2 * k) / 7;
-                    long err0 = 0, err1 = 0;
-                    for (int kk = k; kk < 140 && (2 * kk) / 7 == b; kk++) {
-                        IngestPixel u;
-                        value(kk, u);
-                        const int w = (2 * kk + 1) / 7 == b ? 2 : 1;
-                        int b0 = 0x7fffffff, b1 = 0x7fffffff;
-                        for (int i = 0; i < 4; i++) {
-                            const int e0 = ingest_err(pal, colour4[0][i], u), e1 = ingest_err(pal, colour4[1][i], u);
-                            b0 = e0 < b0 ? e0 : b0;
-                            b1 = e1 < b1 ? e1 : b1;
-                        }
-                        err0 += (long)w * b0;
-                        err1 += (long)w * b1;
-                    }
-                    pb = err1 < err0 ? 1 : 0;
-                }
-                value(k, px);
-                int best = 0, be = 0x7fffffff;
-                for (int i = 0; i < 4; i++) {
-                    const int e = ingest_err(pal, colour4[pb][i], px);
-                    if (e < be) {
-                        be = e;
-                        best = i;
-                    }
-                }
-                pattern = best | (pb << 2);
-                colour = colour4[pb][best];
+                pb = err1 < err0 ? 1 : 0;
             }
-            patt[y][k] = (uint8_t)pattern;
-            const int e[3] = {px.r - pal[3 * colour], px.g - pal[3 * colour + 1], px.b - pal[3 * colour + 2]};
+            value(k, r, g, b);
+            int best = 0, be = 0x7fffffff;
+            for (int i = 0; i < 4; i++) {
+                const int e = ingest_err(pal, colour4[pb][i], r, g, b);
+                if (e < be) {
+                    be = e;
+                    best = i;
+                }
+            }
+            const int colour = colour4[pb][best];
+            patt[y][k] = (uint8_t)(best | (pb << 2));
+            const int e[3] = {r - pal[3 * colour], g - pal[3 * colour + 1], b - pal[3 * colour + 2]};
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 ring[y][k & 7][c] = 0;   // the slot is pixel k + 8's from now on
@@ -216,55 +374,43 @@ __global__ __launch_bounds__(192) void ingest_diffusion_kernel(const uint8_t *__
     }
     // the row's bytes (this thread wrote every pattern of its row itself)
     const int base = y_to_offset(y);
-    if (MODE == kDHGR) {
-        for (int j = 0; j < 80; j++) {
-            int v = 0;
-            for (int i = 0; i < 7; i++) {
-                const int X = 7 * j + i;
-                v |= ((patt[y][X >> 2] >> (X & 3)) & 1) << i;
-            }
-            ((j & 1) ? main_mem : aux_mem)[f * 8192 + base + (j >> 1)] = (uint8_t)v;
+    for (int bb = 0; bb < 40; bb++) {
+        // the byte's palette bit is that of the first pixel whose first dot lies in it
+        int v = ((patt[y][(7 * bb + 1) >> 1] >> 2) & 1) << 7;
+        for (int i = 0; i < 7; i++) {
+            const int X = 7 * bb + i;
+            v |= ((patt[y][X >> 1] >> (X & 1)) & 1) << i;
         }
-    } else {
-        for (int b = 0; b < 40; b++) {
-            // the byte's palette bit is that of the first pixel whose first dot lies in it
-            int v = ((patt[y][(7 * b + 1) >> 1] >> 2) & 1) << 7;
-            for (int i = 0; i < 7; i++) {
-                const int X = 7 * b + i;
-                v |= ((patt[y][X >> 1] >> (X & 1)) & 1) << i;
-            }
-            main_mem[f * 8192 + base + b] = (uint8_t)v;
-        }
+        main_mem[f * 8192 + base + bb] = (uint8_t)v;
     }
 }
 
 int frames_to_memory_maps(int mode, const uint8_t palette_rgb[48], int n, const uint8_t *d_rgb, int dither, uint8_t *d_main,
                           uint8_t *d_aux, hipStream_t st)
 {
-    uint8_t *d_pal = nullptr;
-    IIV_HIP(hipMalloc(&d_pal, 48));
-    int rc = hip_check(hipMemcpyAsync(d_pal, palette_rgb, 48, hipMemcpyHostToDevice, st), "copy palette");
-    // screen holes (and everything else) start as zero, as bmp2dhr's files hold them
-    if (!rc) rc = hip_check(hipMemsetAsync(d_main, 0, (size_t)n * 8192, st), "clear main");
-    if (!rc && mode == kDHGR) rc = hip_check(hipMemsetAsync(d_aux, 0, (size_t)n * 8192, st), "clear aux");
-    if (!rc && dither == IIV_DITHER_DIFFUSION) {
-        if (mode == kDHGR)
-            hipLaunchKernelGGL(ingest_diffusion_kernel<kDHGR>, dim3((unsigned)n), dim3(192), 0, st, d_rgb, d_pal, d_main, d_aux);
+    const IngestPalette P = make_palette(palette_rgb, dither);
+    const int n_banks = mode == kDHGR ? 2 * n : n;
+    hipLaunchKernelGGL(ingest_holes_kernel, dim3((unsigned)(((size_t)n_banks * 64 + 255) / 256)), dim3(256), 0, st, n_banks, d_main,
+                       mode == kDHGR ? d_aux : (uint8_t *)nullptr);
+    int rc = hip_check(hipGetLastError(), "ingest_holes_kernel launch");
+    if (rc) return rc;
+    if (dither == IIV_DITHER_DIFFUSION) {
+        if (mode == kDHGR) {
+            static const int pad = getenv("IIV_EXP_DIFF_LDS_PAD") ? atoi(getenv("IIV_EXP_DIFF_LDS_PAD")) : 0;   // EXPERIMENT: residency cap
+            hipLaunchKernelGGL(ingest_diffusion_dhgr_kernel, dim3((unsigned)((n + kDiffWavesPerBlock - 1) / kDiffWavesPerBlock)),
+                               dim3(64 * kDiffWavesPerBlock), (size_t)pad, st, n, d_rgb, P, d_main, d_aux);
+        }
         else
-            hipLaunchKernelGGL(ingest_diffusion_kernel<kHGR>, dim3((unsigned)n), dim3(192), 0, st, d_rgb, d_pal, d_main, d_aux);
-        rc = hip_check(hipGetLastError(), "ingest_diffusion_kernel launch");
-    } else if (!rc) {
-        const size_t total = (size_t)n * 192 * (mode == kDHGR ? 80 : 40);
-        dim3 grid((unsigned)((total + 255) / 256));
-        if (mode == kDHGR)
-            hipLaunchKernelGGL(ingest_kernel<kDHGR>, grid, dim3(256), 0, st, n, d_rgb, dither, d_pal, d_main, d_aux);
-        else
-            hipLaunchKernelGGL(ingest_kernel<kHGR>, grid, dim3(256), 0, st, n, d_rgb, dither, d_pal, d_main, d_aux);
-        rc = hip_check(hipGetLastError(), "ingest_kernel launch");
+            hipLaunchKernelGGL(ingest_diffusion_hgr_kernel, dim3((unsigned)n), dim3(192), 0, st, d_rgb, P, d_main);
+        return hip_check(hipGetLastError(), "ingest diffusion kernel launch");
     }
-    if (!rc) rc = hip_check(hipStreamSynchronize(st), "ingest sync");  // palette_rgb is caller memory; d_pal freed below
-    (void)hipFree(d_pal);
-    return rc;
+    const size_t total = (size_t)n * 3840;
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (mode == kDHGR)
+        hipLaunchKernelGGL(ingest_kernel<kDHGR>, grid, dim3(256), 0, st, n, d_rgb, P, d_main, d_aux);
+    else
+        hipLaunchKernelGGL(ingest_kernel<kHGR>, grid, dim3(256), 0, st, n, d_rgb, P, d_main, d_aux);
+    return hip_check(hipGetLastError(), "ingest_kernel launch");
 }
 
 }  // namespace iiv
@@ -275,6 +421,8 @@ extern "C" int iiv_frames_to_memory_maps(int mode, const uint8_t palette_rgb[48]
     if ((mode != IIV_HGR && mode != IIV_DHGR) || !palette_rgb || n_frames < 0 || !d_rgb || !d_main ||
         (mode == IIV_DHGR && !d_aux) || dither < 0 || dither > IIV_DITHER_DIFFUSION)
         return iiv::set_error(IIV_ERR_INVALID, "iiv_frames_to_memory_maps: bad argument");
+    if (((uintptr_t)d_rgb & 3) || ((uintptr_t)d_main & 7) || ((uintptr_t)d_aux & 7))
+        return iiv::set_error(IIV_ERR_INVALID, "iiv_frames_to_memory_maps: d_rgb must be 4-byte aligned, d_main / d_aux 8-byte aligned");
     if (n_frames == 0) return IIV_OK;
     return iiv::frames_to_memory_maps(mode, palette_rgb, n_frames, d_rgb, dither, d_main, d_aux, (hipStream_t)stream);
 }

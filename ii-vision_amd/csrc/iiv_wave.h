@@ -27,6 +27,38 @@ __device__ static inline int wave_min_i32(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// The wave's TWO smallest values in one pass.  In: this lane's own two smallest, k1 <= k2 (values that are equal across lanes
+// must be ones the caller does not care about: a value present in two lanes would be counted twice).  A step merges a lane's
+// pair with its DPP partner's: three fused-DPP ops (min / max of the firsts, min of the seconds) and one min, each reading a
+// register written at least two instructions earlier -- no s_nop between them, where two separate minima (the second needs
+// the first's result to find the lane that gives up its key) cost 2 x (6 DPP + 6 s_nop) and a select chain in between.
+// Out: (k1, k2) of lane 63 = the wave's two smallest, in SGPRs.
+// (Written as one asm block: from C++ the compiler fuses only two of a step's three DPP reads and adds a v_mov, a v_mov_dpp and
+// an INT_MAX materialisation per step -- six instructions instead of four.  Hazards: a DPP op may read a VGPR two instructions
+// after the VALU op that wrote it; every read below keeps that distance, the s_nop covers the producers in front of the block.
+// A lane whose DPP source does not exist (row_bcast into row 0, or rows 0 / 1) keeps what its destination held: nonsense that
+// only such lanes ever read.)
+__device__ static inline void wave_top2_i32(int &k1, int &k2)
+{
+    int a, h, m;
+#define IIV_TOP2_STEP(dst, src, ctrl)                                              \
+    "v_min_i32_dpp " dst ", " src ", " src " " ctrl " row_mask:0xf bank_mask:0xf\n\t" \
+    "v_max_i32_dpp %3, " src ", " src " " ctrl " row_mask:0xf bank_mask:0xf\n\t"      \
+    "v_min_i32_dpp %4, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                \
+    "v_min_i32_e32 %1, %3, %4\n\t"
+    asm volatile("s_nop 1\n\t"
+                 IIV_TOP2_STEP("%2", "%0", "quad_perm:[1,0,3,2]")
+                 IIV_TOP2_STEP("%0", "%2", "quad_perm:[2,3,0,1]")
+                 IIV_TOP2_STEP("%2", "%0", "row_half_mirror")
+                 IIV_TOP2_STEP("%0", "%2", "row_mirror")       // every lane holds its row's pair
+                 IIV_TOP2_STEP("%2", "%0", "row_bcast:15")     // row r + row r - 1
+                 IIV_TOP2_STEP("%0", "%2", "row_bcast:31")     // lane 63: all four rows, each once
+                 : "+v"(k1), "+v"(k2), "=&v"(a), "=&v"(h), "=&v"(m));
+#undef IIV_TOP2_STEP
+    k1 = __builtin_amdgcn_readlane(k1, 63);
+    k2 = __builtin_amdgcn_readlane(k2, 63);
+}
+
 template <int CTRL> __device__ static inline uint32_t dpp_u32(uint32_t v)
 {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);

@@ -659,14 +659,26 @@ def emit_chunk(mode, ops, first_op, d_tick_addr, ack_addr, out, ticks=None, cons
 DITHER_DIFFUSION = 256   # IIV_DITHER_DIFFUSION: Floyd-Steinberg error diffusion instead of the ordered dither
 
 
-def frames_to_memory_maps(mode, palette_rgb, rgb, dither=0):
+def frames_to_memory_maps(mode, palette_rgb, rgb, dither=0, out=None):
     """rgb: CUDA uint8 (n, 192, 280, 3) -> (main, aux) CUDA uint8 (n, 32, 256); aux is None for HGR.
-    dither: 0..255 = amplitude of the 4x4 ordered dither, DITHER_DIFFUSION = error diffusion."""
+    dither: 0..255 = amplitude of the 4x4 ordered dither, DITHER_DIFFUSION = error diffusion.
+    out=(main, aux): write into these contiguous CUDA uint8 tensors of n * 8192 bytes each (any shape; aux ignored
+    for HGR) instead of allocating -- e.g. a (streams, frames, 32, 256) slice of a batch's target frames.
+    Asynchronous on torch's current stream."""
     torch = _torch()
-    assert rgb.dtype == torch.uint8 and tuple(rgb.shape[1:]) == (192, 280, 3) and rgb.is_contiguous()
+    if not (rgb.is_cuda and rgb.dtype == torch.uint8 and rgb.dim() == 4 and tuple(rgb.shape[1:]) == (192, 280, 3) and rgb.is_contiguous()):
+        raise ValueError("rgb must be a contiguous CUDA uint8 tensor (n, 192, 280, 3)")
     n = int(rgb.shape[0])
     pal = np.ascontiguousarray(palette_rgb, dtype=np.uint8).reshape(48)
-    main = torch.empty((n, 32, 256), dtype=torch.uint8, device="cuda")
-    aux = torch.empty((n, 32, 256), dtype=torch.uint8, device="cuda") if mode == DHGR else None
+    if out is None:
+        main = torch.empty((n, 32, 256), dtype=torch.uint8, device="cuda")
+        aux = torch.empty((n, 32, 256), dtype=torch.uint8, device="cuda") if mode == DHGR else None
+    else:
+        main, aux = out
+        for t in ((main, aux) if mode == DHGR else (main,)):
+            if not (t is not None and t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous() and t.numel() == n * 8192):
+                raise ValueError("out tensors must be contiguous CUDA uint8 tensors of n * 8192 bytes")
+        if mode != DHGR:
+            aux = None
     check(lib().iiv_frames_to_memory_maps(mode, hptr(pal), n, dptr(rgb), int(dither), dptr(main), dptr(aux), stream_ptr()))
     return main, aux

@@ -190,6 +190,35 @@ def synth_frames_img(n_streams, n_frames, dhgr, seed, device="cuda"):
     return out[0], (out[1] if dhgr else None)
 
 
+def synth_rgb_torch(n_clips, n_frames, seed, device="cuda"):
+    """Synthetic RGB video for the frame-ingest path (f3: iiv_frames_to_memory_maps): (n_clips, n_frames, 192, 280, 3) uint8,
+    picture-like -- per clip three drifting low-frequency colour fields, a moving hard-edged bar and a little noise, so that
+    dithering has gradients to work on and consecutive frames resemble each other.  Generated on the device."""
+    import torch
+    g = torch.Generator(device="cpu")
+    g.manual_seed(int(seed))
+
+    def par(lo, hi, shape=(n_clips, 1, 1, 3)):
+        return (torch.rand(shape, generator=g) * (hi - lo) + lo).to(device)
+
+    fx, fy, ft, ph = par(0.004, 0.03), par(0.004, 0.04), par(0.02, 0.12), par(0.0, 6.28)
+    bar_speed, bar_w, bar_pos = par(0.5, 4.0, (n_clips, 1, 1, 1)), par(10.0, 60.0, (n_clips, 1, 1, 1)), par(0.0, 280.0, (n_clips, 1, 1, 1))
+    bar_col = par(0.0, 255.0, (n_clips, 1, 1, 3))
+    y = torch.arange(192, device=device, dtype=torch.float32).view(1, 192, 1, 1)
+    x = torch.arange(280, device=device, dtype=torch.float32).view(1, 1, 280, 1)
+    gd = torch.Generator(device=device)
+    gd.manual_seed(int(seed) + 1)
+    out = torch.empty((n_clips, n_frames, 192, 280, 3), dtype=torch.uint8, device=device)
+    for f in range(n_frames):
+        v = 127.5 + 127.5 * torch.sin(fx * x + fy * y + ft * f + ph)                       # (n_clips, 192, 280, 3)
+        bx = (bar_pos + bar_speed * f) % 280.0
+        in_bar = ((x - bx) % 280.0) < bar_w
+        v = torch.where(in_bar, bar_col.expand_as(v), v)
+        v = v + (torch.rand(v.shape, device=device, generator=gd) - 0.5) * 6.0
+        out[:, f] = v.clamp_(0, 255).to(torch.uint8)
+    return out
+
+
 class StreamBatch:
     """S independent video.Video encoders advanced in lock step on one GPU."""
 

@@ -423,7 +423,8 @@ int iiv_emit_stream(int mode, int n_streams, long n_ops, const uint8_t *d_ops, c
  * d_rgb: [n_frames][192][280][3] u8 (frame_grabber.py:75,100 resizes every frame to 280x192);
  * palette_rgb: 16 x 3 host bytes, row i = colour value i (palette.py:37-78); dither: amplitude
  * 0..255 of the ordered dither (0 = none), or IIV_DITHER_DIFFUSION; d_main / d_aux: [n_frames][32][256] u8 memory maps (d_aux ignored for
- * HGR).  Synchronises. */
+ * HGR).  d_rgb 4-byte aligned, d_main / d_aux 8-byte aligned.  Asynchronous on `stream` (the palette is read before the call
+ * returns; nothing is allocated): a batch's frames can be converted while the previous batch is being encoded. */
 #define IIV_DITHER_DIFFUSION 256
 int iiv_frames_to_memory_maps(int mode, const uint8_t palette_rgb[48], int n_frames, const uint8_t *d_rgb,
                               int dither, uint8_t *d_main, uint8_t *d_aux, void *stream);

@@ -243,3 +243,36 @@ def test_encoder_picks_the_kernel_form_by_what_its_kernels_report(native, device
         b.enc.set_greedy_kernel("shared")
         assert b.enc.input_stats()[1] == "shared"
         b.close()
+
+
+def test_bench_batch_size_sampled_against_the_oracle(native, O, oracle_tables, device_tables):
+    """The bench's own batch -- 14336 DHGR streams, the persistent workgroups' queue running 3.5 rounds -- for two
+    Movie-paced frames (three generators, a bank flip) through the one-wave kernel's forms: plain, LDS-shared, and both
+    with the fourth offset.  Sixteen streams spread over the whole queue (first, last, the workgroup boundaries around the
+    resident count) equal their stand-alone oracle runs opcode for opcode; the two forms agree on EVERY stream."""
+    import stream_batch
+    S, F = 14336, 2
+    t, s = device_tables.get(1)
+    fm, fa = stream_batch.synth_frames_torch(S, F, True, seed=2025)
+    seeds = [(i + 1, 3 * i + 7) for i in range(S)]
+    sample = sorted({0, 1, 7, 8, 63, 4095, 4096, 4097, 7167, 7168, 8191, 8192, 12287, 12288, S // 2 + 1, S - 2, S - 1})
+    tm, ta = fm[sample].cpu().numpy(), fa[sample].cpu().numpy()
+    for fourth in (False, True):
+        res = {}
+        for kern in ("plain", "shared"):
+            b = stream_batch.StreamBatch(1, t, s, S, seeds=seeds, dm=device_tables.dm[(1, 5)], fourth_offset=fourth)
+            b.enc.set_greedy_kernel(kern)
+            ops, segs = b.encode_frames(fm, fa, F)
+            b.enc.check()
+            res[kern] = ops.cpu().numpy()
+            b.close()
+        assert np.array_equal(res["plain"], res["shared"]), fourth
+        for j, i in enumerate(sample):
+            v = O.Video(1, oracle_tables.get(1), seed_py=seeds[i][0], seed_np=seeds[i][1])
+            v.set_fourth_offset(fourth)
+            exp = []
+            for (f, ia, restart, n) in segs:
+                if restart:
+                    v.encode_frame(tm[j, f], ta[j, f], ia)
+                exp.append(v.next(n))
+            assert np.array_equal(res["shared"][i], np.concatenate(exp)), (fourth, i)

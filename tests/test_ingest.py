@@ -213,3 +213,29 @@ def test_ingest_kernel_on_noise_and_extremes(native, O, mode):
                 assert (main[f] == em).all(), (mode, pal_id, dither, f)
                 if mode == 1:
                     assert (aux[f] == ea).all(), (mode, pal_id, dither, f)
+
+
+@pytest.mark.gpu
+def test_ingest_writes_into_a_batch_slice_asynchronously(native, O):
+    """out=: the conversion writes straight into a (streams, frames, 32, 256) slice of a batch's target frames, several
+    calls back to back on one stream without a host synchronisation in between (the pipeline of bench.py's e2e leg);
+    every frame, holes included, equals the definition -- the buffers start as 0xff, so an unwritten byte shows."""
+    import torch
+    rgb = _test_frames(12, 21)
+    dev = torch.from_numpy(rgb).cuda()
+    for mode in (1, 0):
+        main = torch.full((6, 4, 32, 256), 255, dtype=torch.uint8, device="cuda")
+        aux = torch.full((6, 4, 32, 256), 255, dtype=torch.uint8, device="cuda") if mode == 1 else None
+        for dither, s0 in ((32, 0), (native.DITHER_DIFFUSION, 3)):      # streams 0..2 ordered, 3..5 diffusion
+            native.frames_to_memory_maps(mode, O.PALETTE_RGB[5], dev, dither,
+                                         out=(main[s0:s0 + 3], aux[s0:s0 + 3] if aux is not None else None))
+        torch.cuda.synchronize()
+        m, a = main.cpu().numpy().reshape(24, 32, 256), (aux.cpu().numpy().reshape(24, 32, 256) if aux is not None else None)
+        for i in range(24):
+            dither = 32 if i < 12 else O.DITHER_DIFFUSION
+            em, ea = O.frame_to_memory_map(mode, O.PALETTE_RGB[5], rgb[i % 12], dither)
+            assert (m[i] == em).all(), (mode, i)
+            if mode == 1:
+                assert (a[i] == ea).all(), (mode, i)
+    with pytest.raises(ValueError):
+        native.frames_to_memory_maps(1, O.PALETTE_RGB[5], dev, 0, out=(main[:2], None))
