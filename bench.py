@@ -128,6 +128,8 @@ def parse_args(argv=None):
     ap.add_argument("--greedy", choices=["auto", "wave", "workgroup", "shared", "plain"], default="auto",
                     help="greedy kernel shape: one wave per stream, one 256-thread workgroup per stream, or auto")
     ap.add_argument("--full-sort", action="store_true", help="disable the prologue's prefix sort")
+    ap.add_argument("--no-stream-order", action="store_true",
+                    help="A/B: launch the streams in index order instead of longest first (IIV_OPT_STREAM_ORDER 0; same bytes)")
     ap.add_argument("--lds-pad", type=int, default=-1, help="tuning: extra LDS bytes per greedy wave (caps streams per CU)")
     ap.add_argument("--emit", action="store_true",
                     help="(default unless --no-extras) also time encode -> .a2m byte emission -> pinned host "
@@ -324,6 +326,8 @@ class GpuBackend:
         b.enc.set_greedy_kernel({"auto": None, "wave": True, "workgroup": False}.get(a.greedy, a.greedy))
         if a.full_sort:
             b.enc.set_prefix_sort(False)
+        if getattr(a, "no_stream_order", False):
+            b.enc.set_stream_order(False)
         if a.lds_pad >= 0:
             b.enc.set_greedy_lds_pad(a.lds_pad)
         self.batch = b

@@ -43,6 +43,11 @@ constexpr unsigned kTieHeavyPercent = 30;
 // overhead that a launch of a few dozen real opcodes per stream does not repay)
 constexpr unsigned kSharedMinOpsPerLaunch = 96;
 constexpr int kTeamMaxStreams = 768;   // IIV_GREEDY_AUTO: at most this many streams run the team kernel
+// Longest first (iiv_stream.h: GreedyArgs::perm): batches of at least this many streams run their one-wave launches in the
+// order of what the streams' latest launches cost, re-sorted every kOrderEvery greedy launches (a stream's cost follows its
+// content, which changes slowly; the sort is one 1024-thread workgroup, ~10 us)
+constexpr int kOrderMinStreams = 2048;
+constexpr int kOrderEvery = 4;
 
 
 // ------------------------------------------------------------------------- host object
@@ -102,6 +107,11 @@ struct Encoder {
     double ms[2];
     int64_t launches[2];
     int64_t form_launches[4];   // greedy launches since profiling was switched on: one-wave plain / LDS-shared, team, workgroup
+    // longest-first launch order of the one-wave kernel: what every stream's latest launch cost, the permutation in use
+    uint32_t *d_cost;
+    int *d_perm;
+    int order_countdown;        // greedy launches until the next re-sort
+    int order_streams;          // IIV_OPT_STREAM_ORDER: 1 (default) / 0
 };
 
 static void seed_by_array(uint32_t mt[624], const uint32_t *key, int n)
@@ -174,6 +184,51 @@ static int materialise_up(Encoder *e, int s0, int n)
     return rc ? rc : hip_check(hipDeviceSynchronize(), "materialise_up sync");
 }
 
+// perm = the streams by descending cost (a counting sort over 1024 cost classes between the batch's cheapest and dearest
+// stream; the order inside a class is whatever the atomics give -- any permutation is correct, a better one is faster).
+// identity != 0: perm[i] = i.
+__global__ __launch_bounds__(1024) void order_streams_kernel(const uint32_t *__restrict__ cost, int n, int *__restrict__ perm, int identity)
+{
+    __shared__ uint32_t lo_s, hi_s;
+    __shared__ uint32_t count[1024], start[1024];
+    const int tid = threadIdx.x;
+    if (identity) {
+        for (int i = tid; i < n; i += 1024) perm[i] = i;
+        return;
+    }
+    if (tid == 0) lo_s = 0xffffffffu, hi_s = 0u;
+    count[tid] = 0;
+    __syncthreads();
+    uint32_t lo = 0xffffffffu, hi = 0u;
+    for (int i = tid; i < n; i += 1024) {
+        const uint32_t c = cost[i];
+        lo = c < lo ? c : lo;
+        hi = c > hi ? c : hi;
+    }
+    atomicMin(&lo_s, lo);
+    atomicMax(&hi_s, hi);
+    __syncthreads();
+    lo = lo_s, hi = hi_s;
+    const unsigned long long span = (unsigned long long)(hi - lo) + 1ull;
+    auto cls = [&](uint32_t c) -> int { return (int)(((unsigned long long)(hi - c) * 1024ull) / span); };   // 0 = the dearest
+    for (int i = tid; i < n; i += 1024) atomicAdd(&count[cls(cost[i])], 1u);
+    __syncthreads();
+    // exclusive prefix sum over the 1024 classes (one per thread: a plain two-level scan)
+    __shared__ uint32_t wave_tot[16];
+    uint32_t v = count[tid], incl = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+        if ((tid & 63) >= d) incl += o;
+    }
+    if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < (tid >> 6); w++) base += wave_tot[w];
+    start[tid] = base + incl - v;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) perm[atomicAdd(&start[cls(cost[i])], 1u)] = i;
+}
+
 __global__ __launch_bounds__(256) void max_u16_kernel(const uint16_t *__restrict__ v, size_t n, uint32_t *__restrict__ result)
 {
     uint32_t mx = 0;
@@ -196,6 +251,8 @@ void encoder_destroy(Encoder *e)
     if (e->h_tie_stats) (void)hipHostFree(e->h_tie_stats);
     if (e->tie_ev) (void)hipEventDestroy(e->tie_ev);
     if (e->d_result) (void)hipFree(e->d_result);
+    if (e->d_cost) (void)hipFree(e->d_cost);
+    if (e->d_perm) (void)hipFree(e->d_perm);
     if (e->d_packed) (void)hipFree(e->d_packed);
     if (e->d_states) (void)hipFree(e->d_states);
     if (e->d_snapshot) (void)hipFree(e->d_snapshot);
@@ -278,11 +335,20 @@ int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, c
     e->ms[0] = e->ms[1] = 0;
     e->launches[0] = e->launches[1] = 0;
     e->form_launches[0] = e->form_launches[1] = e->form_launches[2] = e->form_launches[3] = 0;
+    e->d_cost = nullptr;
+    e->d_perm = nullptr;
+    e->order_countdown = 2;     // (the first launches have no history: two of them, then the first sort)
+    e->order_streams = 1;
     uint32_t *d_rng0 = nullptr;
     int rc = IIV_OK;
     do {
         if ((rc = hip_check(hipMalloc(&e->d_states, sizeof(StreamState) * (size_t)n_streams), "hipMalloc(stream states)"))) break;
         if ((rc = hip_check(hipMalloc(&e->d_result, 2 * sizeof(int)), "hipMalloc(result)"))) break;
+        if (n_streams >= kOrderMinStreams) {
+            if ((rc = hip_check(hipMalloc(&e->d_cost, sizeof(uint32_t) * (size_t)n_streams), "hipMalloc(stream costs)"))) break;
+            if ((rc = hip_check(hipMemset(e->d_cost, 0, sizeof(uint32_t) * (size_t)n_streams), "memset"))) break;
+            if ((rc = hip_check(hipMalloc(&e->d_perm, sizeof(int) * (size_t)n_streams), "hipMalloc(stream order)"))) break;
+        }
         if ((rc = hip_check(hipMalloc(&e->d_packed, 4096 * 8), "hipMalloc(packed)"))) break;
         if ((rc = hip_check(hipEventCreateWithFlags(&e->seg_ev[0], hipEventDisableTiming), "event"))) break;
         if ((rc = hip_check(hipEventCreateWithFlags(&e->seg_ev[1], hipEventDisableTiming), "event"))) break;
@@ -320,6 +386,7 @@ int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, c
         seed_genrand(rng0 + 624, 0);
         if ((rc = hip_check(hipMalloc(&d_rng0, sizeof(rng0)), "hipMalloc(rng0)"))) break;
         if ((rc = hip_check(hipMemcpy(d_rng0, rng0, sizeof(rng0), hipMemcpyHostToDevice), "copy rng0"))) break;
+        if (e->d_perm) hipLaunchKernelGGL(order_streams_kernel, dim3(1), dim3(1024), 0, 0, e->d_cost, n_streams, e->d_perm, 1);
         hipLaunchKernelGGL(init_states_kernel, dim3(n_streams), dim3(256), 0, 0, e->d_states, d_rng0);
         if ((rc = hip_check(hipGetLastError(), "init_states launch"))) break;
         rc = hip_check(hipDeviceSynchronize(), "init sync");
@@ -418,6 +485,11 @@ int encoder_set_option(Encoder *e, int option, int value)
         if (value && e->content_choice == IIV_CONTENT_JOINT)
             return set_error(IIV_ERR_INVALID, "the joint content choice and the fourth offset are not implemented together");
         e->fourth_offset = value;
+        return IIV_OK;
+    }
+    if (option == IIV_OPT_STREAM_ORDER) {
+        if (value != 0 && value != 1) return set_error(IIV_ERR_INVALID, "bad value");
+        e->order_streams = value;
         return IIV_OK;
     }
     return set_error(IIV_ERR_INVALID, "unknown option %d", option);
@@ -878,6 +950,15 @@ static int launch_round(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux,
     const bool use_team = use_wave && (e->greedy_mode == IIV_GREEDY_TEAM ||
                                        (e->greedy_mode == IIV_GREEDY_AUTO && e->n_streams <= kTeamMaxStreams));
     if (use_wave) {
+        // longest first: every kOrderEvery launches the streams are sorted by what their latest launch cost them (d_perm holds
+        // the identity until the first sort)
+        const bool ordered = e->d_perm && e->order_streams && !use_team;
+        if (ordered && --e->order_countdown <= 0) {
+            hipLaunchKernelGGL(order_streams_kernel, dim3(1), dim3(1024), 0, st, e->d_cost, e->n_streams, e->d_perm, 0);
+            int orc = hip_check(hipGetLastError(), "order_streams_kernel launch");
+            if (orc) return orc;
+            e->order_countdown = kOrderEvery;
+        }
         GreedyArgs a{e->d_states, d_main, d_aux, n_frames, e->n_streams, d_round, seg_stride, e->d_left, e->d_right, e->nt, d_ops,
                      ops_stride, e->greedy_lds_pad,
                      e->greedy_mode == IIV_GREEDY_WAVE_PLAIN ? -1 : uniform_bank,
@@ -885,7 +966,8 @@ static int launch_round(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux,
                      // kernels have reported input on which the plain form is the faster one (kTieHeavyPercent; until they
                      // have reported: HGR shared, DHGR plain -- the better guess for each)
                      shared_form_now(e),
-                     d_queue, e->fourth_offset != 0, e->d_tie_stats != nullptr && tie_stats_wanted(e)};
+                     d_queue, e->fourth_offset != 0, e->d_tie_stats != nullptr && tie_stats_wanted(e),
+                     ordered ? e->d_perm : (const int *)nullptr, ordered ? e->d_cost : (uint32_t *)nullptr};
         int form = 0;   // what launch_greedy_wave ran: 0 plain, 1 LDS-shared (it needs one bank per round and the stream counter)
         int rc = use_team ? launch_greedy_team(e->mode, a, st) : launch_greedy_wave(e->mode, a, st, &form);
         if (rc) return rc;

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
                                                                    const LaunchSeg *__restrict__ segs, int seg_stride,
                                                                    const NarrowTables nt,
                                                                    uint8_t *__restrict__ ops_out, size_t ops_stride, int n_streams, int bank, int *__restrict__ queue,
-                                                                   int count_stats)
+                                                                   int count_stats, const int *__restrict__ perm, uint32_t *__restrict__ cost)
 {
     using T = SplitTraits<MODE>;
     constexpr uint32_t INF = 0xffffffffu;
@@ -141,6 +141,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
     // W streams ends, and a launch's last round would run partly empty (streams differ by +-20 % in how long a
     // launch takes them; measured with s_memrealtime stamps: 13 of 16-20 wave slots per CU busy on average).
     auto run_stream = [&](const int stream, const int lane) {
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
     StreamState &S = states[stream];
     const LaunchSeg g = segs[(size_t)stream * seg_stride];
     const int n_ops = IIV_SGPR(g.n_ops), is_aux = IIV_SGPR(g.is_aux), frame = IIV_SGPR(g.frame);
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
     // (nzw, pdw: this lane's words of the page's two bitmaps, read by the caller as early as the previous step's updates allow --
     // the step's first decision hangs on them, and an LDS round trip at its start is a stall at raised priority)
     auto step = [&](auto track, uint32_t e, const Loaded &L, uint32_t nzw, uint32_t pdw) -> bool {
-        const int p = (e >> 8) & 31, x = e & 255;
+        const int x = e & 255;
         const uint32_t c = (e >> 16) & 0xffu;  // video.py:134
         const uint32_t xword = (uint32_t)__builtin_amdgcn_readlane((int)nzw, (x >> 5) * 8);
         if (__builtin_expect(!((xword >> (x & 31)) & 1u), 0)) return false;
@@ -443,8 +444,8 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
         const int k1 = a0 < a1 ? a0 : a1, hi01 = a0 < a1 ? a1 : a0, mb = b0 < b1 ? b0 : b1;
         const int k2 = hi01 < mb ? hi01 : mb;
         const int k3 = hi01 < mb ? mb : hi01;   // (FOUR: the lane's third smallest)
-        auto nd_in = [](int K) -> uint32_t { return ((uint32_t)K >> 8) & 0x7ffu; };   // the store value inside a fast-path key
-        // (the exact path's keys have no room for it: there it is read out of the lanes, packed in pairs)
+        // (a fast-path key carries its byte's store value in bits 8..18; the exact path's keys have no room for it: there it is
+        // read out of the lanes, packed in pairs)
         auto nd_of = [&](int y) -> uint32_t {
             const uint32_t nd01 = nd[0] | (nd[1] << 16), nd23 = nd[2] | (nd[3] << 16);
             const uint32_t pa = (uint32_t)__builtin_amdgcn_readlane((int)nd01, y >> 2);
@@ -522,23 +523,21 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
                 const uint32_t k = ((uint32_t)((ke[r] >> kWdDwShift) + 2048) << 16) | (nonce << 8) | (y0 + r);
                 key[r] = ke[r] < 0 ? (int)k : kNone;  // video.py:159
             }
-            // the two smallest (delta, nonce, offset): in the lane, then two fused-DPP wave minima as in the fast path
+            // the two smallest (delta, nonce, offset): in the lane, then the one-pass fused-DPP top-2 of the fast path
             // (keys are unique -- they end in the offset)
             const int ta0 = key[0] < key[1] ? key[0] : key[1], tb0 = key[0] < key[1] ? key[1] : key[0];
             const int ta1 = key[2] < key[3] ? key[2] : key[3], tb1 = key[2] < key[3] ? key[3] : key[2];
             const int t1 = ta0 < ta1 ? ta0 : ta1;
             const int thi = ta0 < ta1 ? ta1 : ta0, tmb = tb0 < tb1 ? tb0 : tb1;
             const int t2 = thi < tmb ? thi : tmb;
-            const int T1 = wave_min_i32(t1);
-            const bool thit1 = t1 == T1;
-            const int tc1 = thit1 ? t2 : t1;
-            const int T2 = wave_min_i32(tc1);
+            int T1 = t1, T2 = t2;
+            wave_top2_i32(T1, T2);   // (kNone in many lanes: a value nobody asks about, see iiv_wave.h)
             W1 = T1 != kNone ? (nd_of(T1 & 255) << 8) | (uint32_t)(T1 & 255) : (uint32_t)x;
             W2 = T2 != kNone ? (nd_of(T2 & 255) << 8) | (uint32_t)(T2 & 255) : (uint32_t)x;
             prev_tie = T2 != kNone && (T1 >> 16) == (T2 >> 16);   // (a prediction only: either path is exact)
             if constexpr (FOUR) {
                 const int t3 = thi < tmb ? tmb : thi;
-                const int T3 = wave_min_i32(tc1 == T2 ? (thit1 ? t3 : t2) : tc1);
+                const int T3 = wave_min_i32(t1 > T2 ? t1 : (t2 > T2 ? t2 : t3));   // every lane's smallest key above T2
                 W3 = T3 != kNone ? (nd_of(T3 & 255) << 8) | (uint32_t)(T3 & 255) : (uint32_t)x;
                 prev_tie = prev_tie || (T3 != kNone && (T2 >> 16) == (T3 >> 16));
             }
@@ -810,6 +809,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
         S.ops += (unsigned long long)done;
         S.pad_ops += pad_ops;
         if (err && S.error == 0) S.error = err;
+        if (cost) cost[stream] = (uint32_t)(__builtin_amdgcn_s_memtime() - clk0);   // what this launch took this stream: the next launches' order (GreedyArgs::perm)
         if (count_stats) {   // (per stream, beside its other counters: 14336 x 3 atomics on one address per launch cost 7 % of it)
             S.stat_exact += (unsigned long long)n_exact;
             S.stat_ops += (unsigned long long)(done - (int)pad_ops);
@@ -831,13 +831,14 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
     };   // run_stream
 
     if constexpr (W == 1) {
-        run_stream((int)blockIdx.x, lane0);
+        run_stream(perm ? IIV_SGPR(perm[blockIdx.x]) : (int)blockIdx.x, lane0);
     } else {
         for (;;) {
             int next = 0;
             if (lane0 == 0) next = atomicAdd(queue, 1);
             next = IIV_SGPR(next);
             if (next >= n_streams) break;
+            if (perm) next = IIV_SGPR(perm[next]);
             // (the lane index is laundered per stream: values derived from it would otherwise be hoisted out of this
             // loop and held in registers across it -- 96 VGPRs instead of 78)
             int lane_i = lane0;
@@ -879,7 +880,7 @@ template <int MODE, bool FOUR> static int launch_shared(const GreedyArgs &a, hip
     }
     const int wgs = (a.n_streams + SC::kW - 1) / SC::kW;
     hipLaunchKernelGGL((greedy_wave_kernel<MODE, SC::kW, FOUR>), dim3(wgs < resident ? wgs : resident), dim3(64 * SC::kW), (size_t)SC::kLds, st, a.states,
-                       a.frames_main, a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, a.queue, a.count_stats ? 1 : 0);
+                       a.frames_main, a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, a.queue, a.count_stats ? 1 : 0, a.perm, a.cost);
     return IIV_OK;
 }
 
@@ -893,18 +894,18 @@ int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st, int *form_
         rc = mode == kDHGR ? launch_shared<kDHGR, true>(a, st) : launch_shared<kHGR, true>(a, st);
     else if (a.fourth && mode == kDHGR)   // (f4: a real fourth offset per opcode -- the plain one-wave form only)
         hipLaunchKernelGGL((greedy_wave_kernel<kDHGR, 1, true>), dim3(a.n_streams), dim3(64), (size_t)a.lds_pad, st, a.states, a.frames_main,
-                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, (int *)nullptr, a.count_stats ? 1 : 0);
+                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, (int *)nullptr, a.count_stats ? 1 : 0, a.perm, a.cost);
     else if (a.fourth)
         hipLaunchKernelGGL((greedy_wave_kernel<kHGR, 1, true>), dim3(a.n_streams), dim3(64), (size_t)a.lds_pad, st, a.states, a.frames_main,
-                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, (int *)nullptr, a.count_stats ? 1 : 0);
+                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, (int *)nullptr, a.count_stats ? 1 : 0, a.perm, a.cost);
     else if (shared)
         rc = mode == kDHGR ? launch_shared<kDHGR, false>(a, st) : launch_shared<kHGR, false>(a, st);
     else if (mode == kDHGR)
         hipLaunchKernelGGL((greedy_wave_kernel<kDHGR, 1>), dim3(a.n_streams), dim3(64), (size_t)a.lds_pad, st, a.states, a.frames_main,
-                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, (int *)nullptr, a.count_stats ? 1 : 0);
+                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, (int *)nullptr, a.count_stats ? 1 : 0, a.perm, a.cost);
     else
         hipLaunchKernelGGL((greedy_wave_kernel<kHGR, 1>), dim3(a.n_streams), dim3(64), (size_t)a.lds_pad, st, a.states, a.frames_main,
-                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, (int *)nullptr, a.count_stats ? 1 : 0);
+                           a.frames_aux, a.n_frames, a.segs, a.seg_stride, a.nt, a.ops_out, a.ops_stride, a.n_streams, a.uniform_bank, (int *)nullptr, a.count_stats ? 1 : 0, a.perm, a.cost);
     if (rc) return rc;
     return hip_check(hipGetLastError(), "greedy_wave_kernel launch");
 }

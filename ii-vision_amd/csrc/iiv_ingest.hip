@@ -63,28 +63,49 @@ static IngestPalette make_palette(const uint8_t pal[48], int dither)
     return p;
 }
 
-// key of colour c for the pixel (r, g, b): 16 * (distance - the term common to all colours) + c
-__device__ static inline int ingest_key(const IngestPalette &P, int c, int r, int g, int b)
+// The sixteen K_c in vector registers: a VOP3 instruction reads ONE scalar register, so mad(r, A_c, K_c) with both constants
+// in SGPRs costs a v_mov besides -- with K_c in a VGPR a colour is exactly three v_mad_i32_i24 (the compiler otherwise
+// builds it from two multiplies, a multiply-add and a three-operand add plus the moves: 4.5 instructions and 2.6 moves)
+struct IngestKv {
+    int k[16];
+};
+__device__ static inline IngestKv ingest_kv(const IngestPalette &P)
 {
-    return __mul24(b, P.c[c]) + (__mul24(g, P.b[c]) + (__mul24(r, P.a[c]) + P.k[c]));   // three v_mad_i32_i24
+    IngestKv v;
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+        v.k[c] = P.k[c];
+        asm volatile("" : "+v"(v.k[c]));
+    }
+    return v;
+}
+
+// key of colour c for the pixel (r, g, b): 16 * (distance - the term common to all colours) + c, as three v_mad_i32_i24
+__device__ static inline int ingest_key(const IngestPalette &P, const IngestKv &kv, int c, int r, int g, int b)
+{
+    int t = __mul24(r, P.a[c]) + kv.k[c];
+    asm("" : "+v"(t));   // (keeps the chain a chain: the compiler otherwise re-associates it into mad + 2 mul + add3)
+    t = __mul24(g, P.b[c]) + t;
+    asm("" : "+v"(t));
+    return __mul24(b, P.c[c]) + t;
 }
 
 // DHGR: the nearest of the sixteen colours (ties to the lower colour value)
-__device__ static inline int nearest16(const IngestPalette &P, int r, int g, int b)
+__device__ static inline int nearest16(const IngestPalette &P, const IngestKv &kv, int r, int g, int b)
 {
-    int m = ingest_key(P, 0, r, g, b);
+    int m = 0x7fffffff;
 #pragma unroll
-    for (int c = 1; c < 16; c++) m = min(m, ingest_key(P, c, r, g, b));
+    for (int c = 0; c < 16; c++) m = min(m, ingest_key(P, kv, c, r, g, b));
     return m & 15;
 }
 
 // HGR: for both palette bits, (distance term << 2 | pattern) of the nearest of the four colours the bit allows
 // (black 0, violet 3 | blue 6, green 12 | orange 9, white 15; ties to the lower pattern)
-__device__ static inline void nearest4x2(const IngestPalette &P, int r, int g, int b, int &key0, int &key1)
+__device__ static inline void nearest4x2(const IngestPalette &P, const IngestKv &kv, int r, int g, int b, int &key0, int &key1)
 {
-    const int f0 = ingest_key(P, 0, r, g, b) >> 4, f15 = ingest_key(P, 15, r, g, b) >> 4;   // (>> 4: the colour value leaves, f stays exact)
-    const int f3 = ingest_key(P, 3, r, g, b) >> 4, f12 = ingest_key(P, 12, r, g, b) >> 4;
-    const int f6 = ingest_key(P, 6, r, g, b) >> 4, f9 = ingest_key(P, 9, r, g, b) >> 4;
+    const int f0 = ingest_key(P, kv, 0, r, g, b) >> 4, f15 = ingest_key(P, kv, 15, r, g, b) >> 4;   // (>> 4: the colour value leaves, f stays exact)
+    const int f3 = ingest_key(P, kv, 3, r, g, b) >> 4, f12 = ingest_key(P, kv, 12, r, g, b) >> 4;
+    const int f6 = ingest_key(P, kv, 6, r, g, b) >> 4, f9 = ingest_key(P, kv, 9, r, g, b) >> 4;
     const int b0 = f0 * 4, w3 = f15 * 4 + 3;
     key0 = min(min(b0, f3 * 4 + 1), min(f12 * 4 + 2, w3));
     key1 = min(min(b0, f6 * 4 + 1), min(f9 * 4 + 2, w3));
@@ -127,6 +148,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(int n, const uint8_t *__res
     q[10] = w[10] >> sh;
     auto byte_at = [&](int nb) -> int { return (int)((q[nb >> 2] >> (8 * (nb & 3))) & 255u); };
     const int drow = (y & 3) * 4;
+    const IngestKv kv = ingest_kv(P);
     int colour[7], k0[7], k1[7];
 #pragma unroll
     for (int i = 0; i < 7; i++) {
@@ -135,9 +157,9 @@ __global__ __launch_bounds__(256) void ingest_kernel(int n, const uint8_t *__res
         const int gg = min(max(((byte_at(6 * i + 1) + byte_at(6 * i + 4) + 1) >> 1) + d, 0), 255);
         const int b = min(max(((byte_at(6 * i + 2) + byte_at(6 * i + 5) + 1) >> 1) + d, 0), 255);
         if (MODE == kDHGR)
-            colour[i] = nearest16(P, r, gg, b);
+            colour[i] = nearest16(P, kv, r, gg, b);
         else
-            nearest4x2(P, r, gg, b, k0[i], k1[i]);
+            nearest4x2(P, kv, r, gg, b, k0[i], k1[i]);
     }
     const size_t out = f * 8192 + (size_t)(y_to_offset(y) + 2 * g);
     if (MODE == kDHGR) {
@@ -166,88 +188,84 @@ __global__ __launch_bounds__(256) void ingest_kernel(int n, const uint8_t *__res
 
 // dither == IIV_DITHER_DIFFUSION, DHGR: Floyd-Steinberg error diffusion (include/iivision.h), one wave per frame.
 // Step t: lane l is at position u = t - 2 l of its 420-pixel sequence (rows l, l + 64, l + 128, 140 pixels each).
-// All lanes are at pixels of the same parity, so a source load fetches two pixels (12 bytes, three aligned dwords)
-// every other step, two steps ahead of their use.
+// All lanes are at even positions at the same time, so a source load fetches a PAIR of pixels (12 bytes, three aligned
+// dwords; a pair never straddles two rows), and two pairs -- positions u + 4 and u + 6 -- are requested together every
+// fourth step, four steps ahead of their use: a lane walks along its own row (a frame's rows are 840 bytes apart: the 64
+// lanes of a load touch 64 cache lines), and the second pair finds the line the first has just brought in.
 constexpr int kDiffWavesPerBlock = 4;
 __global__ __launch_bounds__(64 * kDiffWavesPerBlock) void ingest_diffusion_dhgr_kernel(int n, const uint8_t *__restrict__ rgb_frames, const IngestPalette P,
                                                                                            uint8_t *__restrict__ main_mem, uint8_t *__restrict__ aux_mem)
 {
-    __shared__ int ring_s[kDiffWavesPerBlock][16][4];   // lane 63's D(j) for lane 0, slot j & 15 (read 13 steps after it is written)
+    __shared__ int ring_s[kDiffWavesPerBlock][16][4];   // lane 63's D for lane 0, slot = its position & 15 (read 13 steps after it is written)
+    __shared__ uint32_t pal_s[16];                       // R | G << 8 | B << 16 of the colour values
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x < 16) pal_s[threadIdx.x] = P.rgb[threadIdx.x];
+    __syncthreads();
     const size_t f = (size_t)blockIdx.x * kDiffWavesPerBlock + wv;
     if (f >= (size_t)n) return;
     int (*ring)[4] = ring_s[wv];
     const uint8_t *frame = rgb_frames + f * (size_t)(192 * 280 * 3);
-    // the palette's RGB in lanes 0..15 of one register: a pixel's chosen colour is looked up with one ds_bpermute
-    const uint32_t pal_v = P.rgb[lane & 15];
-    int u = -2 * lane;          // position in this lane's 420-pixel sequence
-    int k = 0, row = lane;      // pixel and row while 0 <= u < 420
-    int ph = 0, grp = 0;        // k % 7, k / 7
-    int A0 = 0, A1 = 0, A2 = 0;          // 7 e of the pixel to the left (sixteenths)
-    int e1r = 0, e1g = 0, e1b = 0;       // error of the previous pixel of the row, and of the one before
-    int e2r = 0, e2g = 0, e2b = 0;
+    int u = -2 * lane;          // position in this lane's 420-pixel sequence (t - 2 l)
+    int k = 0;                  // pixel of the row while 0 <= u < 420
+    int sh4 = 0;                // 4 * (k % 7): where the pixel's dot quad goes in `dots`
+    size_t outp = f * 8192 + (size_t)y_to_offset(lane);   // where the row's next four bytes (two aux, two main) go
+    int row = lane;
+    int e0r = 0, e0g = 0, e0b = 0;       // error of the previous pixel of the row (0 in front of a row)
+    int hr = 0, hg = 0, hb = 0;          // e(k - 2) + 5 e(k - 1): what the row below gets for pixel k - 1, less the 3 e(k) still to come
     int dr = 0, dg = 0, db = 0;          // D(k) from the row above, received from lane l - 1 at the end of the previous step
     uint32_t dots = 0;
-    // source words of pixels (k, k + 1) for even k, and the pair requested for two steps later
-    auto src_of = [&](int rw, int kk) -> const uint32_t * {
-        return reinterpret_cast<const uint32_t *>(frame + (size_t)rw * 840 + (size_t)kk * 6);
-    };
-    auto clamp_pos = [&](int uu, int &rw, int &kk) {   // (row, pixel) of sequence position uu, clamped into the frame
-        const int v = uu < 0 ? 0 : uu > 418 ? 418 : uu;   // (418: the last pair of the last row -- a load never runs off the frame)
+    // the pixel pair at sequence position uu (even), clamped into the frame -- a load never runs off it
+    auto src_of = [&](int uu) -> const uint32_t * {
+        const int v = uu < 0 ? 0 : uu > 418 ? 418 : uu;
         const int qq = v >= 280 ? 2 : v >= 140 ? 1 : 0;
-        rw = lane + 64 * qq;
-        kk = v - 140 * qq;
+        return reinterpret_cast<const uint32_t *>(frame + (size_t)(lane + 64 * qq) * 840 + (size_t)(v - 140 * qq) * 6);
     };
-    uint32_t c0, c1, c2, n0, n1, n2;
+    const IngestKv kv = ingest_kv(P);
+    uint32_t c[6], nx[6];
     {
-        int rw, kk;
-        clamp_pos(u & ~1, rw, kk);
-        const uint32_t *p = src_of(rw, kk);
-        c0 = p[0], c1 = p[1], c2 = p[2];
-        clamp_pos((u & ~1) + 2, rw, kk);
-        p = src_of(rw, kk);
-        n0 = p[0], n1 = p[1], n2 = p[2];
+        const uint32_t *p0 = src_of(u), *p1 = src_of(u + 2), *p2 = src_of(u + 4), *p3 = src_of(u + 6);
+#pragma unroll
+        for (int i = 0; i < 3; i++) c[i] = p0[i], c[3 + i] = p1[i], nx[i] = p2[i], nx[3 + i] = p3[i];
     }
-    // one pixel step; (s0, s1): the source bytes r0 g0 b0 r1 g1 b1 of this pixel as two words (low 48 bits used).
-    // Branch-free: every lane computes (inactive lanes on clamped source bytes, results discarded) -- the palette lookup is a
-    // ds_bpermute, which reads 0 from lanes that are switched off, and lanes 0..15 hold the palette.
+    // one pixel step; (s0, s1): the source bytes r0 g0 b0 r1 | g1 b1 . . of this pixel
     auto step = [&](uint32_t s0, uint32_t s1) {
         const bool active = u >= 0 && u < 420;
-        const bool flush = u == 420;            // one step behind the last pixel: D(139) of the last row still leaves
-        int ir = dr, ig = dg, ib = db;          // from the row above
-        if (lane == 0) {
-            // rows 64 and 128: what lane 63 emitted 140 positions earlier; row 0: nothing above
-            const int *slot = ring[(u - 140) & 15];
-            const bool has = u >= 140;
-            ir = has ? slot[0] : 0, ig = has ? slot[1] : 0, ib = has ? slot[2] : 0;
-        }
-        const int mr = (int)((s0 & 255u) + ((s0 >> 24) & 255u) + 1u) >> 1;
-        const int mg = (int)(((s0 >> 8) & 255u) + (s1 & 255u) + 1u) >> 1;
-        const int mb = (int)(((s0 >> 16) & 255u) + ((s1 >> 8) & 255u) + 1u) >> 1;
-        const int r = min(max(mr + ((A0 + ir) >> 4), 0), 255);   // (>> 4 of a negative int: floor)
-        const int g = min(max(mg + ((A1 + ig) >> 4), 0), 255);
-        const int b = min(max(mb + ((A2 + ib) >> 4), 0), 255);
-        const int col = nearest16(P, r, g, b);
-        const uint32_t prgb = (uint32_t)__builtin_amdgcn_ds_bpermute(col << 2, (int)pal_v);
-        const int er = active ? r - (int)(prgb & 255u) : 0;
-        const int eg = active ? g - (int)((prgb >> 8) & 255u) : 0;
-        const int eb = active ? b - (int)((prgb >> 16) & 255u) : 0;
+        int er = 0, eg = 0, eb = 0;
+        const bool first = k == 0;      // (also at the flush step u == 420: k was reset behind the last row)
         if (active) {
-            dots |= (uint32_t)col << (4 * ph);
-            if (ph == 6) {
-                const size_t out = f * 8192 + (size_t)(y_to_offset(row) + 2 * grp);
+            int ir = dr, ig = dg, ib = db;          // from the row above
+            if (lane == 0) {
+                // rows 64 and 128: what lane 63 emitted 140 positions earlier; row 0: nothing above
+                const int *slot = ring[(u - 140) & 15];
+                const bool has = u >= 140;
+                ir = has ? slot[0] : 0, ig = has ? slot[1] : 0, ib = has ? slot[2] : 0;
+            }
+            // mean of the two source pixels, three channels at once: v_lerp_u8 = per byte (a + b + 1) >> 1
+            const uint32_t m = __builtin_amdgcn_lerp(s0, __builtin_amdgcn_alignbit(s1, s0, 24), 0x01010101u);
+            // value = clamp(mean + floor((7 e(k - 1) + D) / 16))    (>> 4 of a negative int: floor)
+            const int r = min(max((int)(m & 255u) + ((7 * e0r + ir) >> 4), 0), 255);
+            const int g = min(max((int)((m >> 8) & 255u) + ((7 * e0g + ig) >> 4), 0), 255);
+            const int b = min(max((int)((m >> 16) & 255u) + ((7 * e0b + ib) >> 4), 0), 255);
+            const int col = nearest16(P, kv, r, g, b);
+            const uint32_t prgb = pal_s[col];
+            er = r - (int)(prgb & 255u);
+            eg = g - (int)((prgb >> 8) & 255u);
+            eb = b - (int)((prgb >> 16) & 255u);
+            dots |= (uint32_t)col << sh4;
+            sh4 += 4;
+            if (sh4 == 28) {
                 const uint32_t b0 = dots & 0x7fu, b1 = (dots >> 7) & 0x7fu, b2 = (dots >> 14) & 0x7fu, b3 = (dots >> 21) & 0x7fu;
-                *reinterpret_cast<uint16_t *>(aux_mem + out) = (uint16_t)(b0 | (b2 << 8));
-                *reinterpret_cast<uint16_t *>(main_mem + out) = (uint16_t)(b1 | (b3 << 8));
+                *reinterpret_cast<uint16_t *>(aux_mem + outp) = (uint16_t)(b0 | (b2 << 8));
+                *reinterpret_cast<uint16_t *>(main_mem + outp) = (uint16_t)(b1 | (b3 << 8));
+                outp += 2;
                 dots = 0;
+                sh4 = 0;
             }
         }
         // what the row below receives for its pixel j = k - 1 (j = 139 of the row just finished when k == 0 or at the flush):
         // D(j) = e(j - 1) + 5 e(j) + 3 e(j + 1), the last term absent behind the end of the row
-        const bool first = k == 0;
-        const int t3r = first ? 0 : 3 * er, t3g = first ? 0 : 3 * eg, t3b = first ? 0 : 3 * eb;   // (er = 0 at the flush: not active)
-        const int outr = e2r + 5 * e1r + t3r, outg = e2g + 5 * e1g + t3g, outb = e2b + 5 * e1b + t3b;
-        if (lane == 63 && ((active && u >= 1) || flush)) {
+        const int outr = first ? hr : hr + 3 * er, outg = first ? hg : hg + 3 * eg, outb = first ? hb : hb + 3 * eb;
+        if (lane == 63 && u >= 1 && u <= 420) {
             // (slot = position of the emitted D in lane 63's sequence, u - 1: lane 0 reads it 13 steps later as its position - 140)
             int *slot = ring[(u - 1) & 15];
             slot[0] = outr, slot[1] = outg, slot[2] = outb;
@@ -259,29 +277,29 @@ __global__ __launch_bounds__(64 * kDiffWavesPerBlock) void ingest_diffusion_dhgr
         db = __builtin_amdgcn_update_dpp(0, outb, 0x138, 0xf, 0xf, false);
         if (active) {
             // the row's own history: at the first pixel of a row the previous row's errors have just left (above)
-            e2r = first ? 0 : e1r, e2g = first ? 0 : e1g, e2b = first ? 0 : e1b;
-            e1r = er, e1g = eg, e1b = eb;
-            A0 = 7 * er, A1 = 7 * eg, A2 = 7 * eb;
-            k++;
-            if (++ph == 7) ph = 0, grp++;
-            if (k == 140) {
-                k = 0, ph = 0, grp = 0;
+            hr = (first ? 0 : e0r) + 5 * er, hg = (first ? 0 : e0g) + 5 * eg, hb = (first ? 0 : e0b) + 5 * eb;
+            e0r = er, e0g = eg, e0b = eb;
+            if (++k == 140) {
+                k = 0;
                 row += 64;
-                A0 = A1 = A2 = 0;
+                outp = f * 8192 + (size_t)y_to_offset(row < 192 ? row : 191);
+                e0r = e0g = e0b = 0;      // (nothing comes from the left at the start of a row)
             }
         }
         u++;
     };
     // 420 pixels + 126 steps of skew + the flush step of lane 63: u of lane 63 reaches 420 at t = 546
-    for (int t = 0; t < 548; t += 2) {
-        // (u is even here for every lane: t and 2 l are)
-        step(c0, c1);
-        step((c1 >> 16) | (c2 << 16), c2 >> 16);
-        c0 = n0, c1 = n1, c2 = n2;
-        int rw, kk;
-        clamp_pos(u + 2, rw, kk);
-        const uint32_t *p = src_of(rw, kk);
-        n0 = p[0], n1 = p[1], n2 = p[2];
+    for (int t = 0; t < 548; t += 4) {
+        // (u = t - 2 l is even here for every lane; c holds the pairs of positions u and u + 2)
+        step(c[0], c[1]);
+        step((c[1] >> 16) | (c[2] << 16), c[2] >> 16);
+        step(c[3], c[4]);
+        step((c[4] >> 16) | (c[5] << 16), c[5] >> 16);
+#pragma unroll
+        for (int i = 0; i < 6; i++) c[i] = nx[i];
+        const uint32_t *p2 = src_of(u + 4), *p3 = src_of(u + 6);
+#pragma unroll
+        for (int i = 0; i < 3; i++) nx[i] = p2[i], nx[3 + i] = p3[i];
     }
 }
 

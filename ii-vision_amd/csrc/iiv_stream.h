@@ -357,6 +357,13 @@ struct GreedyArgs {
     int *queue;              // device: this launch's stream counter, zero (the LDS-shared form's persistent workgroups)
     bool fourth;             // IIV_OPT_FOURTH_OFFSET: up to three extra offsets per opcode (the plain one-wave kernel only)
     bool count_stats;        // the one-wave kernel adds to the streams' stat_* fields
+    // Longest first (round 5): streams differ by up to 2x in how long a launch takes them (picture-like input), and a launch
+    // ends when its slowest stream does -- in its last fifth a third (S-iid) to three quarters (S-img) of the wave slots idle.
+    // The one-wave kernel writes every stream's shader clocks of this launch to cost[stream]; the encoder sorts the streams
+    // by that, descending, every few launches (iiv_encode.hip: order_streams_kernel), and workgroup / queue position i runs
+    // stream perm[i].  Streams are independent: the order changes no byte.  Either may be NULL.
+    const int *perm;
+    uint32_t *cost;
 };
 
 int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st, int *form_out = nullptr);   // iiv_greedy.hip; *form_out: 0 plain form launched, 1 LDS-shared

@@ -28,6 +28,7 @@ OPT_PREFIX_SORT = 3
 OPT_GREEDY_LDS_PAD = 5
 OPT_CONTENT_CHOICE, CONTENT_TARGET, CONTENT_JOINT = 6, 0, 1
 OPT_FOURTH_OFFSET = 7
+OPT_STREAM_ORDER = 8
 
 # every symbol include/iivision.h declares
 SYMBOLS = [
@@ -446,6 +447,10 @@ class Encoder:
         else:
             v = GREEDY_WAVE if wave_per_stream else GREEDY_WORKGROUP
         check(lib().iiv_encoder_set_option(self._h, OPT_GREEDY_KERNEL, v))
+
+    def set_stream_order(self, enable):
+        """True (default): big batches launch the one-wave kernel longest stream first (IIV_OPT_STREAM_ORDER); same bytes."""
+        check(lib().iiv_encoder_set_option(self._h, OPT_STREAM_ORDER, 1 if enable else 0))
 
     def set_prefix_sort(self, enable):
         check(lib().iiv_encoder_set_option(self._h, OPT_PREFIX_SORT, 1 if enable else 0))

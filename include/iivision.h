@@ -246,6 +246,12 @@ void iiv_encoder_destroy(iiv_encoder *enc);
                                   * literal changed (tests/golden/g8_fourth_offset.npz).  Runs in the one-wave greedy kernel (both
                                   * forms) and, for few streams, the eight-wave one (IIV_GREEDY_WORKGROUP falls back to the
                                   * one-wave kernel; needs dm at creation); not together with IIV_CONTENT_JOINT. */
+#define IIV_OPT_STREAM_ORDER 8   /* 1 (default) / 0: batches of 2048 streams and more launch the one-wave greedy kernel longest
+                                  * stream first -- every stream's shader clocks of a launch are recorded, and every fourth
+                                  * launch the streams are sorted by them (a launch ends when its slowest stream does: on
+                                  * picture-like input streams differ by 2x and the tail of a launch runs three quarters
+                                  * empty).  Streams are independent (movie.py:16-54: one Movie per process in the reference):
+                                  * the order they are processed in changes no byte of any stream's output. */
 int iiv_encoder_set_option(iiv_encoder *enc, int option, int value);
 
 /* The mode and stream count an encoder was created with (what a caller's frame / output buffers must be sized for:

@@ -276,3 +276,30 @@ def test_bench_batch_size_sampled_against_the_oracle(native, O, oracle_tables, d
                     v.encode_frame(tm[j, f], ta[j, f], ia)
                 exp.append(v.next(n))
             assert np.array_equal(res["shared"][i], np.concatenate(exp)), (fourth, i)
+
+
+@pytest.mark.parametrize("kern", ["plain", "shared"])
+def test_longest_first_launch_order_changes_no_byte(native, device_tables, kern):
+    """IIV_OPT_STREAM_ORDER: from 2048 streams on the one-wave kernel launches its streams in the order of what their
+    latest launches cost (re-sorted every fourth launch).  Streams are independent: five Movie-paced frames (13
+    generators, three re-sorts) of 2304 picture-like clips -- whose costs differ by 2x -- give the same opcodes, screens
+    and RNG positions with the ordering on and off."""
+    import stream_batch
+    S, F = 2304, 5
+    t, s = device_tables.get(1)
+    fm, fa = stream_batch.synth_frames_img(S, F, True, seed=77)
+    seeds = [(i + 3, i + 5) for i in range(S)]
+    res = {}
+    for order in (True, False):
+        b = stream_batch.StreamBatch(1, t, s, S, seeds=seeds, dm=device_tables.dm[(1, 5)])
+        b.enc.set_greedy_kernel(kern)
+        b.enc.set_stream_order(order)
+        ops, segs = b.encode_frames(fm, fa, F)
+        b.enc.check()
+        res[order] = (ops.cpu().numpy(), [b.enc.get_state(native.STATE_MEM_MAIN, i) for i in (0, 1, S // 2, S - 1)],
+                      [b.enc.get_state(native.STATE_RNG_PY, i) for i in (0, S - 1)])
+        b.close()
+    assert len(segs) >= 10
+    assert np.array_equal(res[True][0], res[False][0])
+    for a, c in zip(res[True][1] + res[True][2], res[False][1] + res[False][2]):
+        assert np.array_equal(a, c)
