@@ -112,7 +112,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip make_data_tables / single-stream (profiling runs)")
     ap.add_argument("--extras", default="all",
                     help="comma list of the extra legs to run beside the timed region (default all): single_stream, emit, "
-                         "make_data_tables, ingest, dropin, hgr, img, fourth_offset -- for iterating on one of them")
+                         "make_data_tables, ingest, dropin, hgr, img, fourth_offset, joint -- for iterating on one of them")
     ap.add_argument("--cpu-frames", type=int, default=600, help="frames of stream 0 the CPU baseline encodes")
     ap.add_argument("--cpu-frames-all", type=int, default=60, help="frames per stream of the all-cores CPU baseline")
     ap.add_argument("--dw", choices=["split", "recurrence", "table"], default="recurrence",
@@ -552,6 +552,8 @@ def _run(args, backend_cls, quiet):
                     out["img"] = _hgr_leg(be, args, local_rank, world, steps=4, mode="DHGR", img=True)
                 if want("fourth_offset"):
                     out["fourth_offset"] = _hgr_leg(be, args, local_rank, world, steps=4, mode="DHGR", fourth=True)
+                if want("joint"):
+                    out["joint"] = _hgr_leg(be, args, local_rank, world, steps=2, warmup=1, mode="DHGR", joint=True, streams=min(be.S, 3072))
 
         quiet.restore()
         print(json.dumps(out))
@@ -754,13 +756,13 @@ def _roofline_objects(be, args, prof, op_count, seg_count, S, elapsed, live_ceil
     return out
 
 
-def _hgr_leg(be, args, local_rank, world, steps=6, warmup=1, mode="HGR", fourth=False, img=False):
+def _hgr_leg(be, args, local_rank, world, steps=6, warmup=1, mode="HGR", fourth=False, img=False, joint=False, streams=None):
     """HGR frames/s (BASELINE config 3's workload) in the default line: the DHGR leg's clips and tables are
     released, HGR tables are built and `steps` x 50 frames of as many HGR S-iid clips are encoded the same way.
     (mode="DHGR", fourth=True: the same short leg for f4's fourth offset per opcode -- not the reference's stream.)"""
     import copy
     import gc
-    S = be.S
+    S = streams or be.S
     for name in ("fm", "fa", "batch", "ops_buf", "last_ops", "table", "store"):
         if name == "batch" and getattr(be, "batch", None) is not None:
             be.batch.close()
@@ -768,7 +770,7 @@ def _hgr_leg(be, args, local_rank, world, steps=6, warmup=1, mode="HGR", fourth=
     gc.collect()
     be.torch.cuda.empty_cache()
     a2 = copy.copy(args)
-    a2.mode, a2.steps, a2.warmup, a2.fourth = mode, steps, warmup, fourth
+    a2.mode, a2.steps, a2.warmup, a2.fourth, a2.joint = mode, steps, warmup, fourth, joint
     a2.img, a2.coherent, a2.static, a2.img_distinct = img, False, False, 2048
     h = GpuBackend(a2, local_rank, world)
     h.build_tables()
@@ -787,7 +789,11 @@ def _hgr_leg(be, args, local_rank, world, steps=6, warmup=1, mode="HGR", fourth=
         share, form = h.input_stats()
         out["nonce_decided_share_of_steps"] = round(share, 4)
         out["greedy_form"] = form
-    if fourth:
+    if joint:
+        out["note"] = ("IIV_CONTENT_JOINT (SURVEY 8 f4, README.md:212-215): every step's content byte chosen jointly with its extra "
+                       "offsets -- 128 x the lookups of a reference step, the 256-thread workgroup kernel; NOT the reference's stream, "
+                       "off by default")
+    elif fourth:
         o = leg["first_ops"][0].cpu().numpy().reshape(-1, 6)[:, 2:6]
         o.sort(axis=1)
         out["distinct_offsets_per_opcode"] = float(((o[:, 1:] != o[:, :-1]).sum(axis=1) + 1).mean())
@@ -1052,7 +1058,9 @@ def _ingest_and_e2e(be, args, resident_fps, emit_fps):
                                   "peak_measured_copy": HBM_MEASURED_COPY_GBS, "over_measured_copy": gbs / HBM_MEASURED_COPY_GBS},
                      "vs_encoder_rate": fps / resident_fps}
 
-    def e2e(dither, overlap):
+    def e2e(dither, overlap, pre=None):
+        """pre: the steps' frames already converted (a list of buffers like bufs[j]) -- the same pipeline WITHOUT the conversion,
+        on the same content: what e2e's rate is to be compared with"""
         rng = np.random.default_rng(0)
         tick_addr = torch.from_numpy(rng.integers(0x4000, 0x7fff, 1024).astype(np.int16)).cuda()
         b = be.sb.StreamBatch(be.mode, be.table, be.store, S, seeds=rank_seeds(0, S), dm=be.dm)
@@ -1071,6 +1079,8 @@ def _ingest_and_e2e(be, args, resident_fps, emit_fps):
 
         def ingest(k):
             j = k & 1
+            if pre is not None:
+                return
             if overlap:
                 with torch.cuda.stream(ingest_stream):
                     ingest_stream.wait_event(encoded[j])
@@ -1081,13 +1091,16 @@ def _ingest_and_e2e(be, args, resident_fps, emit_fps):
 
         def step(k):
             j = k & 1
-            if overlap:
+            src = bufs[j] if pre is None else pre[k % len(pre)]
+            if pre is not None:
+                pass
+            elif overlap:
                 main.wait_event(converted[j])
                 if k + 1 <= K:
                     ingest(k + 1)                                 # the next step's frames, beside this step's encode
             else:
                 ingest(k)
-            view, segs = b.encode_frames(bufs[j][0], bufs[j][1] if be.dhgr else None, F, ops, loop=True)
+            view, segs = b.encode_frames(src[0], src[1] if be.dhgr else None, F, ops, loop=True)
             encoded[j].record()
             n = sum(s_[3] for s_ in segs)
             main.wait_event(done[j])
@@ -1104,7 +1117,7 @@ def _ingest_and_e2e(be, args, resident_fps, emit_fps):
 
         for ev in done + encoded:
             ev.record()
-        if overlap:
+        if overlap and pre is None:
             ingest(0)
         step(0)                                                   # warm-up step (its frames are step 0's)
         torch.cuda.synchronize()
@@ -1125,10 +1138,29 @@ def _ingest_and_e2e(be, args, resident_fps, emit_fps):
     out["e2e"] = e2e(32, True)
     out["e2e"]["what"] = ("RGB -> iiv_frames_to_memory_maps (ordered dither, amplitude 32) -> iiv_encode -> iiv_emit_chunk -> pinned host "
                           "memory; the conversion of step k + 1 runs on a second HIP stream beside the encode of step k; "
-                          "vs_emit compares with the `emit` leg's rate on S-iid memory maps -- different content, same pipeline behind the frames")
+                          "vs_emit compares with the `emit` leg's rate on S-iid memory maps (different content: these frames are "
+                          "picture-like and encode more slowly), vs_emit_same_content with the same pipeline on THESE frames "
+                          "converted beforehand (emit_same_content)")
     out["e2e_diffusion"] = e2e(native.DITHER_DIFFUSION, True)
     out["e2e_serial"] = e2e(32, False)
     out["e2e_serial"]["what"] = "the same with the conversion on the encode's own stream (no overlap)"
+    # the pipeline behind the frames alone, on the same content: the K steps' frames converted beforehand
+    try:
+        pre = []
+        for k in range(K):
+            pre.append([torch.empty((S, F, 32, 256), dtype=torch.uint8, device="cuda") for _ in range(nb)])
+            keep = bufs[0]
+            bufs[0] = pre[k]
+            convert(k, 0, 32)
+            bufs[0] = keep
+        torch.cuda.synchronize()
+        out["emit_same_content"] = e2e(32, False, pre=pre)
+        out["emit_same_content"]["what"] = "iiv_encode -> iiv_emit_chunk -> pinned host memory on the e2e leg's own frames, converted beforehand"
+        out["e2e"]["vs_emit_same_content"] = out["e2e"]["value"] / out["emit_same_content"]["value"]
+        out["e2e_serial"]["vs_emit_same_content"] = out["e2e_serial"]["value"] / out["emit_same_content"]["value"]
+        del pre
+    except Exception as e:   # (e.g. not enough free HBM for the K pre-converted steps)
+        out["emit_same_content"] = {"value": None, "error": repr(e)}
     del rgb, bufs
     gc.collect()
     torch.cuda.empty_cache()

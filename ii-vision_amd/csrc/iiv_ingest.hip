@@ -17,20 +17,16 @@
 //     evaluated twice and no thread exchanges anything; its 42 source bytes are eleven aligned dword loads
 //     and a funnel shift, its output two 16-bit stores.  (It was one thread per screen byte: every DHGR pixel
 //     evaluated 1.75 times, every HGR pixel twice for both palette bits.)
-//   * Error diffusion, DHGR: one WAVE per frame instead of 192 threads and a workgroup barrier per pixel step.
-//     Lane l works on rows l, l + 64, l + 128 one after the other, two pixels behind lane l - 1; what a row
-//     hands to the row below -- D(j) = e(j - 1) + 5 e(j) + 3 e(j + 1), final once pixel j + 1 is done --
-//     moves to the next lane by one wave-wide DPP shift per channel exactly one step before it is needed;
-//     only lane 63 -> lane 0 (row 63 -> 64, 127 -> 128) goes through a 16-slot LDS ring.  No barrier, no LDS
-//     traffic in the step, 547 steps per frame instead of 1 286 barrier rounds.  Integer sums commute, so the
-//     schedule changes nothing: bit for bit the oracle's raster-order definition.
-//     (HGR's diffusion keeps the skewed-wavefront workgroup kernel: its palette-bit look-ahead needs four
-//     pixels' accumulators ahead of the row above.)
+//   * Error diffusion: lanes are rows, three frames of twenty rows per wave, seven pixels apart, instead of 192
+//     threads and a workgroup barrier per pixel step (ingest_diffusion_kernel below): what a row hands to the
+//     row below moves to the next lane by DPP, every lane is at the same phase of the 7-pixel / 2- or 4-byte
+//     period, so HGR's palette-bit decisions and the stores are uniform and phase-indexed state is static.
 //   * No allocation, no synchronisation: the palette's linear forms travel as a kernel argument, the screen
 //     holes are zeroed by a kernel on the same stream.
 #include "iiv_host.h"
 #include "iiv_stream.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace iiv {
 
@@ -186,220 +182,226 @@ __global__ __launch_bounds__(256) void ingest_kernel(int n, const uint8_t *__res
     }
 }
 
-// dither == IIV_DITHER_DIFFUSION, DHGR: Floyd-Steinberg error diffusion (include/iivision.h), one wave per frame.
-// Step t: lane l is at position u = t - 2 l of its 420-pixel sequence (rows l, l + 64, l + 128, 140 pixels each).
-// All lanes are at even positions at the same time, so a source load fetches a PAIR of pixels (12 bytes, three aligned
-// dwords; a pair never straddles two rows), and two pairs -- positions u + 4 and u + 6 -- are requested together every
-// fourth step, four steps ahead of their use: a lane walks along its own row (a frame's rows are 840 bytes apart: the 64
-// lanes of a load touch 64 cache lines), and the second pair finds the line the first has just brought in.
-constexpr int kDiffWavesPerBlock = 4;
-__global__ __launch_bounds__(64 * kDiffWavesPerBlock) void ingest_diffusion_dhgr_kernel(int n, const uint8_t *__restrict__ rgb_frames, const IngestPalette P,
-                                                                                           uint8_t *__restrict__ main_mem, uint8_t *__restrict__ aux_mem)
+// dither == IIV_DITHER_DIFFUSION: Floyd-Steinberg error diffusion (include/iivision.h) without a barrier: lanes are ROWS.
+// A pixel needs the errors of its left neighbour (its own lane, a step ago) and of three pixels of the row above (the lane
+// above, a few steps ago): what a row hands down, D(j) = e(j - 1) + 5 e(j) + 3 e(j + 1), is final once pixel j + 1 is done and
+// moves to the next lane by one wave-wide DPP shift per channel.  Integer sums commute, so the schedule changes nothing: the
+// result is the oracle's raster-order definition bit for bit.
+// HGR adds a screen byte's palette bit, fixed just before the first pixel whose first dot lies in the byte is quantised, from
+// the nearest-colour errors of the three or four pixels that start in the byte -- their values taken with everything the row
+// ABOVE sends them.  So a row must stay five pixels behind the row above, and 63 x 5 pixels of skew do not fit a 140-pixel
+// row: a wave of 64 rows would idle two thirds of the time.  Instead a wave works on THREE frames, twenty rows of each at a
+// time (lane = 20 x frame slot + row in the pass; 4 lanes idle), SEVEN pixels behind the lane above: 19 x 7 = 133 < 140, so a
+// lane goes from row r to row r + 20 without waiting, and -- 7 colour pixels = 14 HGR dots = two screen bytes = 28 DHGR dots =
+// four screen bytes -- every lane is at the same place of the 7-pixel period at every step: the palette-bit decisions (phases
+// 0 and 4) and the rows' stores (phase 6) are uniform control flow, everything indexed by the phase is a static register, a
+// lane's source bytes are one 42-byte group per seven steps.  What the row above hands down arrives five pixels ahead of its
+// use in a seven-slot queue of registers (slot = pixel mod 7); lane 19 of a frame slot -> lane 0 (row 20 q + 19 -> 20 (q + 1))
+// goes through a 16-slot LDS ring.  1 540 steps per three frames.  (Round 3's kernels -- 192 threads per frame on a skewed
+// wavefront, a workgroup barrier per pixel step -- ran 0.19 M HGR frames/s; a first one-wave-per-frame DHGR form of this
+// round, 64 rows two pixels apart with dynamic phases, 2.9 M; this form 5.9 M HGR.)
+constexpr int kDiffWaves = 2;   // waves per block
+template <int MODE>
+__global__ __launch_bounds__(64 * kDiffWaves) void ingest_diffusion_kernel(int n, const uint8_t *__restrict__ rgb_frames, const IngestPalette P,
+                                                                           uint8_t *__restrict__ main_mem, uint8_t *__restrict__ aux_mem)
 {
-    __shared__ int ring_s[kDiffWavesPerBlock][16][4];   // lane 63's D for lane 0, slot = its position & 15 (read 13 steps after it is written)
-    __shared__ uint32_t pal_s[16];                       // R | G << 8 | B << 16 of the colour values
+    __shared__ int ring_s[kDiffWaves][3][16][4];
+    __shared__ uint32_t pal_s[16];    // DHGR: R | G << 8 | B << 16 of the sixteen colour values
+    __shared__ uint32_t rgb_s[8];     // R | G << 8 | B << 16 of colour4[pb][pattern]: black, violet | blue, green | orange, white
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x < 8) {
+        constexpr int colour4[8] = {0, 3, 12, 15, 0, 6, 9, 15};
+        rgb_s[threadIdx.x] = P.rgb[colour4[threadIdx.x]];
+    }
     if (threadIdx.x < 16) pal_s[threadIdx.x] = P.rgb[threadIdx.x];
     __syncthreads();
-    const size_t f = (size_t)blockIdx.x * kDiffWavesPerBlock + wv;
-    if (f >= (size_t)n) return;
-    int (*ring)[4] = ring_s[wv];
-    const uint8_t *frame = rgb_frames + f * (size_t)(192 * 280 * 3);
-    int u = -2 * lane;          // position in this lane's 420-pixel sequence (t - 2 l)
-    int k = 0;                  // pixel of the row while 0 <= u < 420
-    int sh4 = 0;                // 4 * (k % 7): where the pixel's dot quad goes in `dots`
-    size_t outp = f * 8192 + (size_t)y_to_offset(lane);   // where the row's next four bytes (two aux, two main) go
-    int row = lane;
-    int e0r = 0, e0g = 0, e0b = 0;       // error of the previous pixel of the row (0 in front of a row)
-    int hr = 0, hg = 0, hb = 0;          // e(k - 2) + 5 e(k - 1): what the row below gets for pixel k - 1, less the 3 e(k) still to come
-    int dr = 0, dg = 0, db = 0;          // D(k) from the row above, received from lane l - 1 at the end of the previous step
-    uint32_t dots = 0;
-    // the pixel pair at sequence position uu (even), clamped into the frame -- a load never runs off it
-    auto src_of = [&](int uu) -> const uint32_t * {
-        const int v = uu < 0 ? 0 : uu > 418 ? 418 : uu;
-        const int qq = v >= 280 ? 2 : v >= 140 ? 1 : 0;
-        return reinterpret_cast<const uint32_t *>(frame + (size_t)(lane + 64 * qq) * 840 + (size_t)(v - 140 * qq) * 6);
+    const int slot3 = lane / 20, i = lane - 20 * slot3;          // frame slot 0..2 (3: idle lanes 60..63), row in the pass
+    const size_t f = ((size_t)blockIdx.x * kDiffWaves + wv) * 3 + (size_t)(slot3 < 3 ? slot3 : 0);
+    const bool lane_ok = slot3 < 3 && f < (size_t)n;
+    int (*ring)[4] = ring_s[wv][slot3 < 3 ? slot3 : 0];
+    const uint8_t *frame = rgb_frames + (lane_ok ? f : 0) * (size_t)(192 * 280 * 3);
+    const IngestKv kv = MODE == kDHGR ? ingest_kv(P) : IngestKv{};
+    // HGR: the six colours it can show, their K in vector registers (see IngestKv)
+    int kv0 = P.k[0], kv3 = P.k[3], kv12 = P.k[12], kv15 = P.k[15], kv6 = P.k[6], kv9 = P.k[9];
+    asm volatile("" : "+v"(kv0), "+v"(kv3), "+v"(kv12), "+v"(kv15), "+v"(kv6), "+v"(kv9));
+    auto fkey = [&](int c, int kv, int r, int g, int b) -> int {   // 16 * (distance term) + c >> 4 = the distance term itself
+        int t = __mul24(r, P.a[c]) + kv;
+        asm("" : "+v"(t));
+        t = __mul24(g, P.b[c]) + t;
+        asm("" : "+v"(t));
+        return (__mul24(b, P.c[c]) + t) >> 4;
     };
-    const IngestKv kv = ingest_kv(P);
-    uint32_t c[6], nx[6];
-    {
-        const uint32_t *p0 = src_of(u), *p1 = src_of(u + 2), *p2 = src_of(u + 4), *p3 = src_of(u + 6);
+    struct F6 {
+        int f0, f3, f12, f15, f6, f9;
+    };
+    auto f6 = [&](int r, int g, int b) -> F6 {
+        return F6{fkey(0, kv0, r, g, b), fkey(3, kv3, r, g, b), fkey(12, kv12, r, g, b), fkey(15, kv15, r, g, b), fkey(6, kv6, r, g, b), fkey(9, kv9, r, g, b)};
+    };
+    // per-lane sequence: group tt = T - i of this lane's rows (20 groups of 7 pixels per row; rows i, 20 + i, ...)
+    int Dq[7][3];                         // D from the row above for the pixels of the period, slot = pixel mod 7
 #pragma unroll
-        for (int i = 0; i < 3; i++) c[i] = p0[i], c[3 + i] = p1[i], nx[i] = p2[i], nx[3 + i] = p3[i];
-    }
-    // one pixel step; (s0, s1): the source bytes r0 g0 b0 r1 | g1 b1 . . of this pixel
-    auto step = [&](uint32_t s0, uint32_t s1) {
-        const bool active = u >= 0 && u < 420;
+    for (int j = 0; j < 7; j++) Dq[j][0] = Dq[j][1] = Dq[j][2] = 0;
+    int inr = 0, ing = 0, inb = 0;        // what arrived at the end of the previous step: D(pixel + 5)
+    int e0r = 0, e0g = 0, e0b = 0;        // error of the previous pixel of the row (0 in front of a row)
+    int hr = 0, hg = 0, hb = 0;           // e(k - 2) + 5 e(k - 1)
+    uint32_t cur[11], nxt[11];            // the source bytes of the current / next 7-pixel group, funnel-shifted to start at byte 0
+    int pbA = 0, pbB = 0;
+    uint32_t bytesAB = 0;                 // HGR: the two screen bytes of the group, as they fill; DHGR: its 28 dots
+    // source group of sequence position tt (clamped into the frame)
+    auto load_group = [&](int tt, uint32_t (&w)[11]) {
+        int v = tt < 0 ? 0 : tt;
+        int qq = v / 20, gg = v - 20 * qq;
+        int rw = 20 * qq + i;
+        if (rw > 191) rw = 191, gg = 0;
+        const size_t off = (size_t)rw * 840 + (size_t)gg * 42;
+        const uint32_t *p32 = reinterpret_cast<const uint32_t *>(frame + (off & ~(size_t)3));
+        uint32_t raw[11];
+#pragma unroll
+        for (int j = 0; j < 11; j++) raw[j] = p32[j];
+        const uint32_t sh = ((uint32_t)off & 2u) * 8u;
+#pragma unroll
+        for (int j = 0; j < 10; j++) w[j] = __builtin_amdgcn_alignbit(raw[j + 1], raw[j], sh);
+        w[10] = raw[10] >> sh;
+    };
+    // (eleven dwords from the aligned base never leave the row: a group at an odd halfword is the row's last or has 42 bytes
+    // behind it; positions beyond the frame are clamped to row 191's first group)
+    // mean of the two source pixels of group pixel GP, three channels in one v_lerp_u8: bytes 6 GP .. 6 GP + 5 of cur
+    auto mean_of = [&](auto GPc) -> uint32_t {
+        constexpr int GP = decltype(GPc)::value;
+        constexpr int oa = 6 * GP, ob = 6 * GP + 3;
+        const uint32_t A = (oa & 3) ? __builtin_amdgcn_alignbit(cur[(oa >> 2) + 1], cur[oa >> 2], (oa & 3) * 8) : cur[oa >> 2];
+        const uint32_t B = (ob & 3) ? __builtin_amdgcn_alignbit(cur[(ob >> 2) + 1 > 10 ? 10 : (ob >> 2) + 1], cur[ob >> 2], (ob & 3) * 8) : cur[ob >> 2];
+        return __builtin_amdgcn_lerp(A, B, 0x01010101u);
+    };
+    auto value_of = [&](uint32_t m, int ar, int ag, int ab, int &r, int &g, int &b) {   // clamp(mean + floor(acc / 16))
+        r = min(max((int)(m & 255u) + (ar >> 4), 0), 255);
+        g = min(max((int)((m >> 8) & 255u) + (ag >> 4), 0), 255);
+        b = min(max((int)((m >> 16) & 255u) + (ab >> 4), 0), 255);
+    };
+    int tt = -i;                          // this lane's group number at outer iteration T
+    bool active = false;
+    int row = i;
+    size_t outp = 0;
+    load_group(tt, cur);
+    load_group(tt + 1, nxt);
+    auto step = [&](auto Pc) {
+        constexpr int PH = decltype(Pc)::value;
+        // what arrived: D(pixel + 5) of the row above, into its slot; lane 0 of a frame slot takes it from the ring
+        {
+            // (every lane reads the ring -- a branch per step costs more than three LDS words; only lanes 0 / 20 / 40 keep them)
+            const int s = 7 * tt + PH - 135;         // lane 19's sequence index of that D
+            const int *slot = ring[s & 15];
+            const bool from_ring = i == 0, has = s >= 0;
+            const int ar = from_ring ? (has ? slot[0] : 0) : inr;
+            const int ag = from_ring ? (has ? slot[1] : 0) : ing;
+            const int ab = from_ring ? (has ? slot[2] : 0) : inb;
+            Dq[(PH + 5) % 7][0] = ar, Dq[(PH + 5) % 7][1] = ag, Dq[(PH + 5) % 7][2] = ab;
+        }
         int er = 0, eg = 0, eb = 0;
-        const bool first = k == 0;      // (also at the flush step u == 420: k was reset behind the last row)
+        const bool first = PH == 0 && (tt % 20 == 0 || !active);    // (inactive lanes: only the flush of their last row matters)
+        // to the row below: D(j) = e(j - 1) + 5 e(j) + 3 e(j + 1) for j = this pixel - 1 (j = 139 of the finished row at a row's
+        // first pixel and at the flush behind a lane's last row; an idle lane hands down its h: 0, or the flush)
+        int outr = hr, outg = hg, outb = hb;
         if (active) {
-            int ir = dr, ig = dg, ib = db;          // from the row above
-            if (lane == 0) {
-                // rows 64 and 128: what lane 63 emitted 140 positions earlier; row 0: nothing above
-                const int *slot = ring[(u - 140) & 15];
-                const bool has = u >= 140;
-                ir = has ? slot[0] : 0, ig = has ? slot[1] : 0, ib = has ? slot[2] : 0;
+            int r, g, b;
+            value_of(mean_of(Pc), 7 * e0r + Dq[PH][0], 7 * e0g + Dq[PH][1], 7 * e0b + Dq[PH][2], r, g, b);
+            if constexpr (MODE == kDHGR) {
+                // the nearest of the sixteen colours; its value IS the pixel's dot quad
+                const int col = nearest16(P, kv, r, g, b);
+                const uint32_t prgb = pal_s[col];
+                er = r - (int)(prgb & 255u);
+                eg = g - (int)((prgb >> 8) & 255u);
+                eb = b - (int)((prgb >> 16) & 255u);
+                bytesAB |= (uint32_t)col << (4 * PH);
+                if (PH == 6) {
+                    const uint32_t b0 = bytesAB & 0x7fu, b1 = (bytesAB >> 7) & 0x7fu, b2 = (bytesAB >> 14) & 0x7fu, b3 = (bytesAB >> 21) & 0x7fu;
+                    *reinterpret_cast<uint16_t *>(aux_mem + outp) = (uint16_t)(b0 | (b2 << 8));
+                    *reinterpret_cast<uint16_t *>(main_mem + outp) = (uint16_t)(b1 | (b3 << 8));
+                    outp += 2;
+                    bytesAB = 0;
+                }
+            } else {
+            const F6 fk = f6(r, g, b);
+            if (PH == 0 || PH == 4) {
+                // the palette bit of the byte this pixel opens: summed nearest-colour errors of the pixels that start in it
+                // (weights: their dots in the byte; the term common to all colours cancels), ties to 0
+                int s0 = 2 * min(min(fk.f0, fk.f3), min(fk.f12, fk.f15)), s1 = 2 * min(min(fk.f0, fk.f6), min(fk.f9, fk.f15));
+                auto ahead = [&](auto Qc, int w) {
+                    constexpr int Q = decltype(Qc)::value;
+                    int r2, g2, b2;
+                    value_of(mean_of(Qc), Dq[Q][0], Dq[Q][1], Dq[Q][2], r2, g2, b2);
+                    const F6 fa = f6(r2, g2, b2);
+                    s0 += w * min(min(fa.f0, fa.f3), min(fa.f12, fa.f15));
+                    s1 += w * min(min(fa.f0, fa.f6), min(fa.f9, fa.f15));
+                };
+                if (PH == 0) {
+                    ahead(std::integral_constant<int, 1>{}, 2);
+                    ahead(std::integral_constant<int, 2>{}, 2);
+                    ahead(std::integral_constant<int, 3>{}, 1);
+                    pbA = s1 < s0 ? 1 : 0;
+                } else {
+                    ahead(std::integral_constant<int, 5>{}, 2);
+                    ahead(std::integral_constant<int, 6>{}, 2);
+                    pbB = s1 < s0 ? 1 : 0;
+                }
             }
-            // mean of the two source pixels, three channels at once: v_lerp_u8 = per byte (a + b + 1) >> 1
-            const uint32_t m = __builtin_amdgcn_lerp(s0, __builtin_amdgcn_alignbit(s1, s0, 24), 0x01010101u);
-            // value = clamp(mean + floor((7 e(k - 1) + D) / 16))    (>> 4 of a negative int: floor)
-            const int r = min(max((int)(m & 255u) + ((7 * e0r + ir) >> 4), 0), 255);
-            const int g = min(max((int)((m >> 8) & 255u) + ((7 * e0g + ig) >> 4), 0), 255);
-            const int b = min(max((int)((m >> 16) & 255u) + ((7 * e0b + ib) >> 4), 0), 255);
-            const int col = nearest16(P, kv, r, g, b);
-            const uint32_t prgb = pal_s[col];
+            const int pb = PH < 4 ? pbA : pbB;
+            const int k0 = min(min(fk.f0 * 4, fk.f3 * 4 + 1), min(fk.f12 * 4 + 2, fk.f15 * 4 + 3));
+            const int k1 = min(min(fk.f0 * 4, fk.f6 * 4 + 1), min(fk.f9 * 4 + 2, fk.f15 * 4 + 3));
+            const uint32_t pat = (uint32_t)(pb ? k1 : k0) & 3u;
+            const uint32_t prgb = rgb_s[pb * 4 + (int)pat];
             er = r - (int)(prgb & 255u);
             eg = g - (int)((prgb >> 8) & 255u);
             eb = b - (int)((prgb >> 16) & 255u);
-            dots |= (uint32_t)col << sh4;
-            sh4 += 4;
-            if (sh4 == 28) {
-                const uint32_t b0 = dots & 0x7fu, b1 = (dots >> 7) & 0x7fu, b2 = (dots >> 14) & 0x7fu, b3 = (dots >> 21) & 0x7fu;
-                *reinterpret_cast<uint16_t *>(aux_mem + outp) = (uint16_t)(b0 | (b2 << 8));
-                *reinterpret_cast<uint16_t *>(main_mem + outp) = (uint16_t)(b1 | (b3 << 8));
+            // dots 2 PH, 2 PH + 1 of the group: byte A = dots 0..6 | palette bit, byte B = dots 7..13 | palette bit
+            if (PH < 3) bytesAB |= pat << (2 * PH);
+            if (PH == 3) bytesAB |= ((pat & 1u) << 6) | ((uint32_t)pbA << 7) | ((pat >> 1) << 8);
+            if (PH > 3) bytesAB |= pat << (2 * PH + 1);       // PH 4, 5, 6 -> bits 9, 11, 13 (byte B bits 1, 3, 5)
+            if (PH == 6) {
+                *reinterpret_cast<uint16_t *>(main_mem + outp) = (uint16_t)(bytesAB | ((uint32_t)pbB << 15));
                 outp += 2;
-                dots = 0;
-                sh4 = 0;
+                bytesAB = 0;
             }
-        }
-        // what the row below receives for its pixel j = k - 1 (j = 139 of the row just finished when k == 0 or at the flush):
-        // D(j) = e(j - 1) + 5 e(j) + 3 e(j + 1), the last term absent behind the end of the row
-        const int outr = first ? hr : hr + 3 * er, outg = first ? hg : hg + 3 * eg, outb = first ? hb : hb + 3 * eb;
-        if (lane == 63 && u >= 1 && u <= 420) {
-            // (slot = position of the emitted D in lane 63's sequence, u - 1: lane 0 reads it 13 steps later as its position - 140)
-            int *slot = ring[(u - 1) & 15];
-            slot[0] = outr, slot[1] = outg, slot[2] = outb;
-        }
-        wave_lds_sync();   // (LDS accesses of one wave execute in order; this keeps the compiler from moving them)
-        // to lane l + 1 (wave_shr:1; lane 0 keeps the 0 it is given, which it never uses)
-        dr = __builtin_amdgcn_update_dpp(0, outr, 0x138, 0xf, 0xf, false);
-        dg = __builtin_amdgcn_update_dpp(0, outg, 0x138, 0xf, 0xf, false);
-        db = __builtin_amdgcn_update_dpp(0, outb, 0x138, 0xf, 0xf, false);
-        if (active) {
-            // the row's own history: at the first pixel of a row the previous row's errors have just left (above)
-            hr = (first ? 0 : e0r) + 5 * er, hg = (first ? 0 : e0g) + 5 * eg, hb = (first ? 0 : e0b) + 5 * eb;
+            }   // HGR
+            if (!first) outr += 3 * er, outg += 3 * eg, outb += 3 * eb;
+            hr = e0r + 5 * er, hg = e0g + 5 * eg, hb = e0b + 5 * eb;
             e0r = er, e0g = eg, e0b = eb;
-            if (++k == 140) {
-                k = 0;
-                row += 64;
-                outp = f * 8192 + (size_t)y_to_offset(row < 192 ? row : 191);
-                e0r = e0g = e0b = 0;      // (nothing comes from the left at the start of a row)
+        } else if (PH == 0) {
+            hr = hg = hb = 0;     // (flushed: out holds it)
+        }
+        {
+            const int s = 7 * tt + PH - 1;            // this lane's sequence index of the emitted D
+            if (i == 19 && s >= 0) {
+                int *slot = ring[s & 15];
+                slot[0] = outr, slot[1] = outg, slot[2] = outb;
             }
         }
-        u++;
+        wave_lds_sync();
+        inr = __builtin_amdgcn_update_dpp(0, outr, 0x138, 0xf, 0xf, false);   // wave_shr:1
+        ing = __builtin_amdgcn_update_dpp(0, outg, 0x138, 0xf, 0xf, false);
+        inb = __builtin_amdgcn_update_dpp(0, outb, 0x138, 0xf, 0xf, false);
     };
-    // 420 pixels + 126 steps of skew + the flush step of lane 63: u of lane 63 reaches 420 at t = 546
-    for (int t = 0; t < 548; t += 4) {
-        // (u = t - 2 l is even here for every lane; c holds the pairs of positions u and u + 2)
-        step(c[0], c[1]);
-        step((c[1] >> 16) | (c[2] << 16), c[2] >> 16);
-        step(c[3], c[4]);
-        step((c[4] >> 16) | (c[5] << 16), c[5] >> 16);
-#pragma unroll
-        for (int i = 0; i < 6; i++) c[i] = nx[i];
-        const uint32_t *p2 = src_of(u + 4), *p3 = src_of(u + 6);
-#pragma unroll
-        for (int i = 0; i < 3; i++) nx[i] = p2[i], nx[3 + i] = p3[i];
-    }
-}
-
-// dither == IIV_DITHER_DIFFUSION, HGR: a pixel needs the errors of its left neighbour and of three pixels of the row
-// above, and a screen byte's palette bit is fixed from the accumulated error of up to four pixels ahead, which must
-// have received everything the row above sends them: the rows of a frame advance as a skewed wavefront, one thread
-// per row, row y working on pixel t - 6 y at step t, one workgroup barrier per step, 140 + 6 * 191 steps per frame.
-// The accumulators of a row live in an eight-slot ring in LDS (pixel k in slot k & 7): the row above writes slots
-// k + 5 .. k + 7 while the row itself reads k .. k + 3 and adds to k + 1.
-__device__ static inline int ingest_err(const uint8_t *pal, int c, int r, int g, int b)
-{
-    const int dr = r - pal[3 * c], dg = g - pal[3 * c + 1], db = b - pal[3 * c + 2];
-    return 2 * dr * dr + 4 * dg * dg + 3 * db * db;
-}
-
-__global__ __launch_bounds__(192) void ingest_diffusion_hgr_kernel(const uint8_t *__restrict__ rgb_frames, const IngestPalette P,
-                                                                   uint8_t *__restrict__ main_mem)
-{
-    constexpr int colour4[2][4] = {{0, 3, 12, 15}, {0, 6, 9, 15}};
-    __shared__ int ring[192][8][3];
-    __shared__ uint8_t patt[192][140];   // 2-dot pattern | palette bit << 2
-    __shared__ uint8_t pal[48];
-    const int y = threadIdx.x;
-    const size_t f = blockIdx.x;
-    const uint8_t *rgb = rgb_frames + f * (size_t)(192 * 280 * 3) + (size_t)y * 280 * 3;
-    if (y < 16) {
-        pal[3 * y] = (uint8_t)(P.rgb[y] & 255u);
-        pal[3 * y + 1] = (uint8_t)((P.rgb[y] >> 8) & 255u);
-        pal[3 * y + 2] = (uint8_t)((P.rgb[y] >> 16) & 255u);
-    }
-    for (int i = 0; i < 24; i++) (&ring[y][0][0])[i] = 0;
-    __syncthreads();
-    auto value = [&](int k, int &r, int &g, int &b) {
-        const uint8_t *p = rgb + 6 * k;
-        const int *a = ring[y][k & 7];
-        int v = ((int)p[0] + (int)p[3] + 1) / 2 + (a[0] >> 4);   // (>> 4 of a negative int: floor)
-        r = v < 0 ? 0 : v > 255 ? 255 : v;
-        v = ((int)p[1] + (int)p[4] + 1) / 2 + (a[1] >> 4);
-        g = v < 0 ? 0 : v > 255 ? 255 : v;
-        v = ((int)p[2] + (int)p[5] + 1) / 2 + (a[2] >> 4);
-        b = v < 0 ? 0 : v > 255 ? 255 : v;
-    };
-    int pb = 0;
-    for (int t = 0; t < 140 + 6 * 191; t++) {
-        const int k = t - 6 * y;
-        if (k >= 0 && k < 140) {
-            int r, g, b;
-            if (k == 0 || (2 * k) / 7 != (2 * k - 2) / 7) {   // the first dot of this pixel opens screen byte bb
-                const int bb = (2 * k) / 7;
-                long err0 = 0, err1 = 0;
-                for (int kk = k; kk < 140 && (2 * kk) / 7 == bb; kk++) {
-                    int ur, ug, ub;
-                    value(kk, ur, ug, ub);
-                    const int w = (2 * kk + 1) / 7 == bb ? 2 : 1;
-                    int b0 = 0x7fffffff, b1 = 0x7fffffff;
-                    for (int i = 0; i < 4; i++) {
-                        const int e0 = ingest_err(pal, colour4[0][i], ur, ug, ub), e1 = ingest_err(pal, colour4[1][i], ur, ug, ub);
-                        b0 = e0 < b0 ? e0 : b0;
-                        b1 = e1 < b1 ? e1 : b1;
-                    }
-                    err0 += (long)w * b0;
-                    err1 += (long)w * b1;
-                }
-                pb = err1 < err0 ? 1 : 0;
-            }
-            value(k, r, g, b);
-            int best = 0, be = 0x7fffffff;
-            for (int i = 0; i < 4; i++) {
-                const int e = ingest_err(pal, colour4[pb][i], r, g, b);
-                if (e < be) {
-                    be = e;
-                    best = i;
-                }
-            }
-            const int colour = colour4[pb][best];
-            patt[y][k] = (uint8_t)(best | (pb << 2));
-            const int e[3] = {r - pal[3 * colour], g - pal[3 * colour + 1], b - pal[3 * colour + 2]};
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                ring[y][k & 7][c] = 0;   // the slot is pixel k + 8's from now on
-                if (k + 1 < 140) ring[y][(k + 1) & 7][c] += 7 * e[c];
-                if (y + 1 < 192) {
-                    if (k > 0) ring[y + 1][(k - 1) & 7][c] += 3 * e[c];
-                    ring[y + 1][k & 7][c] += 5 * e[c];
-                    if (k + 1 < 140) ring[y + 1][(k + 1) & 7][c] += e[c];
-                }
-            }
+    // lane i starts at T = i and runs 200 groups (pass 9: rows 180 + i < 192 only); one more iteration flushes the last rows
+    for (int T = 0; T < 19 + 200 + 1; T++) {
+        const int qq = tt >= 0 ? tt / 20 : 0;
+        row = 20 * qq + i;
+        active = lane_ok && tt >= 0 && row < 192;
+        if (tt >= 0 && tt % 20 == 0) {
+            // a new row: nothing from the left; where its bytes go
+            e0r = e0g = e0b = 0;
+            outp = f * 8192 + (size_t)y_to_offset(row < 192 ? row : 191);
         }
-        __syncthreads();
-    }
-    // the row's bytes (this thread wrote every pattern of its row itself)
-    const int base = y_to_offset(y);
-    for (int bb = 0; bb < 40; bb++) {
-        // the byte's palette bit is that of the first pixel whose first dot lies in it
-        int v = ((patt[y][(7 * bb + 1) >> 1] >> 2) & 1) << 7;
-        for (int i = 0; i < 7; i++) {
-            const int X = 7 * bb + i;
-            v |= ((patt[y][X >> 1] >> (X & 1)) & 1) << i;
-        }
-        main_mem[f * 8192 + base + bb] = (uint8_t)v;
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+        step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{});
+        step(std::integral_constant<int, 4>{});
+        step(std::integral_constant<int, 5>{});
+        step(std::integral_constant<int, 6>{});
+#pragma unroll
+        for (int j = 0; j < 11; j++) cur[j] = nxt[j];
+        tt++;
+        load_group(tt + 1, nxt);
     }
 }
 
@@ -413,13 +415,11 @@ int frames_to_memory_maps(int mode, const uint8_t palette_rgb[48], int n, const 
     int rc = hip_check(hipGetLastError(), "ingest_holes_kernel launch");
     if (rc) return rc;
     if (dither == IIV_DITHER_DIFFUSION) {
-        if (mode == kDHGR) {
-            static const int pad = getenv("IIV_EXP_DIFF_LDS_PAD") ? atoi(getenv("IIV_EXP_DIFF_LDS_PAD")) : 0;   // EXPERIMENT: residency cap
-            hipLaunchKernelGGL(ingest_diffusion_dhgr_kernel, dim3((unsigned)((n + kDiffWavesPerBlock - 1) / kDiffWavesPerBlock)),
-                               dim3(64 * kDiffWavesPerBlock), (size_t)pad, st, n, d_rgb, P, d_main, d_aux);
-        }
+        const dim3 grid((unsigned)((n + 3 * kDiffWaves - 1) / (3 * kDiffWaves)));
+        if (mode == kDHGR)
+            hipLaunchKernelGGL(ingest_diffusion_kernel<kDHGR>, grid, dim3(64 * kDiffWaves), 0, st, n, d_rgb, P, d_main, d_aux);
         else
-            hipLaunchKernelGGL(ingest_diffusion_hgr_kernel, dim3((unsigned)n), dim3(192), 0, st, d_rgb, P, d_main);
+            hipLaunchKernelGGL(ingest_diffusion_kernel<kHGR>, grid, dim3(64 * kDiffWaves), 0, st, n, d_rgb, P, d_main, d_aux);
         return hip_check(hipGetLastError(), "ingest diffusion kernel launch");
     }
     const size_t total = (size_t)n * 3840;

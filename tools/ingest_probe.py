@@ -10,7 +10,10 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 102400
 mode = native.HGR if (len(sys.argv) > 2 and sys.argv[2] == "HGR") else native.DHGR
 pal = palette.NTSCPalette.rgb_array()
 clips, frames = 256, N // 256
-rgb = stream_batch.synth_rgb_torch(clips, frames, seed=3).view(-1, 192, 280, 3)
+if os.environ.get("IIV_PROBE_NOISE") == "1":   # (one kernel instead of thousands: for counter runs)
+    rgb = torch.randint(0, 256, (clips * frames, 192, 280, 3), dtype=torch.uint8, device="cuda")
+else:
+    rgb = stream_batch.synth_rgb_torch(clips, frames, seed=3).view(-1, 192, 280, 3)
 main = torch.empty((rgb.shape[0], 32, 256), dtype=torch.uint8, device="cuda")
 aux = torch.empty_like(main)
 for name, d in (("none", 0), ("ordered 32", 32), ("diffusion", native.DITHER_DIFFUSION)):
