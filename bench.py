@@ -677,11 +677,12 @@ def _roofline_objects(be, args, prof, op_count, seg_count, S, elapsed, live_ceil
     issue = _pmc_issue(args.mode, _input_kind(args), getattr(args, "fourth", False)) if be.uses_wave_kernel() else None
     out["roofline"] = {
         "kernel": "greedy_wave_kernel" if be.uses_wave_kernel() else "greedy_kernel",
-        # What binds the kernel is NOT the quantity the HBM fraction below measures: a step is a chain of dependent wave
-        # reductions and scalar bookkeeping at 4-7 waves per SIMD (`issue`: instructions per clock and SIMD well below 1, the
-        # vector pipe a third busy, HBM -- `traffic_frac` -- under 0.4).  achieved / peak / frac stay the SURVEY 8(d) HBM
-        # figure (algorithmic bytes over launch time), the contract's yardstick for the path.
-        "bound": "latency",
+        # What binds the kernel is NOT the quantity the HBM fraction below measures: a step is ~310 instructions per wave, and at
+        # 4-7 waves per SIMD the SIMD's vector issue slot is two thirds to three quarters taken (`issue.valu_busy_frac`, at the
+        # 4 clocks per wave64 instruction this chip sustains) and its scalar slot likewise; 24 waves per CU run no faster than
+        # 16 (profiles/r05_occupancy_timing_experiment.txt), HBM (`traffic_frac`) is under 0.4.  achieved / peak / frac stay
+        # the SURVEY 8(d) HBM figure (algorithmic bytes over launch time), the contract's yardstick for the path.
+        "bound": "issue",
         "frac_is": "algorithmic HBM bytes per launch / launch time / the 8 TB/s peak (SURVEY 8d) -- the contract's yardstick, not the binding resource",
         "issue": issue,
         "achieved": achieved,

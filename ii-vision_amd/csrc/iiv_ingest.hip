@@ -291,10 +291,12 @@ __global__ __launch_bounds__(64 * kDiffWaves) void ingest_diffusion_kernel(int n
             // (every lane reads the ring -- a branch per step costs more than three LDS words; only lanes 0 / 20 / 40 keep them)
             const int s = 7 * tt + PH - 135;         // lane 19's sequence index of that D
             const int *slot = ring[s & 15];
+            int s0 = slot[0], s1 = slot[1], s2 = slot[2];
+            asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2));   // (read by every lane: kept out of an exec region each)
             const bool from_ring = i == 0, has = s >= 0;
-            const int ar = from_ring ? (has ? slot[0] : 0) : inr;
-            const int ag = from_ring ? (has ? slot[1] : 0) : ing;
-            const int ab = from_ring ? (has ? slot[2] : 0) : inb;
+            const int ar = from_ring ? (has ? s0 : 0) : inr;
+            const int ag = from_ring ? (has ? s1 : 0) : ing;
+            const int ab = from_ring ? (has ? s2 : 0) : inb;
             Dq[(PH + 5) % 7][0] = ar, Dq[(PH + 5) % 7][1] = ag, Dq[(PH + 5) % 7][2] = ab;
         }
         int er = 0, eg = 0, eb = 0;
@@ -304,7 +306,10 @@ __global__ __launch_bounds__(64 * kDiffWaves) void ingest_diffusion_kernel(int n
         int outr = hr, outg = hg, outb = hb;
         if (active) {
             int r, g, b;
-            value_of(mean_of(Pc), 7 * e0r + Dq[PH][0], 7 * e0g + Dq[PH][1], 7 * e0b + Dq[PH][2], r, g, b);
+            // 7 e + D as (e << 3) + (D - e): two full-rate instructions (a plain 7 * e + D becomes the quarter-rate v_mad_u64_u32)
+            int tr = Dq[PH][0] - e0r, tg = Dq[PH][1] - e0g, tb = Dq[PH][2] - e0b;
+            asm("" : "+v"(tr), "+v"(tg), "+v"(tb));
+            value_of(mean_of(Pc), (e0r << 3) + tr, (e0g << 3) + tg, (e0b << 3) + tb, r, g, b);
             if constexpr (MODE == kDHGR) {
                 // the nearest of the sixteen colours; its value IS the pixel's dot quad
                 const int col = nearest16(P, kv, r, g, b);
@@ -331,8 +336,8 @@ __global__ __launch_bounds__(64 * kDiffWaves) void ingest_diffusion_kernel(int n
                     int r2, g2, b2;
                     value_of(mean_of(Qc), Dq[Q][0], Dq[Q][1], Dq[Q][2], r2, g2, b2);
                     const F6 fa = f6(r2, g2, b2);
-                    s0 += w * min(min(fa.f0, fa.f3), min(fa.f12, fa.f15));
-                    s1 += w * min(min(fa.f0, fa.f6), min(fa.f9, fa.f15));
+                    s0 += __mul24(w, min(min(fa.f0, fa.f3), min(fa.f12, fa.f15)));   // (|f| < 2^21)
+                    s1 += __mul24(w, min(min(fa.f0, fa.f6), min(fa.f9, fa.f15)));
                 };
                 if (PH == 0) {
                     ahead(std::integral_constant<int, 1>{}, 2);
@@ -363,8 +368,8 @@ __global__ __launch_bounds__(64 * kDiffWaves) void ingest_diffusion_kernel(int n
                 bytesAB = 0;
             }
             }   // HGR
-            if (!first) outr += 3 * er, outg += 3 * eg, outb += 3 * eb;
-            hr = e0r + 5 * er, hg = e0g + 5 * eg, hb = e0b + 5 * eb;
+            if (!first) outr += __mul24(3, er), outg += __mul24(3, eg), outb += __mul24(3, eb);
+            hr = e0r + __mul24(5, er), hg = e0g + __mul24(5, eg), hb = e0b + __mul24(5, eb);
             e0r = er, e0g = eg, e0b = eb;
         } else if (PH == 0) {
             hr = hg = hb = 0;     // (flushed: out holds it)
