@@ -76,22 +76,25 @@ __device__ static inline IngestKv ingest_kv(const IngestPalette &P)
     return v;
 }
 
-// key of colour c for the pixel (r, g, b): 16 * (distance - the term common to all colours) + c, as three v_mad_i32_i24
-__device__ static inline int ingest_key(const IngestPalette &P, const IngestKv &kv, int c, int r, int g, int b)
-{
-    int t = __mul24(r, P.a[c]) + kv.k[c];
-    asm("" : "+v"(t));   // (keeps the chain a chain: the compiler otherwise re-associates it into mad + 2 mul + add3)
-    t = __mul24(g, P.b[c]) + t;
-    asm("" : "+v"(t));
-    return __mul24(b, P.c[c]) + t;
-}
-
-// DHGR: the nearest of the sixteen colours (ties to the lower colour value)
+// key of colour c for the pixel (r, g, b) = 16 * (distance - the term common to all colours) + c: three v_mad_i32_i24.
+// DHGR: the nearest of the sixteen colours (ties to the lower colour value).  Three rounds of sixteen independent
+// multiply-adds with ONE compiler barrier between rounds (the barrier keeps the compiler from re-associating a colour's
+// chain into mad + 2 mul + add3; one asm statement per round rather than per colour, because the hazard recogniser puts an
+// s_nop behind every inline-asm statement)
 __device__ static inline int nearest16(const IngestPalette &P, const IngestKv &kv, int r, int g, int b)
 {
+    int t[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) t[c] = __mul24(r, P.a[c]) + kv.k[c];
+    asm("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]), "+v"(t[8]), "+v"(t[9]),
+             "+v"(t[10]), "+v"(t[11]), "+v"(t[12]), "+v"(t[13]), "+v"(t[14]), "+v"(t[15]));
+#pragma unroll
+    for (int c = 0; c < 16; c++) t[c] = __mul24(g, P.b[c]) + t[c];
+    asm("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]), "+v"(t[8]), "+v"(t[9]),
+             "+v"(t[10]), "+v"(t[11]), "+v"(t[12]), "+v"(t[13]), "+v"(t[14]), "+v"(t[15]));
     int m = 0x7fffffff;
 #pragma unroll
-    for (int c = 0; c < 16; c++) m = min(m, ingest_key(P, kv, c, r, g, b));
+    for (int c = 0; c < 16; c++) m = min(m, __mul24(b, P.c[c]) + t[c]);
     return m & 15;
 }
 
@@ -99,9 +102,18 @@ __device__ static inline int nearest16(const IngestPalette &P, const IngestKv &k
 // (black 0, violet 3 | blue 6, green 12 | orange 9, white 15; ties to the lower pattern)
 __device__ static inline void nearest4x2(const IngestPalette &P, const IngestKv &kv, int r, int g, int b, int &key0, int &key1)
 {
-    const int f0 = ingest_key(P, kv, 0, r, g, b) >> 4, f15 = ingest_key(P, kv, 15, r, g, b) >> 4;   // (>> 4: the colour value leaves, f stays exact)
-    const int f3 = ingest_key(P, kv, 3, r, g, b) >> 4, f12 = ingest_key(P, kv, 12, r, g, b) >> 4;
-    const int f6 = ingest_key(P, kv, 6, r, g, b) >> 4, f9 = ingest_key(P, kv, 9, r, g, b) >> 4;
+    // the six colours HGR can show, three rounds of six multiply-adds (see nearest16 for the barriers)
+    constexpr int col[6] = {0, 3, 12, 15, 6, 9};
+    int t[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) t[j] = __mul24(r, P.a[col[j]]) + kv.k[col[j]];
+    asm("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]));
+#pragma unroll
+    for (int j = 0; j < 6; j++) t[j] = __mul24(g, P.b[col[j]]) + t[j];
+    asm("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]));
+#pragma unroll
+    for (int j = 0; j < 6; j++) t[j] = (__mul24(b, P.c[col[j]]) + t[j]) >> 4;   // (>> 4: the colour value leaves, the distance term stays exact)
+    const int f0 = t[0], f3 = t[1], f12 = t[2], f15 = t[3], f6 = t[4], f9 = t[5];
     const int b0 = f0 * 4, w3 = f15 * 4 + 3;
     key0 = min(min(b0, f3 * 4 + 1), min(f12 * 4 + 2, w3));
     key1 = min(min(b0, f6 * 4 + 1), min(f9 * 4 + 2, w3));
@@ -224,18 +236,18 @@ __global__ __launch_bounds__(64 * kDiffWaves) void ingest_diffusion_kernel(int n
     // HGR: the six colours it can show, their K in vector registers (see IngestKv)
     int kv0 = P.k[0], kv3 = P.k[3], kv12 = P.k[12], kv15 = P.k[15], kv6 = P.k[6], kv9 = P.k[9];
     asm volatile("" : "+v"(kv0), "+v"(kv3), "+v"(kv12), "+v"(kv15), "+v"(kv6), "+v"(kv9));
-    auto fkey = [&](int c, int kv, int r, int g, int b) -> int {   // 16 * (distance term) + c >> 4 = the distance term itself
-        int t = __mul24(r, P.a[c]) + kv;
-        asm("" : "+v"(t));
-        t = __mul24(g, P.b[c]) + t;
-        asm("" : "+v"(t));
-        return (__mul24(b, P.c[c]) + t) >> 4;
-    };
     struct F6 {
         int f0, f3, f12, f15, f6, f9;
     };
-    auto f6 = [&](int r, int g, int b) -> F6 {
-        return F6{fkey(0, kv0, r, g, b), fkey(3, kv3, r, g, b), fkey(12, kv12, r, g, b), fkey(15, kv15, r, g, b), fkey(6, kv6, r, g, b), fkey(9, kv9, r, g, b)};
+    auto f6 = [&](int r, int g, int b) -> F6 {   // the distance terms of the six colours: three rounds of six multiply-adds (see nearest16)
+        int t0 = __mul24(r, P.a[0]) + kv0, t3 = __mul24(r, P.a[3]) + kv3, t12 = __mul24(r, P.a[12]) + kv12;
+        int t15 = __mul24(r, P.a[15]) + kv15, t6 = __mul24(r, P.a[6]) + kv6, t9 = __mul24(r, P.a[9]) + kv9;
+        asm("" : "+v"(t0), "+v"(t3), "+v"(t12), "+v"(t15), "+v"(t6), "+v"(t9));
+        t0 += __mul24(g, P.b[0]), t3 += __mul24(g, P.b[3]), t12 += __mul24(g, P.b[12]);
+        t15 += __mul24(g, P.b[15]), t6 += __mul24(g, P.b[6]), t9 += __mul24(g, P.b[9]);
+        asm("" : "+v"(t0), "+v"(t3), "+v"(t12), "+v"(t15), "+v"(t6), "+v"(t9));
+        return F6{(t0 + __mul24(b, P.c[0])) >> 4, (t3 + __mul24(b, P.c[3])) >> 4, (t12 + __mul24(b, P.c[12])) >> 4,
+                  (t15 + __mul24(b, P.c[15])) >> 4, (t6 + __mul24(b, P.c[6])) >> 4, (t9 + __mul24(b, P.c[9])) >> 4};
     };
     // per-lane sequence: group tt = T - i of this lane's rows (20 groups of 7 pixels per row; rows i, 20 + i, ...)
     int Dq[7][3];                         // D from the row above for the pixels of the period, slot = pixel mod 7
