@@ -30,7 +30,8 @@ Budget: a generator may be abandoned after any next() (movie.py:94-109 does so a
 every frame and bank flip), and its side effects must then be exactly those of
 the opcodes consumed.  Without a hint every next() is therefore one device step.
 `encode_frame(target, is_aux, budget=K)` promises that K opcodes will be pulled;
-they are then computed by one launch.  `Video.SPECULATE = N` (default 256; 0 = one device
+they are then computed by one launch.  `Video.SPECULATE = N` (default: what one generator of movie.py's
+pacing can be asked for -- 292 opcodes, the gap between two DHGR bank flips, or a frame's worth in HGR; 0 = one device
 step per next()) gets batched launches without a promise: N opcodes are produced from a
 device-side snapshot and rolled back + replayed if fewer were consumed.  Batched, many-stream encoding
 (what bench.py measures) goes through stream_batch.StreamBatch instead.
@@ -60,7 +61,10 @@ class Video:
     #: opcodes.  Nothing observable depends on it (an assertion of the reference that would
     #: fire inside the unconsumed part of a chunk makes the generator fall back to exact
     #: stepping), only the speed does.
-    SPECULATE = 256
+    #: None (default): the longest generator movie.py's pacing produces -- DHGR 292 opcodes (2044 bytes of a 2 KiB socket frame
+    #: / 7, movie.py:139-148: a bank flip ends the generator), HGR a frame's worth (ticks_per_frame, video.py:64-70) -- so
+    #: that a Movie-paced generator is one launch (and in HGR usually exact: nothing to roll back).
+    SPECULATE = None
 
     #: True: after every next() the host arrays and the *global* random / np.random states
     #: are those of the reference at that point (one full state round trip per opcode).
@@ -275,12 +279,16 @@ class Video:
         self._brief_fresh = True
         return b
 
-    def _launch(self, token, restart, n_ops):
-        """[prologue +] n_ops greedy steps on the device state as it stands."""
+    def _launch(self, token, restart, n_ops, fetch=True):
+        """[prologue +] n_ops greedy steps on the device state as it stands.  fetch=False: a replay of opcodes the caller has
+        already consumed (after a roll-back): nothing to bring home and nothing that can fail -- the speculative launch they
+        came from passed its check, and this is a prefix of it -- so the launch is only enqueued."""
         self._brief_fresh = False
         ops = self._enc.encode(token.fm, token.fa, [(0, int(bool(token.is_aux)), int(restart), int(n_ops))])
-        self._enc.check()
         self._host_current = False
+        if not fetch:
+            return None
+        self._enc.check()
         return ops[0].cpu().numpy()
 
     def _settle(self, download=True):
@@ -292,7 +300,7 @@ class Video:
             self._enc.rollback()
             self._host_current = False
             if p["consumed"]:
-                self._launch(p["token"], p["restart"], p["consumed"])
+                self._launch(p["token"], p["restart"], p["consumed"], fetch=False)
             elif p["restart"]:
                 self._live = p["prev_live"]  # the prologue never happened
                 p["token"].started = False
@@ -350,7 +358,10 @@ class Video:
             self._dev_main = torch.empty((1, 1, 32, 256), dtype=torch.uint8, device="cuda")
             self._dev_aux = torch.empty((1, 1, 32, 256), dtype=torch.uint8, device="cuda") if token.aux is not None else None
         token.fm, token.fa = self._dev_main, self._dev_aux
-        chunk = int(budget) if budget else 1 if self.STRICT_SYNC else max(1, int(self.SPECULATE))
+        spec = self.SPECULATE
+        if spec is None:
+            spec = 292 if self.mode == VideoMode.DHGR else max(1, int(round(self.ticks_per_frame)))
+        chunk = int(budget) if budget else 1 if self.STRICT_SYNC else max(1, int(spec))
         speculative = not budget and chunk > 1
         try:
             while True:
