@@ -828,29 +828,53 @@ def _dropin_video(args, n_frames=20):
     class FrameGrabber:
         input_frame_rate = 30
 
+    def target_of(tgts, fr):
+        if fr not in tgts:
+            main = screen.MemoryMap(1, fm[0, fr].numpy().copy())
+            tgts[fr] = (screen.DHGRBitmap(main_memory=main, aux_memory=screen.MemoryMap(1, fa[0, fr].numpy().copy()), palette=pal)
+                        if dhgr else screen.HGRBitmap(main_memory=main, palette=pal))
+        return tgts[fr]
+
     def run(budget):
         random.seed(1)
         np.random.seed(1)
         v = video.Video(FrameGrabber(), ticks_per_second=14700., palette=pal,
                         mode=video_mode.VideoMode.DHGR if dhgr else video_mode.VideoMode.HGR)
-        segs = stream_batch.MovieClock(dhgr).segments(n_frames)
         tgts = {}
         t0 = time.perf_counter()
         with contextlib.redirect_stdout(io.StringIO()):
-            for (fr, ia, _, k) in segs:
-                if fr not in tgts:
-                    main = screen.MemoryMap(1, fm[0, fr].numpy().copy())
-                    tgts[fr] = (screen.DHGRBitmap(main_memory=main, aux_memory=screen.MemoryMap(1, fa[0, fr].numpy().copy()), palette=pal)
-                                if dhgr else screen.HGRBitmap(main_memory=main, palette=pal))
-                gen = v.encode_frame(tgts[fr], is_aux=bool(ia), **({"budget": k} if budget else {}))
-                for _ in range(k):
-                    next(gen)
+            if budget:
+                for (fr, ia, _, k) in stream_batch.MovieClock(dhgr).segments(n_frames):
+                    gen = v.encode_frame(target_of(tgts, fr), is_aux=bool(ia), budget=k)
+                    for _ in range(k):
+                        next(gen)
+            else:
+                # movie.Movie.encode + emit_stream, statement by statement (movie.py:56-150), audio and opcode objects left out
+                ticks, stream_pos, aux, last_bank, op_seq, target = 0, 7, False, False, None, None
+                while True:
+                    ticks += 1
+                    if v.tick(ticks):
+                        if v.frame_number - 1 >= n_frames:
+                            break
+                        target = target_of(tgts, v.frame_number - 1)
+                        op_seq = v.encode_frame(target, is_aux=aux)
+                        v.out_of_work = {True: False, False: False}
+                    if aux != last_bank:
+                        last_bank = aux
+                        op_seq = v.encode_frame(target, is_aux=aux)
+                    next(op_seq)
+                    stream_pos += 7
+                    if stream_pos % 2048 >= 2044:
+                        if dhgr:
+                            aux = not aux
+                        stream_pos += 4
         return n_frames / (time.perf_counter() - t0)
 
     try:
         run(False)   # (warm-up: table build, first launches)
         return {"value": run(False), "with_budget": run(True), "unit": "frames/s", "frames": n_frames,
-                "what": "video.Video.encode_frame generators driven from Python one next() per opcode, %s, one clip" % args.mode}
+                "what": "video.Video driven from Python as movie.Movie.encode drives it (tick() per audio sample, a generator per "
+                        "frame and bank flip, one next() per opcode), %s, one clip; with_budget: encode_frame(..., budget=k)" % args.mode}
     except Exception as e:
         return {"value": None, "error": repr(e)}
 

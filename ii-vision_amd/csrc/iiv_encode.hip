@@ -66,7 +66,7 @@ struct Encoder {
     NarrowTables nt;             // the narrow form of the split store table the greedy kernels read (iiv_stream.h)
     uint32_t *d_dwl, *d_dwr;     // split diff-weight table, likewise
     uint32_t *d_left_t, *d_right_t;  // split store table, content innermost (joint content choice; built on first use)
-    void *d_brief;                   // iiv_encoder_get_video_brief's 32 bytes
+    void *d_brief;                   // iiv_encoder_get_video_brief's staging struct
     ulonglong2 *d_strings;  // colour string of every masked value (recurrence mode)
     uint2 *d_hgr_slut;      // HGR: the three-lookup string table the prologue copies into LDS (iiv_edit.h)
     uint32_t *d_dw_pieces;  // DHGR: the diff weights' pair-term table the prologue copies into LDS (iiv_tables.hip)
@@ -603,8 +603,9 @@ int encoder_get_video_state(Encoder *e, int s, iiv_video_state *out)
     return IIV_OK;
 }
 
-// priority sums and hole bytes of one stream: out = {sum up[0], sum up[1]} (i64), {holes mem[0], holes mem[1]} (i32)
-__global__ __launch_bounds__(256) void brief_kernel(const StreamState *__restrict__ S, long long *__restrict__ out)
+// iiv_video_brief of one stream, assembled on the device so that it travels in one copy: priority sums, hole bytes,
+// out_of_work and both MT19937 states in the struct's own layout
+__global__ __launch_bounds__(256) void brief_kernel(const StreamState *__restrict__ S, iiv_video_brief *__restrict__ out)
 {
     __shared__ long long sums[2][4];
     __shared__ int holes[2][4];
@@ -616,6 +617,10 @@ __global__ __launch_bounds__(256) void brief_kernel(const StreamState *__restric
             a[b] += up_value(*S, b, i);
             if (is_hole(i & 255) && S->mem[b][i] != 0) h[b]++;
         }
+    for (int i = tid; i < 624; i += 256) {
+        out->rng_py[i] = S->mt_py[i];
+        out->rng_np[i] = S->mt_np[i];
+    }
     for (int b = 0; b < 2; b++) {
         for (int d = 1; d < 64; d <<= 1) {
             a[b] += __shfl_xor(a[b], d, 64);
@@ -628,27 +633,21 @@ __global__ __launch_bounds__(256) void brief_kernel(const StreamState *__restric
     }
     __syncthreads();
     if (tid < 2) {
-        out[tid] = sums[tid][0] + sums[tid][1] + sums[tid][2] + sums[tid][3];
-        reinterpret_cast<int *>(out + 2)[tid] = holes[tid][0] + holes[tid][1] + holes[tid][2] + holes[tid][3];
+        out->priority_sum[tid] = sums[tid][0] + sums[tid][1] + sums[tid][2] + sums[tid][3];
+        out->hole_bytes[tid] = holes[tid][0] + holes[tid][1] + holes[tid][2] + holes[tid][3];
+        out->out_of_work[tid] = S->out_of_work[tid];
+        (tid ? out->rng_np : out->rng_py)[624] = tid ? S->mt_np_idx : S->mt_py_idx;
     }
 }
 
 int encoder_get_video_brief(Encoder *e, int s, iiv_video_brief *out)
 {
     if (!e || !out || s < 0 || s >= e->n_streams) return set_error(IIV_ERR_INVALID, "get_video_brief: bad argument");
-    uint8_t *base = reinterpret_cast<uint8_t *>(e->d_states + s);
     IIV_HIP(hipDeviceSynchronize());
-    if (!e->d_brief) IIV_HIP(hipMalloc(&e->d_brief, 32));
-    hipLaunchKernelGGL(brief_kernel, dim3(1), dim3(256), 0, 0, e->d_states + s, (long long *)e->d_brief);
+    if (!e->d_brief) IIV_HIP(hipMalloc(&e->d_brief, sizeof(iiv_video_brief)));
+    hipLaunchKernelGGL(brief_kernel, dim3(1), dim3(256), 0, 0, e->d_states + s, (iiv_video_brief *)e->d_brief);
     IIV_HIP(hipGetLastError());
-    uint32_t rng[1250];
-    IIV_HIP(hipMemcpy(rng, base + offsetof(StreamState, mt_py), sizeof(rng), hipMemcpyDeviceToHost));
-    memcpy(out->rng_py, rng, 2496);
-    memcpy(out->rng_np, rng + 624, 2496);
-    out->rng_py[624] = rng[1248];
-    out->rng_np[624] = rng[1249];
-    IIV_HIP(hipMemcpy(out->out_of_work, base + offsetof(StreamState, out_of_work), 8, hipMemcpyDeviceToHost));
-    IIV_HIP(hipMemcpy(out->priority_sum, e->d_brief, 24, hipMemcpyDeviceToHost));   // 2 x i64 | 2 x i32
+    IIV_HIP(hipMemcpy(out, e->d_brief, sizeof(iiv_video_brief), hipMemcpyDeviceToHost));
     return IIV_OK;
 }
 

@@ -37,6 +37,7 @@ device-side snapshot and rolled back + replayed if fewer were consumed.  Batched
 (what bench.py measures) goes through stream_batch.StreamBatch instead.
 """
 
+import ctypes
 import random
 from typing import Iterator, List, Tuple
 
@@ -46,6 +47,24 @@ import _iiv_native as native
 import screen
 from palette import Palette
 from video_mode import VideoMode
+
+_np_global = [None, None]
+
+
+def _np_rng_addr():
+    """Address of the process-wide np.random MT19937 state -- key[624] (u32) then pos (i32), the words np.random.get_state()
+    reports -- through numpy's own ctypes interface (BitGenerator.ctypes.state_address): reading and writing 2500 bytes there
+    costs under a microsecond where get_state() / set_state() cost ~50 each, twice per generator."""
+    bg = np.random.mtrand._rand._bit_generator
+    if _np_global[0] is not bg:
+        if type(bg).__name__ != "MT19937":
+            raise RuntimeError("np.random's global generator is not the MT19937 the reference draws from")
+        _np_global[0], _np_global[1] = bg, int(bg.ctypes.state_address)
+    return _np_global[1]
+
+
+def _np_rng_raw():
+    return ctypes.string_at(_np_rng_addr(), 2500)
 
 
 class Video:
@@ -61,9 +80,12 @@ class Video:
     #: opcodes.  Nothing observable depends on it (an assertion of the reference that would
     #: fire inside the unconsumed part of a chunk makes the generator fall back to exact
     #: stepping), only the speed does.
-    #: None (default): the longest generator movie.py's pacing produces -- DHGR 292 opcodes (2044 bytes of a 2 KiB socket frame
-    #: / 7, movie.py:139-148: a bank flip ends the generator), HGR a frame's worth (ticks_per_frame, video.py:64-70) -- so
-    #: that a Movie-paced generator is one launch (and in HGR usually exact: nothing to roll back).
+    #: None (default): the number of opcodes movie.py's pacing will pull from this generator, as far as this object can tell
+    #: from what the caller has shown it (_paced_chunk): tick() tells it the tick count, so the tick that starts the next
+    #: frame is known (video.py:64-70); a generator started for the other bank without a new frame was a bank flip, and the
+    #: next one comes 292 opcodes later (2044 bytes of a 2 KiB socket frame / 7, movie.py:139-148).  A right guess is one
+    #: launch and nothing to roll back; a wrong one costs a roll-back or a second launch, never a different opcode.
+    #: Without tick() calls: DHGR 292, HGR a frame's worth (ticks_per_frame).
     SPECULATE = None
 
     #: True: after every next() the host arrays and the *global* random / np.random states
@@ -134,6 +156,11 @@ class Video:
         self._rng_seen = None  # the global (random, np.random) states as this object last left or read them
         self._brief_fresh = False  # self._vb describes the device state as it stands
         self._dev_main = self._dev_aux = None   # the live generator's target on the device
+        # what the caller's pacing has shown so far (only the size of speculative launches depends on it)
+        self._tick_now = None     # the latest tick() argument
+        self._ops_done = 0        # opcodes consumed from settled chunks
+        self._flip_base = -1      # _ops_done at the last bank flip seen (movie.py's first socket frame holds 291 opcodes)
+        self._last_bank = None    # is_aux of the latest generator that ran
 
     # ---- the reference's public attributes; reading one settles any speculation first
     def _settled(name):  # noqa: N805
@@ -187,10 +214,26 @@ class Video:
 
     def tick(self, ticks: int) -> bool:
         """Keep track of when it is time for a new image frame (video.py:64-70)."""
+        self._tick_now = ticks
         if ticks >= (self.ticks_per_frame * self.frame_number):
             self.frame_number += 1
             return True
         return False
+
+    def _paced_chunk(self):
+        """How many opcodes a movie.py-paced caller will pull before it starts another generator (SPECULATE = None)."""
+        dhgr = self.mode == VideoMode.DHGR
+        n = 292 if dhgr else max(1, int(round(self.ticks_per_frame)))
+        if self._tick_now is not None:
+            # pulls at ticks _tick_now, _tick_now + 1, ... up to the tick in front of the one that starts a frame
+            to_frame = int(-(-(self.ticks_per_frame * self.frame_number) // 1)) - int(self._tick_now)
+            if to_frame >= 1:
+                n = to_frame if not dhgr else min(n, to_frame)
+        if dhgr:
+            to_flip = 292 - (self._ops_done - self._flip_base)
+            if 1 <= to_flip < n:
+                n = to_flip
+        return min(n, 2048)
 
     # ------------------------------------------------------------------ device sync
 
@@ -205,11 +248,9 @@ class Video:
             st.array("up_aux", np.int32, (32, 256))[...] = self._aux_update_priority
         py = random.getstate()[1]
         st.array("rng_py", np.uint32, (625,))[...] = py
-        nps = np.random.get_state()
-        rn = st.array("rng_np", np.uint32, (625,))
-        rn[:624] = nps[1]
-        rn[624] = nps[2]
-        self._rng_seen = (py, nps[1].tobytes(), int(nps[2]))
+        raw = _np_rng_raw()
+        st.array("rng_np", np.uint32, (625,))[...] = np.frombuffer(raw, dtype=np.uint32)
+        self._rng_seen = (py, raw)
         # movie.py:96 resets the flags at every frame
         st.out_of_work[0] = int(bool(self._out_of_work[False]))
         st.out_of_work[1] = int(bool(self._out_of_work[True]))
@@ -237,31 +278,25 @@ class Video:
 
     def _set_global_rng(self, st):
         """the device's random / np.random positions (st.rng_py, st.rng_np) become the process's"""
-        py = tuple(st.rng_py)
+        py = tuple(np.frombuffer(st.rng_py, dtype=np.uint32).tolist())
         random.setstate((3, py, None))
-        npw = np.frombuffer(st.rng_np, dtype=np.uint32)
-        nps = np.random.get_state()
-        key = npw[:624].copy()
-        np.random.set_state((nps[0], key, int(npw[624]), nps[3], nps[4]))
-        self._rng_seen = (py, key.tobytes(), int(npw[624]))
+        ctypes.memmove(_np_rng_addr(), st.rng_np, 2500)   # (has_gauss / cached_gaussian are the caller's: untouched)
+        self._rng_seen = (py, bytes(st.rng_np))
 
     def _global_rng_moved(self):
         """did anyone draw from / reseed random or np.random since this object last synchronised them?"""
         if self._rng_seen is None:
             return True
-        nps = np.random.get_state()
-        return (random.getstate()[1], nps[1].tobytes(), int(nps[2])) != self._rng_seen
+        return (random.getstate()[1], _np_rng_raw()) != self._rng_seen
 
     def _upload_rng(self):
         py = np.array(random.getstate()[1], dtype=np.uint32)
-        nps = np.random.get_state()
-        rn = np.empty(625, dtype=np.uint32)
-        rn[:624] = nps[1]
-        rn[624] = nps[2]
+        raw = _np_rng_raw()
+        rn = np.frombuffer(raw, dtype=np.uint32).copy()
         self._enc.set_state(native.STATE_RNG_PY, py)
         self._enc.set_state(native.STATE_RNG_NP, rn)
         self._brief_fresh = False
-        self._rng_seen = (tuple(int(x) for x in py), nps[1].tobytes(), int(nps[2]))
+        self._rng_seen = (tuple(py.tolist()), raw)
 
     def _sync_brief(self):
         """Settle the device state and bring home the small things: global RNG positions, out_of_work
@@ -295,6 +330,8 @@ class Video:
         """Make the device state -- and, with download, the host's -- reflect exactly the opcodes consumed so far."""
         p = self._pending
         self._pending = None
+        if p is not None:
+            self._ops_done += p["consumed"]
         if p is not None and p["consumed"] < p["produced"]:
             # abandoned mid-chunk: restore the snapshot and replay only what was consumed
             self._enc.rollback()
@@ -359,10 +396,9 @@ class Video:
             self._dev_aux = torch.empty((1, 1, 32, 256), dtype=torch.uint8, device="cuda") if token.aux is not None else None
         token.fm, token.fa = self._dev_main, self._dev_aux
         spec = self.SPECULATE
-        if spec is None:
-            spec = 292 if self.mode == VideoMode.DHGR else max(1, int(round(self.ticks_per_frame)))
-        chunk = int(budget) if budget else 1 if self.STRICT_SYNC else max(1, int(spec))
-        speculative = not budget and chunk > 1
+        paced = spec is None and not budget and not self.STRICT_SYNC
+        chunk = int(budget) if budget else 1 if self.STRICT_SYNC else max(1, int(spec)) if not paced else 0
+        speculative = paced or (not budget and chunk > 1)
         try:
             while True:
                 restart = 0 if self._live is token else 1
@@ -377,6 +413,12 @@ class Video:
                     self._upload()
                 elif restart and self._global_rng_moved():
                     self._upload_rng()  # someone drew from / reseeded random or np.random in between
+                if restart:
+                    if self._last_bank is not None and self._last_bank != token.is_aux:
+                        self._flip_base = self._ops_done  # (the previous generator is settled: _ops_done is exact)
+                    self._last_bank = token.is_aux
+                if paced and speculative:
+                    chunk = max(1, self._paced_chunk())
                 if restart:
                     self._dev_main.copy_(torch.from_numpy(token.main))
                     if token.aux is not None:
@@ -414,6 +456,9 @@ class Video:
                 else:
                     if rec is not None and self._pending is rec:
                         self._pending = None
+                        self._ops_done += len(rows)
+                    elif rec is None:
+                        self._ops_done += len(rows)
                 if not speculative:
                     chunk = 1
         except GeneratorExit:

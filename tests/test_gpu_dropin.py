@@ -324,7 +324,9 @@ def test_video_random_interleavings(O, oracle_tables, mode, seed, fourth, monkey
     L = O.lib()
     with contextlib.redirect_stdout(io.StringIO()):
         for step in range(40):
-            v.SPECULATE = int(rng.choice([0, 1, 7, 64, 256, 256]))
+            v.SPECULATE = [0, 1, 7, 64, 256, 256, None, None][int(rng.integers(0, 8))]
+            if rng.random() < 0.3:   # (None: the launch size follows tick(): any tick count must leave the opcodes alone)
+                v.tick(int(rng.integers(0, 4000)))
             # between generators: sometimes draw, sometimes reseed, sometimes reset the flags
             act = rng.random()
             if act < 0.15:
@@ -379,3 +381,72 @@ def test_video_random_interleavings(O, oracle_tables, mode, seed, fourth, monkey
     rp, rn = ov.rng_py(), ov.rng_np()
     assert [random.getrandbits(8) for _ in range(4)] == [L.orc_py_getrandbits8(C.byref(rp)) for _ in range(4)]
     assert np.random.randint(0, 256, size=4).tolist() == [L.orc_np_randint256(C.byref(rn)) for _ in range(4)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,n_frames", [(1, 4), (0, 3)])
+def test_movie_paced_generators_are_single_launches(O, oracle_tables, mode, n_frames):
+    """Driven exactly as movie.Movie.encode + emit_stream drive it (movie.py:56-150: tick() every audio sample, a new
+    generator per frame and per bank flip, one next() per sample), the default Video sizes every speculative launch to
+    what the caller then pulls: no roll-back, one launch per generator -- and the reference's opcodes."""
+    import palette
+    import screen
+    import stream_batch
+    import video
+    import video_mode
+    from test_gpu_encode import _synth
+    frames = _synth(mode, n_frames, 777, coherent=False)
+    random.seed(11)
+    np.random.seed(12)
+    pal = palette.Palette.NTSC
+    v = video.Video(_FG(), ticks_per_second=14700., mode=video_mode.VideoMode.DHGR if mode else video_mode.VideoMode.HGR, palette=pal)
+    assert v.SPECULATE is None
+    ov = O.Video(mode, oracle_tables.get(mode, 5), seed_py=11, seed_np=12)
+    calls = {"rollback": 0, "encode": 0}
+    rb, en = v._enc.rollback, v._enc.encode
+    v._enc.rollback = lambda *a, **k: (calls.__setitem__("rollback", calls["rollback"] + 1), rb(*a, **k))[1]
+    v._enc.encode = lambda *a, **k: (calls.__setitem__("encode", calls["encode"] + 1), en(*a, **k))[1]
+    segs = stream_batch.MovieClock(bool(mode)).segments(n_frames)
+    ticks, stream_pos, aux, last_bank = 0, 7, False, False
+    op_seq, target, got, pulled = None, None, [], []
+    with contextlib.redirect_stdout(io.StringIO()):
+        while True:
+            ticks += 1
+            if v.tick(ticks):
+                if v.frame_number - 1 >= n_frames:
+                    break
+                fi = v.frame_number - 1
+                if mode:
+                    target = screen.DHGRBitmap(main_memory=screen.MemoryMap(1, frames[fi, 0].copy()),
+                                               aux_memory=screen.MemoryMap(1, frames[fi, 1].copy()), palette=pal)
+                else:
+                    target = screen.HGRBitmap(main_memory=screen.MemoryMap(1, frames[fi, 0].copy()), palette=pal)
+                op_seq = v.encode_frame(target, is_aux=aux)
+                v.out_of_work = {True: False, False: False}
+                pulled.append([fi, int(aux), 0])
+            if aux != last_bank:
+                last_bank = aux
+                op_seq = v.encode_frame(target, is_aux=aux)
+                if pulled[-1][2]:
+                    pulled.append([pulled[-1][0], int(aux), 0])
+                else:
+                    pulled[-1][1] = int(aux)
+            page, content, offsets = next(op_seq)
+            got.append([page, content] + list(offsets))
+            pulled[-1][2] += 1
+            stream_pos += 7
+            if stream_pos % 2048 >= 2044:
+                if mode:
+                    aux = not aux
+                stream_pos += 4
+    assert [tuple(p) for p in pulled] == [(f, a, k) for (f, a, _, k) in segs]
+    want, prev = [], None
+    for (f, a, _, k) in segs:
+        if f != prev:
+            ov.reset_out_of_work()    # movie.py:96
+            prev = f
+        ov.encode_frame(frames[f, 0], frames[f, 1] if mode else None, int(a))
+        want.append(ov.next(k))
+    assert (np.array(got, np.uint8) == np.concatenate(want)).all()
+    assert calls["rollback"] == 0, calls
+    assert calls["encode"] == len(segs), (calls, len(segs))

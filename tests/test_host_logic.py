@@ -234,3 +234,23 @@ def test_movie_clock_against_a_tick_by_tick_walk():
             if clock.ticks == before:     # nothing left to do: the clip has ended
                 break
         assert stream_batch.merge_generators(parts) == want, (trial, "sliced", dhgr, tps, fps, every_n, n_frames, n_audio)
+
+
+def test_np_random_state_words_read_and_written_in_place():
+    """video.Video reads / writes np.random's global MT19937 words through numpy's ctypes interface instead of
+    get_state() / set_state(): the same 625 words, and the cached-gaussian part of the legacy state is left alone."""
+    import ctypes
+    import video
+    np.random.seed(77)
+    np.random.standard_normal()          # leaves has_gauss = 1
+    st = np.random.get_state()
+    raw = video._np_rng_raw()
+    assert raw[:2496] == st[1].tobytes() and int.from_bytes(raw[2496:], "little") == st[2]
+    a = np.random.randint(0, 256, size=700).tolist()      # crosses a block boundary
+    assert video._np_rng_raw() != raw
+    ctypes.memmove(video._np_rng_addr(), raw, 2500)
+    st2 = np.random.get_state()
+    assert (st2[1] == st[1]).all() and st2[2:] == st[2:] and st2[3] == 1
+    assert np.random.randint(0, 256, size=700).tolist() == a
+    np.random.seed(78)                   # reseeding keeps the generator object: the address stays valid
+    assert video._np_rng_raw()[:2496] == np.random.get_state()[1].tobytes()
