@@ -119,9 +119,10 @@ def parse_args(argv=None):
                     help="how the prologue obtains the diff weights (same values): the recurrence in the kernel, two "
                          "gathers from the split table, or one gather from the full table in HBM")
     ap.add_argument("--dw-table", action="store_true", help="same as --dw table")
-    ap.add_argument("--joint", action="store_true",
+    ap.add_argument("--joint", nargs="?", const=True, default=False, choices=[True, "split"],
                     help="SURVEY 8(f4): choose every step's content byte jointly with its extra offsets "
-                         "(IIV_CONTENT_JOINT; NOT the reference's output -- not the BASELINE workload)")
+                         "(IIV_CONTENT_JOINT; NOT the reference's output -- not the BASELINE workload); "
+                         "`--joint split`: the second implementation (IIV_CONTENT_JOINT_SPLIT)")
     ap.add_argument("--fourth", action="store_true",
                     help="SURVEY 8(f4): up to three extra offsets per opcode instead of two and a copy of the first "
                          "(IIV_OPT_FOURTH_OFFSET; NOT the reference's output -- not the BASELINE workload)")
@@ -792,8 +793,8 @@ def _hgr_leg(be, args, local_rank, world, steps=6, warmup=1, mode="HGR", fourth=
         out["greedy_form"] = form
     if joint:
         out["note"] = ("IIV_CONTENT_JOINT (SURVEY 8 f4, README.md:212-215): every step's content byte chosen jointly with its extra "
-                       "offsets -- 128 x the lookups of a reference step, the 256-thread workgroup kernel; NOT the reference's stream, "
-                       "off by default")
+                       "offsets -- 128 x the lookups of a reference step, two byte values per packed 16-bit instruction in the "
+                       "256-thread workgroup kernel (DESIGN.md 7b); NOT the reference's stream, off by default")
     elif fourth:
         o = leg["first_ops"][0].cpu().numpy().reshape(-1, 6)[:, 2:6]
         o.sort(axis=1)

@@ -65,7 +65,8 @@ struct Encoder {
     uint32_t *d_left, *d_right;  // split store table (iiv_stream.h), built at creation when dm is given
     NarrowTables nt;             // the narrow form of the split store table the greedy kernels read (iiv_stream.h)
     uint32_t *d_dwl, *d_dwr;     // split diff-weight table, likewise
-    uint32_t *d_left_t, *d_right_t;  // split store table, content innermost (joint content choice; built on first use)
+    uint32_t *d_left_t, *d_right_t;  // split store table, content innermost (IIV_CONTENT_JOINT_SPLIT; built on first use)
+    uint32_t *d_joint_l, *d_joint_r; // narrow form, content innermost, two byte values per word (IIV_CONTENT_JOINT; built on first use)
     void *d_brief;                   // iiv_encoder_get_video_brief's staging struct
     ulonglong2 *d_strings;  // colour string of every masked value (recurrence mode)
     uint2 *d_hgr_slut;      // HGR: the three-lookup string table the prologue copies into LDS (iiv_edit.h)
@@ -265,6 +266,8 @@ void encoder_destroy(Encoder *e)
     free_narrow_tables(&e->nt);
     if (e->d_dwl) (void)hipFree(e->d_dwl);
     if (e->d_left_t) (void)hipFree(e->d_left_t);
+    if (e->d_joint_l) (void)hipFree(e->d_joint_l);
+    if (e->d_joint_r) (void)hipFree(e->d_joint_r);
     if (e->d_brief) (void)hipFree(e->d_brief);
     if (e->d_right_t) (void)hipFree(e->d_right_t);
     if (e->d_dwr) (void)hipFree(e->d_dwr);
@@ -301,6 +304,7 @@ int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, c
     e->nt.exact = 0;
     e->d_dwl = e->d_dwr = nullptr;
     e->d_left_t = e->d_right_t = nullptr;
+    e->d_joint_l = e->d_joint_r = nullptr;
     e->d_brief = nullptr;
     e->d_states = e->d_snapshot = nullptr;
     e->d_strings = nullptr;
@@ -461,13 +465,21 @@ int encoder_set_option(Encoder *e, int option, int value)
         return IIV_OK;
     }
     if (option == IIV_OPT_CONTENT_CHOICE) {
-        if (value != IIV_CONTENT_TARGET && value != IIV_CONTENT_JOINT) return set_error(IIV_ERR_INVALID, "bad value");
-        if (value == IIV_CONTENT_JOINT && !e->d_left)
+        if (value != IIV_CONTENT_TARGET && value != IIV_CONTENT_JOINT && value != IIV_CONTENT_JOINT_SPLIT)
+            return set_error(IIV_ERR_INVALID, "bad value");
+        if (value != IIV_CONTENT_TARGET && !e->d_left)
             return set_error(IIV_ERR_INVALID, "the joint content choice reads the split store table, which is built "
                                                "from dm (none was given at creation)");
-        if (value == IIV_CONTENT_JOINT && e->fourth_offset)
+        if (value != IIV_CONTENT_TARGET && e->fourth_offset)
             return set_error(IIV_ERR_INVALID, "the joint content choice and the fourth offset are not implemented together");
-        if (value == IIV_CONTENT_JOINT && !e->d_left_t) {
+        // (a store table that the narrow form does not reproduce -- not the one dm yields -- leaves only the split-table form)
+        if (value == IIV_CONTENT_JOINT && !e->nt.exact) value = IIV_CONTENT_JOINT_SPLIT;
+        if (value == IIV_CONTENT_JOINT && !e->d_joint_l) {
+            int rc = build_joint_tables(e->mode, e->nt, &e->d_joint_l, &e->d_joint_r, 0);
+            if (rc) return rc;
+            IIV_HIP(hipDeviceSynchronize());
+        }
+        if (value == IIV_CONTENT_JOINT_SPLIT && !e->d_left_t) {
             IIV_HIP(hipMalloc(&e->d_left_t, split_entries(e->mode, 0) * 4));
             IIV_HIP(hipMalloc(&e->d_right_t, split_entries(e->mode, 1) * 4));
             int rc = transpose_split_tables(e->mode, e->d_left, e->d_right, e->d_left_t, e->d_right_t, 0);
@@ -482,7 +494,7 @@ int encoder_set_option(Encoder *e, int option, int value)
         if (value && (!e->d_left || !e->nt.exact))
             return set_error(IIV_ERR_INVALID, "the fourth offset runs in the one-wave kernel, which reads the split store table "
                                                "built from dm (none was given at creation, or it does not reproduce the store table given)");
-        if (value && e->content_choice == IIV_CONTENT_JOINT)
+        if (value && e->content_choice != IIV_CONTENT_TARGET)
             return set_error(IIV_ERR_INVALID, "the joint content choice and the fourth offset are not implemented together");
         e->fourth_offset = value;
         return IIV_OK;
@@ -972,9 +984,10 @@ static int launch_round(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux,
         if (rc) return rc;
         if (e->profiling) e->form_launches[use_team ? 2 : form]++;
     } else {
-        const WorkgroupArgs wa{e->d_states, d_main, d_aux, n_frames, e->n_streams, d_round, seg_stride, e->d_store, e->d_left_t,
-                               e->d_right_t, d_ops, ops_stride};
-        int wrc = launch_greedy_workgroup(e->mode, e->content_choice == IIV_CONTENT_JOINT, wa, st);
+        const bool packed = e->content_choice == IIV_CONTENT_JOINT;
+        const WorkgroupArgs wa{e->d_states, d_main, d_aux, n_frames, e->n_streams, d_round, seg_stride, e->d_store,
+                               packed ? e->d_joint_l : e->d_left_t, packed ? e->d_joint_r : e->d_right_t, d_ops, ops_stride};
+        int wrc = launch_greedy_workgroup(e->mode, packed ? 2 : e->content_choice == IIV_CONTENT_JOINT_SPLIT ? 1 : 0, wa, st);
         if (wrc) return wrc;
         if (e->profiling) e->form_launches[3]++;
     }

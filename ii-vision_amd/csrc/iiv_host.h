@@ -46,6 +46,8 @@ int build_narrow_store_table(int mode, const int32_t dm[256], const uint16_t *d_
                              unsigned long long *n_mismatch, hipStream_t st);
 int transpose_split_tables(int mode, const uint32_t *d_left, const uint32_t *d_right, uint32_t *d_left_t,
                            uint32_t *d_right_t, hipStream_t st);
+struct NarrowTables;
+int build_joint_tables(int mode, const NarrowTables &nt, uint32_t **d_jl, uint32_t **d_jr, hipStream_t st);
 size_t split_dw_entries(int mode, int right);
 int build_split_dw_tables(int mode, const ulonglong2 *d_strings, const uint16_t *d_sub, uint32_t *d_left, uint32_t *d_right,
                           hipStream_t st);

@@ -202,6 +202,18 @@ template <int MODE> __host__ __device__ constexpr size_t narrow_total_bytes()
 {
     return narrow_right_off<MODE>() + split_right_entries<MODE>() * 2;
 }
+// the narrow form with content innermost, two byte values per word (iiv_tables.hip: joint_pack_kernel)
+template <int MODE> struct JointPack {
+    static constexpr int kPairs = (1 << ModeTraits<MODE>::kContentBits) / 128;   // words per lane and row: DHGR 1, HGR 2
+};
+template <int MODE> __host__ __device__ constexpr size_t joint_left_entries()
+{
+    return ((size_t)ModeTraits<MODE>::kOffsets << SplitTraits<MODE>::kLeftRowBits) * JointPack<MODE>::kPairs * 64;
+}
+template <int MODE> __host__ __device__ constexpr size_t joint_right_entries()
+{
+    return ((size_t)ModeTraits<MODE>::kOffsets << SplitTraits<MODE>::kRightRowBits) * JointPack<MODE>::kPairs * 64;
+}
 // the window back from its two rows
 template <int MODE> __host__ __device__ inline uint32_t split_window_from_rows(uint32_t row_left, uint32_t row_right, int odd)
 {
@@ -394,10 +406,12 @@ struct WorkgroupArgs {
     const LaunchSeg *segs;
     int seg_stride;
     const uint16_t *store;                 // dense store table
-    const uint32_t *left_t, *right_t;      // split store table, content-innermost (joint content choice)
+    const uint32_t *left_t, *right_t;      // joint content choice: the narrow form packed two byte values per word (joint == 2:
+                                           // joint_pack_kernel) or the two-component split table, content innermost (joint == 1)
     uint8_t *ops_out;
     size_t ops_stride;
 };
-int launch_greedy_workgroup(int mode, bool joint, const WorkgroupArgs &a, hipStream_t st);
+// joint: 0 = the reference's content byte, 1 / 2 = the joint content choice scored from the split table / from the packed narrow form
+int launch_greedy_workgroup(int mode, int joint, const WorkgroupArgs &a, hipStream_t st);
 
 }  // namespace iiv

@@ -456,6 +456,52 @@ int transpose_split_tables(int mode, const uint32_t *d_left, const uint32_t *d_r
     return hip_check(hipGetLastError(), "split_transpose_kernel launch");
 }
 
+// The narrow form with content innermost and two byte values per word, for the joint content choice's packed scoring
+// (iiv_workgroup.hip, greedy_kernel<MODE, 2>): lane l of a wave scores byte values l + 128 j (low half) and l + 128 j + 64
+// (high half), j < kPairs, so
+//     JL[o][row][j][l] = L1[o][left part of l + 128 j][row] | L1[o][left part of l + 128 j + 64][row] << 16
+// and JR likewise from RF: the values of every byte value for one byte of the page are 2 x kPairs coalesced 256-byte
+// loads, and v_pk_add_u16 adds both halves at once.
+template <int MODE>
+__global__ __launch_bounds__(256) void joint_pack_kernel(const uint8_t *__restrict__ narrow, uint32_t right_off,
+                                                         uint32_t *__restrict__ jl, uint32_t *__restrict__ jr)
+{
+    using T = SplitTraits<MODE>;
+    constexpr int NP = JointPack<MODE>::kPairs;
+    const size_t nl = joint_left_entries<MODE>(), nr = joint_right_entries<MODE>();
+    size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool is_left = idx < nl;
+    if (!is_left) idx -= nl;
+    if (!is_left && idx >= nr) return;
+    const int rb = is_left ? T::kLeftRowBits : T::kRightRowBits, cb = is_left ? T::kLeftCBits : T::kRightCBits;
+    const uint32_t l = idx & 63u, j = (uint32_t)(idx >> 6) % NP;
+    const size_t orow = (idx >> 6) / NP;
+    const uint32_t row = (uint32_t)(orow & ((1u << rb) - 1));
+    const int o = (int)(orow >> rb), od = MODE == kDHGR ? o >> 1 : o;   // (byte_offset: the parity of the page offset)
+    const uint16_t *half = reinterpret_cast<const uint16_t *>(narrow + (is_left ? 0u : right_off));
+    uint32_t v = 0;
+    for (int h = 0; h < 2; h++) {
+        const uint32_t c = l + 128u * j + 64u * (uint32_t)h;
+        const uint32_t part = is_left ? split_content_left<MODE>(c, od) : split_content_right<MODE>(c, od);
+        v |= (uint32_t)half[((((size_t)o << cb) + part) << rb) + row] << (16 * h);
+    }
+    (is_left ? jl : jr)[idx] = v;
+}
+
+int build_joint_tables(int mode, const NarrowTables &nt, uint32_t **d_jl, uint32_t **d_jr, hipStream_t st)
+{
+    const size_t nl = mode == kDHGR ? joint_left_entries<kDHGR>() : joint_left_entries<kHGR>();
+    const size_t nr = mode == kDHGR ? joint_right_entries<kDHGR>() : joint_right_entries<kHGR>();
+    IIV_HIP(hipMalloc(d_jl, nl * 4));
+    IIV_HIP(hipMalloc(d_jr, nr * 4));
+    const dim3 grid((unsigned)((nl + nr + 255) / 256));
+    if (mode == kDHGR)
+        hipLaunchKernelGGL(joint_pack_kernel<kDHGR>, grid, dim3(256), 0, st, nt.base, nt.right_off, *d_jl, *d_jr);
+    else
+        hipLaunchKernelGGL(joint_pack_kernel<kHGR>, grid, dim3(256), 0, st, nt.base, nt.right_off, *d_jl, *d_jr);
+    return hip_check(hipGetLastError(), "joint_pack_kernel launch");
+}
+
 // The halves of the diff-weight table (iiv_stream.h): the same recurrence between two arbitrary
 // windows, each built from its row part alone.
 template <int MODE>

@@ -18,10 +18,13 @@ constexpr int kChunk = 8;  // initial-list entries whose store-table rows are ga
 //     R(c) = (dw[primary] - nd_c[primary]) - (d1 + d2),
 // d1, d2 = the two smallest negative deltas nd_c[y] - dw[y] among the page's other bytes with non-zero
 // priority (ties: the target byte, then the smallest c), and the primary keeps nd_c[primary] as its
-// priority.  All else is the reference's step applied to the chosen byte.  Each wave scores a quarter
-// of the byte values over the whole page (4 bytes per lane), two wave minima per value.
-template <int MODE, bool JOINT>
-__global__ __launch_bounds__(256) void greedy_kernel(StreamState *__restrict__ states,
+// priority.  All else is the reference's step applied to the chosen byte.  Every wave scores all byte values against
+// the eligible bytes of its quarter of the page.  JOINT == 2 (default): from the narrow form packed two byte values per
+// word (iiv_tables.hip: joint_pack_kernel) with packed 16-bit arithmetic -- two loads and five vector instructions per
+// byte of the page and PAIR of byte values; JOINT == 1: from the two-component split table, one byte value at a time
+// (round 2's form, kept as the independent second implementation: IIV_CONTENT_JOINT_SPLIT).
+template <int MODE, int JOINT>
+__global__ __launch_bounds__(256, JOINT ? 5 : 1) void greedy_kernel(StreamState *__restrict__ states,
                                                      const uint8_t *__restrict__ frames_main,
                                                      const uint8_t *__restrict__ frames_aux, int n_frames,
                                                      const LaunchSeg *__restrict__ segs, int seg_stride,
@@ -39,7 +42,11 @@ __global__ __launch_bounds__(256) void greedy_kernel(StreamState *__restrict__ s
     constexpr int CB = ModeTraits<MODE>::kContentBits;
     constexpr int NB = ModeTraits<MODE>::kBanks;
     constexpr uint32_t INF = 0xffffffffu;
-    __shared__ __attribute__((aligned(16))) uint8_t tgt[NB][8192];  // [0] = bank being encoded, [1] = the other one
+    // target bytes, [0] = bank being encoded, [1] = the other one.  JOINT: read where they lie (a step looks at two rows of them
+    // against 32768 table values): without their 16 KiB five workgroups fit a CU instead of four, and the joint step is short
+    // of waves, not of bandwidth
+    constexpr bool kTgtLds = !JOINT;
+    __shared__ __attribute__((aligned(16))) uint8_t tgt_lds[kTgtLds ? NB : 1][kTgtLds ? 8192 : 16];
     __shared__ __attribute__((aligned(16))) uint16_t dwf[8192];     // diff_weight | (priority != 0) << 15
     __shared__ uint32_t mt[2][624];
     __shared__ uint32_t xw_cnt[4];
@@ -61,14 +68,22 @@ __global__ __launch_bounds__(256) void greedy_kernel(StreamState *__restrict__ s
     }
 
     // ---- stage target bytes, diff weights + validity flags, sorted order, RNG block
-    for (int i = tid; i < 512 * NB; i += 256) {
-        int b = i >> 9, k = i & 511;
-        const uint8_t *src;
-        if (MODE == kDHGR)
-            src = ((b == 0) == (is_aux != 0) ? frames_aux : frames_main) + fbase;
-        else
-            src = frames_main + fbase;
-        reinterpret_cast<uint4 *>(tgt[b])[k] = reinterpret_cast<const uint4 *>(src)[k];
+    const uint8_t *tgt[2];
+    if constexpr (kTgtLds) {
+        for (int i = tid; i < 512 * NB; i += 256) {
+            int b = i >> 9, k = i & 511;
+            const uint8_t *src;
+            if (MODE == kDHGR)
+                src = ((b == 0) == (is_aux != 0) ? frames_aux : frames_main) + fbase;
+            else
+                src = frames_main + fbase;
+            reinterpret_cast<uint4 *>(tgt_lds[b])[k] = reinterpret_cast<const uint4 *>(src)[k];
+        }
+        tgt[0] = tgt_lds[0];
+        tgt[1] = tgt_lds[NB - 1];
+    } else {
+        tgt[0] = (MODE == kDHGR && is_aux ? frames_aux : frames_main) + fbase;
+        tgt[1] = (MODE == kDHGR ? (is_aux ? frames_main : frames_aux) : frames_main) + fbase;
     }
     for (int i = tid; i < 8192; i += 256) {
         uint32_t bit = (S.nzbits[i >> 5] >> (i & 31)) & 1u;
@@ -222,7 +237,82 @@ __global__ __launch_bounds__(256) void greedy_kernel(StreamState *__restrict__ s
             const int dw_m = (int)(wv & 0x7fffu);
             // (a byte with priority 0, the primary itself, or a zero diff weight can never yield d < 0)
             unsigned long long todo = __ballot((wv & 0x8000u) && ym != x && dw_m != 0);
+            typedef short v2s __attribute__((ext_vector_type(2)));
+            constexpr int NP = JointPack<MODE>::kPairs;
+            // JOINT == 2: the packed words of every byte value for the byte with window `win` at parity `od`: lane l gets the
+            // sums L1 + RF (= store value + kNarrowBias) of byte values l + 128 j (low half) and l + 128 j + 64 (high half)
+            auto row_packed = [&](uint32_t win, int yy, v2s (&nd)[NP]) {
+                const int od = yy & 1, o = byte_offset<MODE>(yy, is_aux);
+                const uint32_t *lrow = left_t + ((((size_t)o << T::kLeftRowBits) + split_row_left<MODE>(win, od)) * NP) * 64 + lane;
+                const uint32_t *rrow = right_t + ((((size_t)o << T::kRightRowBits) + split_row_right<MODE>(win, od)) * NP) * 64 + lane;
+#pragma unroll
+                for (int j = 0; j < NP; j++) nd[j] = __builtin_bit_cast(v2s, lrow[64 * j]) + __builtin_bit_cast(v2s, rrow[64 * j]);
+            };
             int m1[NS], m2[NS];  // per byte value: the two smallest negative deltas (m1 <= m2 <= 0)
+            if constexpr (JOINT == 2) {
+                // per lane, once per step: where the rows of its byte of the quarter start (byte offsets into the two packed
+                // tables) and its diff weight plus the bias of the sums -- a trip then needs three v_readlane per byte and no
+                // address arithmetic: the loads are buffer loads, row offset in a scalar register, 4 * lane in the vector one
+                const int od_m = ym & 1, o_m = byte_offset<MODE>(ym, is_aux);
+                const uint32_t lo_m = (uint32_t)((((size_t)o_m << T::kLeftRowBits) + split_row_left<MODE>(win_m, od_m)) * NP) << 8;
+                const uint32_t ro_m = (uint32_t)((((size_t)o_m << T::kRightRowBits) + split_row_right<MODE>(win_m, od_m)) * NP) << 8;
+                const int db_m = dw_m + (int)kNarrowBias;   // (diff weights are < 2^12: iiv_stream.h, kWdDwShift)
+                const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc((void *)left_t, 0, (int)(joint_left_entries<MODE>() * 4), 0x00020000);
+                const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)right_t, 0, (int)(joint_right_entries<MODE>() * 4), 0x00020000);
+                v2s q1[NP], q2[NP];
+#pragma unroll
+                for (int j = 0; j < NP; j++) q1[j] = q2[j] = v2s{0, 0};
+#ifndef IIV_JOINT_U
+#define IIV_JOINT_U 8
+#endif
+                constexpr int U = IIV_JOINT_U / NP;   // bytes per trip, their rows in flight together
+                auto score = [&](const int (&lo)[U], const int (&ro)[U], const int (&db)[U]) {
+                    v2s nd[U][NP];
+#pragma unroll
+                    for (int u = 0; u < U; u++)
+#pragma unroll
+                        for (int j = 0; j < NP; j++)
+                            nd[u][j] = __builtin_bit_cast(v2s, __builtin_amdgcn_raw_buffer_load_b32(rs_l, 4 * lane + 256 * j, lo[u], 0)) +
+                                       __builtin_bit_cast(v2s, __builtin_amdgcn_raw_buffer_load_b32(rs_r, 4 * lane + 256 * j, ro[u], 0));
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const short b = (short)db[u];
+                        const v2s bb = v2s{b, b};
+#pragma unroll
+                        for (int j = 0; j < NP; j++) {
+                            const v2s d = nd[u][j] - bb;
+                            const v2s lo2 = __builtin_elementwise_min(d, q1[j]), hi2 = __builtin_elementwise_max(d, q1[j]);
+                            q1[j] = lo2;
+                            q2[j] = __builtin_elementwise_min(hi2, q2[j]);
+                        }
+                    }
+                };
+                while (todo) {
+                    // (a missing byte repeats the first with diff weight 0: d >= 0 changes nothing.  Walking all 64 bytes of the
+                    // quarter without the mask bookkeeping was measured: no faster, DHGR, and 7 % slower, HGR)
+                    int lo[U], ro[U], db[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        if (todo) {
+                            const int k = __builtin_ctzll(todo);
+                            todo &= todo - 1;
+                            lo[u] = __builtin_amdgcn_readlane((int)lo_m, k);
+                            ro[u] = __builtin_amdgcn_readlane((int)ro_m, k);
+                            db[u] = __builtin_amdgcn_readlane(db_m, k);
+                        } else {
+                            lo[u] = lo[0];
+                            ro[u] = ro[0];
+                            db[u] = (int)kNarrowBias;
+                        }
+                    }
+                    score(lo, ro, db);
+                }
+#pragma unroll
+                for (int j = 0; j < NP; j++) {
+                    m1[2 * j] = q1[j].x, m1[2 * j + 1] = q1[j].y;
+                    m2[2 * j] = q2[j].x, m2[2 * j + 1] = q2[j].y;
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < NS; j++) m1[j] = m2[j] = 0;
             while (todo) {
@@ -258,6 +348,7 @@ __global__ __launch_bounds__(256) void greedy_kernel(StreamState *__restrict__ s
                         m2[j] = hi < m2[j] ? hi : m2[j];
                     }
             }
+            }
 #pragma unroll
             for (int j = 0; j < NS; j++) xw_m12[wave][lane + 64 * j] = (uint32_t)(uint16_t)m1[j] | ((uint32_t)(uint16_t)m2[j] << 16);
             // the primary's own byte (uniform)
@@ -265,7 +356,17 @@ __global__ __launch_bounds__(256) void greedy_kernel(StreamState *__restrict__ s
             if (wave == (x >> 6) && lane == 0) xw_joint[0] = (int)winx;
             __syncthreads();
             int ndx[NS];
-            row_values((uint32_t)xw_joint[0], x, ndx);
+            if constexpr (JOINT == 2) {
+                v2s nx2[NP];
+                row_packed((uint32_t)xw_joint[0], x, nx2);
+#pragma unroll
+                for (int j = 0; j < NP; j++) {
+                    ndx[2 * j] = (int)nx2[j].x - (int)kNarrowBias;
+                    ndx[2 * j + 1] = (int)nx2[j].y - (int)kNarrowBias;
+                }
+            } else {
+                row_values((uint32_t)xw_joint[0], x, ndx);
+            }
             const int dwx = (int)(dwf[p * 256 + x] & 0x7fffu);
             int best = -2147483647 - 1;
 #pragma unroll
@@ -464,15 +565,17 @@ __global__ __launch_bounds__(256) void greedy_kernel(StreamState *__restrict__ s
         if (err && S.error == 0) S.error = err;
     }
 }
-int launch_greedy_workgroup(int mode, bool joint, const WorkgroupArgs &a, hipStream_t st)
+int launch_greedy_workgroup(int mode, int joint, const WorkgroupArgs &a, hipStream_t st)
 {
 #define IIV_GREEDY(K)                                                                                                     \
     hipLaunchKernelGGL(K, dim3(a.n_streams), dim3(256), 0, st, a.states, a.frames_main, a.frames_aux, a.n_frames, a.segs, \
                        a.seg_stride, a.store, a.left_t, a.right_t, a.ops_out, a.ops_stride)
-    if (joint) {
-        if (mode == kDHGR) IIV_GREEDY((greedy_kernel<kDHGR, true>)); else IIV_GREEDY((greedy_kernel<kHGR, true>));
+    if (joint == 2) {
+        if (mode == kDHGR) IIV_GREEDY((greedy_kernel<kDHGR, 2>)); else IIV_GREEDY((greedy_kernel<kHGR, 2>));
+    } else if (joint) {
+        if (mode == kDHGR) IIV_GREEDY((greedy_kernel<kDHGR, 1>)); else IIV_GREEDY((greedy_kernel<kHGR, 1>));
     } else {
-        if (mode == kDHGR) IIV_GREEDY((greedy_kernel<kDHGR, false>)); else IIV_GREEDY((greedy_kernel<kHGR, false>));
+        if (mode == kDHGR) IIV_GREEDY((greedy_kernel<kDHGR, 0>)); else IIV_GREEDY((greedy_kernel<kHGR, 0>));
     }
 #undef IIV_GREEDY
     return hip_check(hipGetLastError(), "greedy_kernel launch");

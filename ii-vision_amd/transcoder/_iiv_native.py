@@ -26,7 +26,7 @@ OPT_GREEDY_KERNEL, GREEDY_WAVE, GREEDY_WORKGROUP, GREEDY_AUTO, GREEDY_TEAM = 2, 
 GREEDY_WAVE_SHARED, GREEDY_WAVE_PLAIN = 4, 5
 OPT_PREFIX_SORT = 3
 OPT_GREEDY_LDS_PAD = 5
-OPT_CONTENT_CHOICE, CONTENT_TARGET, CONTENT_JOINT = 6, 0, 1
+OPT_CONTENT_CHOICE, CONTENT_TARGET, CONTENT_JOINT, CONTENT_JOINT_SPLIT = 6, 0, 1, 2
 OPT_FOURTH_OFFSET = 7
 OPT_STREAM_ORDER = 8
 
@@ -461,8 +461,10 @@ class Encoder:
     def set_content_choice(self, joint):
         """False (default): the reference's greedy step.  True: the content byte of every step is
         chosen jointly with its extra offsets (include/iivision.h: IIV_CONTENT_JOINT) -- the
-        reference README's "global optimization" idea, NOT the reference's output."""
-        check(lib().iiv_encoder_set_option(self._h, OPT_CONTENT_CHOICE, CONTENT_JOINT if joint else CONTENT_TARGET))
+        reference README's "global optimization" idea, NOT the reference's output.  "split": the same choice
+        computed by the slower second implementation (IIV_CONTENT_JOINT_SPLIT)."""
+        value = CONTENT_JOINT_SPLIT if joint == "split" else CONTENT_JOINT if joint else CONTENT_TARGET
+        check(lib().iiv_encoder_set_option(self._h, OPT_CONTENT_CHOICE, value))
 
     def set_fourth_offset(self, enable):
         """f4: up to three extra offsets per opcode instead of two and a copy of the first (the reference's exit test

@@ -235,7 +235,7 @@ class StreamBatch:
         self.use_torch_ops = bool(use_torch_ops)
         self.enc = native.Encoder(mode, table, store_table, self.n_streams, dm=dm)
         if joint_content:
-            self.enc.set_content_choice(True)
+            self.enc.set_content_choice(joint_content)   # (True, or "split" for the second implementation)
         if fourth_offset:
             self.enc.set_fourth_offset(True)
         self.clock = MovieClock(mode == native.DHGR, **clock_kw)

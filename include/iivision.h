@@ -232,7 +232,11 @@ void iiv_encoder_destroy(iiv_encoder *enc);
                                   *   scored against the target's neighbours, screen.py:542-545), so a joint step never
                                   *   removes less by that accounting; measured on the screen itself a single step may, a
                                   *   frame of them does not (tests/test_gpu_joint.py).  128 / 256 times the lookups of a reference step; runs in the
-                                  *   workgroup greedy kernel whatever IIV_OPT_GREEDY_KERNEL says. */
+                                  *   workgroup greedy kernel whatever IIV_OPT_GREEDY_KERNEL says, two byte values per
+                                  *   instruction (packed 16-bit sums of the narrow split table). */
+#define IIV_CONTENT_JOINT_SPLIT 2 /*  the same choice, byte for byte, computed one byte value at a time from the two-component
+                                  *   split table: the slower, independent second implementation (what IIV_CONTENT_JOINT
+                                  *   falls back to when the store table given is not the one dm yields). */
 #define IIV_OPT_FOURTH_OFFSET 7  /* 0 (default, the reference) / 1: a real fourth offset per opcode.  NOT reference behaviour.
                                   * The player stores every opcode's content byte at FOUR offsets, and video.py:146 says
                                   * "Need to find 3 more offsets to fill this opcode", but the loop's exit test

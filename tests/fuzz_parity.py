@@ -67,7 +67,7 @@ for rnd in range(rounds):
     # one round in five of the others: a real fourth offset per opcode (IIV_OPT_FOURTH_OFFSET), against the oracle's flag
     fourth = bool(not joint and rng.random() < 0.2)
     enc = native.Encoder(mode, dtab[key][0], dtab[key][1], n, dm=dms[pal])
-    enc.set_content_choice(joint)
+    enc.set_content_choice("split" if joint and rng.random() < 0.3 else joint)   # (both implementations of the joint choice)
     enc.set_fourth_offset(fourth)
     enc.set_diff_weights_mode(recurrence)
     enc.set_greedy_kernel(wave)

@@ -39,16 +39,18 @@ def _oracle(O, oracle_tables, mode, frames, sched, sp, sn, joint):
     return v, np.concatenate(out)
 
 
+@pytest.mark.parametrize("impl", [True, "split"])
 @pytest.mark.parametrize("mode", [1, 0])
-def test_joint_steps_equal_the_definition(native, O, oracle_tables, device_tables, mode):
+def test_joint_steps_equal_the_definition(native, O, oracle_tables, device_tables, mode, impl):
     """Four streams (iid and coherent data), generators on both banks, a continued frame: opcodes,
     memory maps, priorities (the primary keeps its residual), packed screen and both RNG positions
-    equal the oracle's joint run."""
+    equal the oracle's joint run -- both implementations (packed 16-bit sums of the narrow form, IIV_CONTENT_JOINT;
+    the two-component split table one byte value at a time, IIV_CONTENT_JOINT_SPLIT)."""
     n = 4
     sched = [(0, 0, 60), (0, 1 if mode == 1 else 0, 45), (1, 0, 70), (1, 1 if mode == 1 else 0, 1), (2, 0, 40)]
     frames = [_synth(mode, 3, 300 + i, coherent=(i % 2 == 1)) for i in range(n)]
     seeds = [(i + 5, 70 + i) for i in range(n)]
-    enc, got = _device(native, device_tables, mode, frames, sched, seeds, O, True)
+    enc, got = _device(native, device_tables, mode, frames, sched, seeds, O, impl)
     differs_from_greedy = 0
     for i in range(n):
         v, exp = _oracle(O, oracle_tables, mode, frames[i], sched, *seeds[i], True)
@@ -105,8 +107,8 @@ def test_joint_leaves_less_error_per_opcode(native, O, device_tables, mode):
     assert 0.01 < gain < 0.2, gain
 
 
-@pytest.mark.parametrize("mode,ops", [(1, 6000), (0, 4500)])
-def test_joint_runs_past_the_list_into_the_bag(native, O, oracle_tables, device_tables, mode, ops):
+@pytest.mark.parametrize("mode,ops,impl", [(1, 6000, True), (0, 4500, True), (1, 6000, "split")])
+def test_joint_runs_past_the_list_into_the_bag(native, O, oracle_tables, device_tables, mode, ops, impl):
     """A generator pulled far past its sorted list: the joint choice leaves a primary with a residual priority (it is not
     re-queued, video.py:140 with IIV_CONTENT_JOINT), so a stale bag entry of that location, pushed when it was an extra
     offset, finds it live when it is popped and the location is encoded again -- as the oracle's definition does.  (Until
@@ -117,7 +119,7 @@ def test_joint_runs_past_the_list_into_the_bag(native, O, oracle_tables, device_
     frames = [np.stack([fm[i].numpy(), fa[i].numpy() if fa is not None else np.zeros_like(fm[i].numpy())], axis=1) for i in range(n)]
     sched = [(0, 0, ops), (1, 0, 1500)]
     seeds = [(i + 3, i + 9) for i in range(n)]
-    enc, got = _device(native, device_tables, mode, frames, sched, seeds, O, True)
+    enc, got = _device(native, device_tables, mode, frames, sched, seeds, O, impl)
     for i in range(n):
         v, exp = _oracle(O, oracle_tables, mode, frames[i], sched, *seeds[i], True)
         bad = np.nonzero((got[i] != exp).any(axis=1))[0]
