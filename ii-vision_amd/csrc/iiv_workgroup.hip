@@ -289,7 +289,8 @@ __global__ __launch_bounds__(256, JOINT ? 5 : 1) void greedy_kernel(StreamState 
                 };
                 while (todo) {
                     // (a missing byte repeats the first with diff weight 0: d >= 0 changes nothing.  Walking all 64 bytes of the
-                    // quarter without the mask bookkeeping was measured: no faster, DHGR, and 7 % slower, HGR)
+                    // quarter without the mask bookkeeping was measured: no faster, DHGR, and 7 % slower, HGR; so was the left row
+                    // offset riding in the diff-weight word's high half -- one v_readlane less, two scalar shifts more: 3 % slower)
                     int lo[U], ro[U], db[U];
 #pragma unroll
                     for (int u = 0; u < U; u++) {

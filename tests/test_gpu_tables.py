@@ -134,6 +134,14 @@ def test_encoder_falls_back_when_its_tables_disagree(native, device_tables, dms,
             enc.set_greedy_kernel(kern)
     enc.set_greedy_kernel(False)
     enc.set_greedy_kernel(None)
+    # (the joint content choice then scores from the two-component split table: its packed form is built from the narrow one)
+    enc.set_content_choice(True)
+    import torch
+    fm = torch.zeros((1, 1, 32, 256), dtype=torch.uint8, device="cuda")
+    fm[0, 0, 3, 5:40] = 0x2a
+    ops = enc.encode(fm, fm.clone() if mode == 1 else None, [(0, 0, 1, 12)])
+    enc.check()
+    assert ops.shape == (1, 12, 6) and int(ops[0, 0, 0]) == 32 + 3
     enc.close()
     enc = native.Encoder(mode, table, dense, 1, dm=dms[5])
     enc.set_greedy_kernel(True)
