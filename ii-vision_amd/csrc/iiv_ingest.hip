@@ -39,6 +39,7 @@ __device__ __host__ static inline int y_to_offset(int y)  // y_to_base_addr(y, 0
 struct IngestPalette {
     int32_t k[16];        // 16 (2 R^2 + 4 G^2 + 3 B^2) + colour value
     int32_t a[16], b[16], c[16];   // -16 * 4 R, -16 * 8 G, -16 * 6 B
+    uint32_t bc[16];      // the last two as a pair of 16-bit halves (both fit: 128 x 255, 96 x 255 < 2^15): v_dot2c_i32_i16's operand
     uint32_t rgb[16];     // R | G << 8 | B << 16
     int32_t dither[16];   // ordered-dither offset of (y & 3) * 4 + (k & 3): floor((2 Bayer - 15) * amplitude / 16)
 };
@@ -53,6 +54,7 @@ static IngestPalette make_palette(const uint8_t pal[48], int dither)
         p.a[c] = -64 * R;
         p.b[c] = -128 * G;
         p.c[c] = -96 * B;
+        p.bc[c] = (uint32_t)(uint16_t)(int16_t)(-128 * G) | ((uint32_t)(uint16_t)(int16_t)(-96 * B) << 16);
         p.rgb[c] = (uint32_t)R | ((uint32_t)G << 8) | ((uint32_t)B << 16);
         p.dither[c] = dither == IIV_DITHER_DIFFUSION ? 0 : ((2 * bayer[c] - 15) * dither + 16 * 256) / 16 - 256;
     }
@@ -76,12 +78,31 @@ __device__ static inline IngestKv ingest_kv(const IngestPalette &P)
     return v;
 }
 
-// key of colour c for the pixel (r, g, b) = 16 * (distance - the term common to all colours) + c: three v_mad_i32_i24.
-// DHGR: the nearest of the sixteen colours (ties to the lower colour value).  Three rounds of sixteen independent
-// multiply-adds with ONE compiler barrier between rounds (the barrier keeps the compiler from re-associating a colour's
-// chain into mad + 2 mul + add3; one asm statement per round rather than per colour, because the hazard recogniser puts an
-// s_nop behind every inline-asm statement)
+// key of colour c for the pixel (r, g, b) = 16 * (distance - the term common to all colours) + c
+//     = (K_c + r * (-64 R_c)) + (g, b) . (-128 G_c, -96 B_c):
+// a v_mad_i32_i24 into a fresh register and a v_dot2c_i32_i16 that accumulates in place (16-bit pairs, exact 32-bit sum; g, b
+// are clamped to 0..255, the coefficients fit 16 bits) -- two instructions instead of three multiply-adds.  (Both products
+// in dot form, (r, g) . (..) + (b, 0) . (..), compile to the accumulate-in-place form too and then need a copy of K_c each:
+// three again.)  DHGR: the nearest of the sixteen colours (ties to the lower colour value).
+typedef short ingest_v2s __attribute__((ext_vector_type(2)));
+__device__ static inline int dist_key(const IngestPalette &P, int kc, int c, int r, ingest_v2s gb)
+{
+    return __builtin_amdgcn_sdot2(gb, __builtin_bit_cast(ingest_v2s, P.bc[c]), __mul24(r, P.a[c]) + kc, false);
+}
 __device__ static inline int nearest16(const IngestPalette &P, const IngestKv &kv, int r, int g, int b)
+{
+    const ingest_v2s gb = __builtin_bit_cast(ingest_v2s, (uint32_t)g | ((uint32_t)b << 16));
+    int m = 0x7fffffff;
+#pragma unroll
+    for (int c = 0; c < 16; c++) m = min(m, dist_key(P, kv.k[c], c, r, gb));
+    return m & 15;
+}
+// The same with three v_mad_i32_i24 per colour, for the error-diffusion kernel: a lane's pixels there are one dependent chain,
+// and the wait states between a v_dot2c and the minimum that reads it cost that kernel more (1.6 %, same-box A/B) than the
+// sixteen instructions save.  Three rounds of sixteen independent multiply-adds with ONE compiler barrier between rounds (the
+// barrier keeps the compiler from re-associating a colour's chain into mad + 2 mul + add3; one asm statement per round rather
+// than per colour, because the hazard recogniser puts an s_nop behind every inline-asm statement)
+__device__ static inline int nearest16_mad(const IngestPalette &P, const IngestKv &kv, int r, int g, int b)
 {
     int t[16];
 #pragma unroll
@@ -102,17 +123,12 @@ __device__ static inline int nearest16(const IngestPalette &P, const IngestKv &k
 // (black 0, violet 3 | blue 6, green 12 | orange 9, white 15; ties to the lower pattern)
 __device__ static inline void nearest4x2(const IngestPalette &P, const IngestKv &kv, int r, int g, int b, int &key0, int &key1)
 {
-    // the six colours HGR can show, three rounds of six multiply-adds (see nearest16 for the barriers)
+    // the six colours HGR can show
     constexpr int col[6] = {0, 3, 12, 15, 6, 9};
+    const ingest_v2s gb = __builtin_bit_cast(ingest_v2s, (uint32_t)g | ((uint32_t)b << 16));
     int t[6];
 #pragma unroll
-    for (int j = 0; j < 6; j++) t[j] = __mul24(r, P.a[col[j]]) + kv.k[col[j]];
-    asm("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]));
-#pragma unroll
-    for (int j = 0; j < 6; j++) t[j] = __mul24(g, P.b[col[j]]) + t[j];
-    asm("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]));
-#pragma unroll
-    for (int j = 0; j < 6; j++) t[j] = (__mul24(b, P.c[col[j]]) + t[j]) >> 4;   // (>> 4: the colour value leaves, the distance term stays exact)
+    for (int j = 0; j < 6; j++) t[j] = dist_key(P, kv.k[col[j]], col[j], r, gb) >> 4;   // (>> 4: the colour value leaves, the distance term stays exact)
     const int f0 = t[0], f3 = t[1], f12 = t[2], f15 = t[3], f6 = t[4], f9 = t[5];
     const int b0 = f0 * 4, w3 = f15 * 4 + 3;
     key0 = min(min(b0, f3 * 4 + 1), min(f12 * 4 + 2, w3));
@@ -239,15 +255,10 @@ __global__ __launch_bounds__(64 * kDiffWaves) void ingest_diffusion_kernel(int n
     struct F6 {
         int f0, f3, f12, f15, f6, f9;
     };
-    auto f6 = [&](int r, int g, int b) -> F6 {   // the distance terms of the six colours: three rounds of six multiply-adds (see nearest16)
-        int t0 = __mul24(r, P.a[0]) + kv0, t3 = __mul24(r, P.a[3]) + kv3, t12 = __mul24(r, P.a[12]) + kv12;
-        int t15 = __mul24(r, P.a[15]) + kv15, t6 = __mul24(r, P.a[6]) + kv6, t9 = __mul24(r, P.a[9]) + kv9;
-        asm("" : "+v"(t0), "+v"(t3), "+v"(t12), "+v"(t15), "+v"(t6), "+v"(t9));
-        t0 += __mul24(g, P.b[0]), t3 += __mul24(g, P.b[3]), t12 += __mul24(g, P.b[12]);
-        t15 += __mul24(g, P.b[15]), t6 += __mul24(g, P.b[6]), t9 += __mul24(g, P.b[9]);
-        asm("" : "+v"(t0), "+v"(t3), "+v"(t12), "+v"(t15), "+v"(t6), "+v"(t9));
-        return F6{(t0 + __mul24(b, P.c[0])) >> 4, (t3 + __mul24(b, P.c[3])) >> 4, (t12 + __mul24(b, P.c[12])) >> 4,
-                  (t15 + __mul24(b, P.c[15])) >> 4, (t6 + __mul24(b, P.c[6])) >> 4, (t9 + __mul24(b, P.c[9])) >> 4};
+    auto f6 = [&](int r, int g, int b) -> F6 {   // the distance terms of the six colours (dist_key)
+        const ingest_v2s gb = __builtin_bit_cast(ingest_v2s, (uint32_t)g | ((uint32_t)b << 16));
+        return F6{dist_key(P, kv0, 0, r, gb) >> 4, dist_key(P, kv3, 3, r, gb) >> 4, dist_key(P, kv12, 12, r, gb) >> 4,
+                  dist_key(P, kv15, 15, r, gb) >> 4, dist_key(P, kv6, 6, r, gb) >> 4, dist_key(P, kv9, 9, r, gb) >> 4};
     };
     // per-lane sequence: group tt = T - i of this lane's rows (20 groups of 7 pixels per row; rows i, 20 + i, ...)
     int Dq[7][3];                         // D from the row above for the pixels of the period, slot = pixel mod 7
@@ -324,7 +335,7 @@ __global__ __launch_bounds__(64 * kDiffWaves) void ingest_diffusion_kernel(int n
             value_of(mean_of(Pc), (e0r << 3) + tr, (e0g << 3) + tg, (e0b << 3) + tb, r, g, b);
             if constexpr (MODE == kDHGR) {
                 // the nearest of the sixteen colours; its value IS the pixel's dot quad
-                const int col = nearest16(P, kv, r, g, b);
+                const int col = nearest16_mad(P, kv, r, g, b);
                 const uint32_t prgb = pal_s[col];
                 er = r - (int)(prgb & 255u);
                 eg = g - (int)((prgb >> 8) & 255u);
