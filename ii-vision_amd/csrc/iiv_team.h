@@ -21,7 +21,10 @@
 // nonces at its offset, and what was scored behind it is scored again next round.
 // Seven waves score; the eighth keeps random's MT19937 stream ahead: the state lives in LDS as a
 // ring of ten 624-word blocks (a round can draw 7 * 258 words), and while the others score, that
-// wave twists up to two more blocks into the slots the stream has left behind.
+// wave twists up to two more blocks into the slots the stream has left behind.  (Two such waves, half of a block's chains
+// each, were measured in round 5: no faster -- a ninth wave shares a SIMD with two others -- and removed; so was that wave
+// skipping the run formation and picking the run's length up from LDS: the wait at barrier B fell from 590 to 340 clocks, the
+// round from 6 447 to 6 406.)
 // The table words of the entry a wave will most likely score next round (the one 7 positions
 // further, if the whole run commits) are requested before this round's commit, so that they
 // travel while the stores, the barrier and the bookkeeping run.
@@ -157,13 +160,17 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
     auto nd_of = [&](const Scored &sc, int y) -> uint32_t {
         const uint32_t pa = (uint32_t)__builtin_amdgcn_readlane((int)sc.nd01, y >> 2);
         const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane((int)sc.nd23, y >> 2);
-        return (((y & 2) ? pb : pa) >> ((y & 1) * 16)) & 0xffffu;
+        return ((((y & 2) ? pb : pa) >> ((y & 1) * 16)) & 0xffffu) - kNarrowBias;   // (the sums are kept with RF's bias)
     };
     // the immutable inputs of a step: the entry's row of wd[] and its eight table words
     struct Loaded {
         uint32_t e;              // the entry they belong to (0 with bit 31 clear: nothing loaded)
-        uint32_t dwm[4], gl[4], gr[4];
+        uint32_t kb[4], gl[4], gr[4];   // kb: -diff weight << 20 | offset, less the bias term of the key (see score)
     };
+    // the allocation as a raw buffer: a slice base is one 32-bit scalar offset instead of a 64-bit pointer added per lane
+    const __amdgpu_buffer_rsrc_t rsrc_nt = __builtin_amdgcn_make_buffer_rsrc((void *)nt.base, 0, 0x7fffffff, 0x00020000);
+    // a key is value * kKeyMul + kb = delta << 20 | value << 8 | offset: the winner's key brings its store value along
+    constexpr uint32_t kKeyMul = (1u << kWdDwShift) | (1u << 8);
     auto load = [&](uint32_t e, Loaded &L) {
         const int p = (e >> 8) & 31;
         const uint32_t c = (e >> 16) & 0xffu;
@@ -172,13 +179,12 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
         const uint32_t sl_d = l1_d + (split_content_left<MODE>(c, 1) << (T::kLeftRowBits + 1));
         const uint32_t sr_e = r1_e + (split_content_right<MODE>(c, 0) << (T::kRightRowBits + 1));
         const uint32_t sr_d = r1_d + (split_content_right<MODE>(c, 1) << (T::kRightRowBits + 1));
-        const uint8_t *le = nt.base + sl_e, *ld = nt.base + sl_d, *re = nt.base + sr_e, *rd = nt.base + sr_d;
         const uint32_t wr[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            L.gl[r] = *reinterpret_cast<const uint16_t *>(((r & 1) ? ld : le) + wd_off_left(wr[r]));
-            L.gr[r] = *reinterpret_cast<const uint16_t *>(((r & 1) ? rd : re) + wd_off_right(wr[r]));
-            L.dwm[r] = wd_dw(wr[r]) << kWdDwShift;
+            L.gl[r] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc_nt, (int)wd_off_left(wr[r]), (int)((r & 1) ? sl_d : sl_e), 0);
+            L.gr[r] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc_nt, (int)wd_off_right(wr[r]), (int)((r & 1) ? sr_d : sr_e), 0);
+            L.kb[r] = (y0 + (uint32_t)r) - (wd_dw(wr[r]) << kWdDwShift) - kNarrowBias * kKeyMul;
         }
         L.e = e | 0x80000000u;
     };
@@ -197,8 +203,8 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
         sc.C = 0;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            nd[r] = L.gl[r] + L.gr[r] - kNarrowBias;   // L1 + RF (iiv_stream.h: narrow form)
-            const int d = (int)((nd[r] << kWdDwShift) | (y0 + r)) - (int)L.dwm[r];   // screen.py:547
+            nd[r] = L.gl[r] + L.gr[r];   // L1 + RF = store value + kNarrowBias (iiv_stream.h: narrow form)
+            const int d = (int)(__umul24(nd[r], kKeyMul) + L.kb[r]);   // delta << 20 | value << 8 | offset (screen.py:547)
             const int gone = __builtin_amdgcn_sbfe((int)pdw, sh0 + r, 1);
             const int live = __builtin_amdgcn_sbfe((int)nzw, sh0 + r, 1);
             sc.ke[r] = d & live;                                   // video.py:159
@@ -212,7 +218,8 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
         const int k1 = a0 < a1 ? a0 : a1, hi01 = a0 < a1 ? a1 : a0, mb = b0 < b1 ? b0 : b1;
         const int k2 = hi01 < mb ? hi01 : mb;
         const int k3 = hi01 < mb ? mb : hi01;   // (FOUR: the lane's third smallest)
-        const int K1 = wave_min_i32(k1);
+        int K1 = k1, K2 = k2;
+        wave_top2_i32(K1, K2);   // the wave's two smallest eligible keys in one fused-DPP pass (iiv_wave.h)
         sc.y1 = sc.y2 = sc.y3 = -1;
         sc.nd1 = sc.nd2 = sc.nd3 = 0;
         sc.tie = false;
@@ -230,25 +237,22 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const bool member = ((uint32_t)(sc.ke[r] ^ K) >> kWdDwShift) == 0u;
-                zero |= __ballot(member && nd[r] == 0u);
-                nonzero |= __ballot(member && nd[r] != 0u);
+                zero |= __ballot(member && nd[r] == kNarrowBias);
+                nonzero |= __ballot(member && nd[r] != kNarrowBias);
             }
         };
         if (K1 < 0) {
             sc.y1 = K1 & 255;
-            sc.nd1 = nd_of(sc, sc.y1);
-            const bool hit1 = k1 == K1;
-            const int c1 = hit1 ? k2 : k1;
-            const int K2 = wave_min_i32(c1);
+            sc.nd1 = ((uint32_t)K1 >> 8) & 0x7ffu;
             int K3 = 0;
             if (K2 < 0) {
                 sc.y2 = K2 & 255;
-                sc.nd2 = nd_of(sc, sc.y2);
+                sc.nd2 = ((uint32_t)K2 >> 8) & 0x7ffu;
                 if constexpr (FOUR) {
-                    K3 = wave_min_i32(c1 == K2 ? (hit1 ? k3 : k2) : c1);
+                    K3 = wave_min_i32(k1 > K2 ? k1 : (k2 > K2 ? k2 : k3));   // every lane's smallest key above K2
                     if (K3 < 0) {
                         sc.y3 = K3 & 255;
-                        sc.nd3 = nd_of(sc, sc.y3);
+                        sc.nd3 = ((uint32_t)K3 >> 8) & 0x7ffu;
                     }
                 }
             }
@@ -304,23 +308,21 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
             const uint32_t k = ((uint32_t)((sc.ke[r] >> kWdDwShift) + 2048) << 16) | (nonce << 8) | (y0 + r);
             key[r] = sc.ke[r] < 0 ? (int)k : kNone;
         }
-        // the two smallest: in the lane, then two fused-DPP wave minima (the keys end in the offset: unique)
+        // the two smallest: in the lane, then the one-pass fused-DPP top-2 (the keys end in the offset: unique)
         const int ta0 = key[0] < key[1] ? key[0] : key[1], tb0 = key[0] < key[1] ? key[1] : key[0];
         const int ta1 = key[2] < key[3] ? key[2] : key[3], tb1 = key[2] < key[3] ? key[3] : key[2];
         const int t1 = ta0 < ta1 ? ta0 : ta1;
         const int thi = ta0 < ta1 ? ta1 : ta0, tmb = tb0 < tb1 ? tb0 : tb1;
         const int t2 = thi < tmb ? thi : tmb;
-        const int T1 = wave_min_i32(t1);
-        const bool thit1 = t1 == T1;
-        const int tc1 = thit1 ? t2 : t1;
-        const int T2 = wave_min_i32(tc1);
+        int T1 = t1, T2 = t2;
+        wave_top2_i32(T1, T2);   // (kNone in many lanes: a value nobody asks about, see iiv_wave.h)
         sc.y1 = T1 != kNone ? (T1 & 255) : -1;
         sc.y2 = T2 != kNone ? (T2 & 255) : -1;
         sc.nd1 = sc.y1 >= 0 ? nd_of(sc, sc.y1) : 0u;
         sc.nd2 = sc.y2 >= 0 ? nd_of(sc, sc.y2) : 0u;
         if constexpr (FOUR) {
             const int t3 = thi < tmb ? tmb : thi;
-            const int T3 = wave_min_i32(tc1 == T2 ? (thit1 ? t3 : t2) : tc1);
+            const int T3 = wave_min_i32(t1 > T2 ? t1 : (t2 > T2 ? t2 : t3));   // every lane's smallest key above T2
             sc.y3 = T3 != kNone ? (T3 & 255) : -1;
             sc.nd3 = sc.y3 >= 0 ? nd_of(sc, sc.y3) : 0u;
         }
