@@ -229,8 +229,13 @@ __global__ __launch_bounds__(256) void ingest_kernel(int n, const uint8_t *__res
 // wavefront, a workgroup barrier per pixel step -- ran 0.19 M HGR frames/s; a first one-wave-per-frame DHGR form of this
 // round, 64 rows two pixels apart with dynamic phases, 2.9 M; this form 5.9 M HGR.)
 constexpr int kDiffWaves = 2;   // waves per block
+// waves per SIMD the error-diffusion kernel's registers are held to: DHGR runs 11 % faster at five (96 VGPRs, six dwords
+// spilled) than at the four it gets unasked (110 VGPRs); HGR does not (-1 %); six (80 VGPRs) costs both a quarter
+#ifndef IIV_DIFF_OCC
+#define IIV_DIFF_OCC(MODE) ((MODE) == kDHGR ? 5 : 4)
+#endif
 template <int MODE>
-__global__ __launch_bounds__(64 * kDiffWaves) void ingest_diffusion_kernel(int n, const uint8_t *__restrict__ rgb_frames, const IngestPalette P,
+__global__ __launch_bounds__(64 * kDiffWaves, IIV_DIFF_OCC(MODE)) void ingest_diffusion_kernel(int n, const uint8_t *__restrict__ rgb_frames, const IngestPalette P,
                                                                            uint8_t *__restrict__ main_mem, uint8_t *__restrict__ aux_mem)
 {
     __shared__ int ring_s[kDiffWaves][3][16][4];
