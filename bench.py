@@ -340,7 +340,8 @@ class GpuBackend:
         """One step of every clip; returns the segments it ran.  The resident clip is as long as the TIMED
         region (steps x frames-per-step frames); the warm-up steps run on its first frames and the timed
         steps carry on from there and wrap around, so every frame of the clip is encoded exactly once inside
-        the timed region and the clip count does not depend on --warmup."""
+        the timed region and the clip count does not depend on --warmup.  (S-coh / S-static clips do not wrap: they are
+        as long as warm-up + timed region -- a wrap would put one complete redraw into the timed region; see main().)"""
         self.last_ops, segs = self.batch.encode_frames(self.fm, self.fa, self.args.frames_per_step, self.ops_buf, loop=True)
         return segs
 
