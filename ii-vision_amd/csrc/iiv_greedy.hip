@@ -510,7 +510,10 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
             n_exact++;
             // (on picture-like input this is the normal path: 96 % of the opcodes of S-img tie, with 11 bytes sharing the
             // smallest delta; on random input 2.5 %)
-            constexpr int kNone = 0x7fffffff;   // the keys below are < 2^28: signed minima order them
+            // keys: delta (signed, top 16 bits) | nonce | offset.  An eligible byte's delta is negative, so its key is; the
+            // others keep whatever non-negative key their bits make -- no bias, no select: signed minima find the eligible ones
+            // first, and a winner that is not negative is "none"
+            static_assert(kWdDwShift == 20, "the key's delta field is taken from bits 20..31 of an eligible key");
             int key[4];
             // candidates in lower lanes draw first, then this lane's bytes in ascending order
             int run = mt_idx;
@@ -520,8 +523,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
             for (int r = 0; r < 4; r++) {
                 const uint32_t nonce = mt_temper(mt[run]) >> 24;
                 run += (int)((cand[r] >> lane) & 1ull);
-                const uint32_t k = ((uint32_t)((ke[r] >> kWdDwShift) + 2048) << 16) | (nonce << 8) | (y0 + r);
-                key[r] = ke[r] < 0 ? (int)k : kNone;  // video.py:159
+                key[r] = (int)(((uint32_t)(ke[r] >> 4) & 0xffff0000u) | (nonce << 8) | (y0 + r));   // video.py:159
             }
             // the two smallest (delta, nonce, offset): in the lane, then the one-pass fused-DPP top-2 of the fast path
             // (keys are unique -- they end in the offset)
@@ -531,15 +533,15 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
             const int thi = ta0 < ta1 ? ta1 : ta0, tmb = tb0 < tb1 ? tb0 : tb1;
             const int t2 = thi < tmb ? thi : tmb;
             int T1 = t1, T2 = t2;
-            wave_top2_i32(T1, T2);   // (kNone in many lanes: a value nobody asks about, see iiv_wave.h)
-            W1 = T1 != kNone ? (nd_of(T1 & 255) << 8) | (uint32_t)(T1 & 255) : (uint32_t)x;
-            W2 = T2 != kNone ? (nd_of(T2 & 255) << 8) | (uint32_t)(T2 & 255) : (uint32_t)x;
-            prev_tie = T2 != kNone && (T1 >> 16) == (T2 >> 16);   // (a prediction only: either path is exact)
+            wave_top2_i32(T1, T2);   // (keys are unique: they end in the offset)
+            W1 = T1 < 0 ? (nd_of(T1 & 255) << 8) | (uint32_t)(T1 & 255) : (uint32_t)x;
+            W2 = T2 < 0 ? (nd_of(T2 & 255) << 8) | (uint32_t)(T2 & 255) : (uint32_t)x;
+            prev_tie = T2 < 0 && (T1 >> 16) == (T2 >> 16);   // (a prediction only: either path is exact)
             if constexpr (FOUR) {
                 const int t3 = thi < tmb ? tmb : thi;
                 const int T3 = wave_min_i32(t1 > T2 ? t1 : (t2 > T2 ? t2 : t3));   // every lane's smallest key above T2
-                W3 = T3 != kNone ? (nd_of(T3 & 255) << 8) | (uint32_t)(T3 & 255) : (uint32_t)x;
-                prev_tie = prev_tie || (T3 != kNone && (T2 >> 16) == (T3 >> 16));
+                W3 = T3 < 0 ? (nd_of(T3 & 255) << 8) | (uint32_t)(T3 & 255) : (uint32_t)x;
+                prev_tie = prev_tie || (T3 < 0 && (T2 >> 16) == (T3 >> 16));
             }
         }
         apply(track, e, W1, W2, W3, C);
