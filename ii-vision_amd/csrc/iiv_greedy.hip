@@ -305,20 +305,21 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
         }
     };
 
-    // opcodes emitted but not yet written: opcode ob_base + l sits in lane l of (ob0, ob1) -- as the step has them, its entry
-    // word (page << 8 | x | content << 16) and its extra offsets (y1 | y2 << 8 [| y3 << 16]); the six bytes of
-    // (page + 32, content, x, y1, y2, x) are formed by the 64 lanes at once when the buffer leaves, not by ten scalar
-    // instructions in every step
-    uint32_t ob0 = 0, ob1 = 0;
-    int ob_base = 0;
+    // opcodes emitted but not yet written: opcode ob_base + l sits in lane l of (ob0, ob1, ob2[, ob3]) -- as the step has
+    // them: its entry word (page << 8 | x | content << 16) and its winners (store value << 8 | offset); the six bytes of
+    // (page + 32, content, x, y1, y2, x) are formed by the 64 lanes at once when the buffer leaves, not by scalar
+    // instructions in every step (round 5: not even the packing of the offsets)
+    uint32_t ob0 = 0, ob1 = 0, ob2 = 0, ob3 = 0;
+    int ob_base = 0, ob_n = 0;   // ob_n = done - ob_base, kept as a counter of its own
     auto flush_ops = [&]() {
-        if (lane < done - ob_base) {
+        if (lane < ob_n) {
             uint8_t *q = out + (size_t)(ob_base + lane) * 6;
             const uint32_t pg = (ob0 >> 8) & 31u, xx = ob0 & 255u, cc = (ob0 >> 16) & 255u;
             *reinterpret_cast<u32_a2 *>(q) = (pg + 32u) | (cc << 8) | (xx << 16) | (ob1 << 24);
-            *reinterpret_cast<uint16_t *>(q + 4) = (uint16_t)(((ob1 >> 8) & 255u) | ((FOUR ? (ob1 >> 16) & 255u : xx) << 8));
+            *reinterpret_cast<uint16_t *>(q + 4) = (uint16_t)((ob2 & 255u) | ((FOUR ? ob3 & 255u : xx) << 8));
         }
         ob_base = done;
+        ob_n = 0;
     };
 
     // video.py:140-144, 170-187; screen.py:256-293.  Lanes 0..2 (FOUR: 0..3) carry (x, y1, y2[, y3]); a missing secondary
@@ -341,7 +342,14 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
     auto apply = [&](auto track, uint32_t e, uint32_t W1, uint32_t W2, uint32_t W3, int C) {
         const int p = (e >> 8) & 31, x = e & 255;
         const uint32_t c = (e >> 16) & 0xffu;
-        const int f1 = (int)min(W1 >> 8, 1u), f2 = (int)min(W2 >> 8, 1u), f3 = FOUR ? (int)min(W3 >> 8, 1u) : 0;
+        // (a winner's store value is non-zero: it is re-queued.  As s_min_u32: written as min(v, 1) or v != 0 the flag takes
+        // a v_cndmask / v_readfirstlane round trip through a vector register)
+        auto flag = [](uint32_t w) -> int {
+            int f;
+            asm("s_min_u32 %0, %1, 1" : "=s"(f) : "s"(w >> 8) : "scc");   // (s_min writes SCC)
+            return f;
+        };
+        const int f1 = flag(W1), f2 = flag(W2), f3 = FOUR ? flag(W3) : 0;
         if (__builtin_expect(n_pushed > kPushedCap - 4, 0)) {
             err = kErrPushedOverflow;
             return;
@@ -354,9 +362,16 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
         uint32_t w_v = (uint32_t)x, k_v = 0u;
         asm("v_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %3, 2\n\tv_writelane_b32 %1, %4, 2"
             : "+v"(w_v), "+v"(k_v)
-            : "s"(IIV_SGPR(W1)), "s"(IIV_SGPR(W2)), "s"(IIV_SGPR(f1)));
+            : "s"(W1), "s"(W2), "s"(f1));   // (wave-uniform by construction: no v_readfirstlane round trip for a flag)
         if (FOUR)
-            asm("v_writelane_b32 %0, %2, 3\n\tv_writelane_b32 %1, %3, 3" : "+v"(w_v), "+v"(k_v) : "s"(IIV_SGPR(W3)), "s"(IIV_SGPR(f1 + f2)));
+            asm("v_writelane_b32 %0, %2, 3\n\tv_writelane_b32 %1, %3, 3" : "+v"(w_v), "+v"(k_v) : "s"(W3), "s"(f1 + f2));
+        // the opcode: the entry word and the winners go into lane ob_n of three registers; 64 of them leave in two
+        // coalesced stores (flush_ops).  (Here, not at the end: the winners' scalar registers are free from here on)
+        // (gfx9 VOP3 reads one SGPR only; v_writelane may take its lane select from m0 besides)
+        asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %5, m0\n\tv_writelane_b32 %2, %6, m0"
+            : "+v"(ob0), "+v"(ob1), "+v"(ob2)
+            : "s"(IIV_SGPR(e)), "s"(ob_n), "s"(W1), "s"(W2));
+        if (FOUR) asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(ob3) : "s"(W3), "s"(ob_n));
         int ln = lane;
         asm volatile("" : "+v"(ln));   // (keeps `lane < 3` from becoming one more hoisted, spilled mask)
         if (ln < (FOUR ? 4 : 3)) {
@@ -377,20 +392,13 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
             __builtin_amdgcn_raw_buffer_store_b32(pkey, rsrc_s, (int)slot, (int)offsetof(StreamState, pushed), 0);
             if (decltype(track)::value) pkey_v = pkey;
         }
-        // the opcode: the entry word and the extra offsets go into lane (done - ob_base) of a register pair; 64 of them
-        // leave in two coalesced stores (flush_ops)
-        const uint32_t ys = (W1 & 255u) | ((W2 & 255u) << 8) | (FOUR ? (W3 & 255u) << 16 : 0u);
-        const int ob_lane = IIV_SGPR(done - ob_base);
-        // (gfx9 VOP3 reads one SGPR only; v_writelane may take its lane select from m0 besides)
-        asm("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
-            : "+v"(ob0), "+v"(ob1)
-            : "s"(IIV_SGPR(e)), "s"(ob_lane), "s"(IIV_SGPR(ys)));
         if (decltype(track)::value) push_f1 = f1, push_f2 = f2, push_f3 = f3, push_base = n_pushed;
         mt_idx += C + f1 + f2 + f3;
         draws += (uint32_t)(C + f1 + f2 + f3);
         n_pushed += f1 + f2 + f3;
         done++;
-        if (__builtin_expect(done - ob_base == 64, 0)) flush_ops();
+        ob_n++;
+        if (__builtin_expect(ob_n == 64, 0)) flush_ops();
         if (__builtin_expect(mt_idx >= 624, 0)) {
             // the next block becomes the current one: its head moves down now, the rest of it
             // and the new head are generated later, while table loads are in flight
