@@ -663,6 +663,18 @@ int encoder_get_video_brief(Encoder *e, int s, iiv_video_brief *out)
     return IIV_OK;
 }
 
+// The same, enqueued on `st` behind whatever was launched there: nothing waits.  host_out holds the brief once the
+// stream has been synchronised (iiv_encoder_check does); pinned memory makes the copy truly asynchronous.
+int encoder_get_video_brief_async(Encoder *e, int s, iiv_video_brief *out, hipStream_t st)
+{
+    if (!e || !out || s < 0 || s >= e->n_streams) return set_error(IIV_ERR_INVALID, "get_video_brief_async: bad argument");
+    if (!e->d_brief) IIV_HIP(hipMalloc(&e->d_brief, sizeof(iiv_video_brief)));
+    hipLaunchKernelGGL(brief_kernel, dim3(1), dim3(256), 0, st, e->d_states + s, (iiv_video_brief *)e->d_brief);
+    IIV_HIP(hipGetLastError());
+    IIV_HIP(hipMemcpyAsync(out, e->d_brief, sizeof(iiv_video_brief), hipMemcpyDeviceToHost, st));
+    return IIV_OK;
+}
+
 int encoder_set_video_state(Encoder *e, int s, const iiv_video_state *in)
 {
     if (!e || !in || s < 0 || s >= e->n_streams) return set_error(IIV_ERR_INVALID, "set_video_state: bad argument");
@@ -1187,6 +1199,12 @@ int iiv_encoder_get_video_brief(iiv_encoder *enc, int stream_index, iiv_video_br
 {
     if (!enc) return iiv::set_error(IIV_ERR_INVALID, "null encoder");
     return iiv::encoder_get_video_brief(enc->impl, stream_index, host_out);
+}
+
+int iiv_encoder_get_video_brief_async(iiv_encoder *enc, int stream_index, iiv_video_brief *host_out, void *stream)
+{
+    if (!enc) return iiv::set_error(IIV_ERR_INVALID, "null encoder");
+    return iiv::encoder_get_video_brief_async(enc->impl, stream_index, host_out, (hipStream_t)stream);
 }
 
 int iiv_encoder_set_video_state(iiv_encoder *enc, int stream_index, const iiv_video_state *host_in)

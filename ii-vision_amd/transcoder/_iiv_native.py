@@ -41,7 +41,7 @@ SYMBOLS = [
     "iiv_encoder_create", "iiv_encoder_destroy", "iiv_encoder_set_option", "iiv_encoder_info",
     "iiv_encoder_snapshot", "iiv_encoder_rollback", "iiv_encoder_get_state", "iiv_encoder_set_state",
     "iiv_encoder_set_state_range", "iiv_encoder_get_video_state", "iiv_encoder_set_video_state",
-    "iiv_encoder_get_video_brief",
+    "iiv_encoder_get_video_brief", "iiv_encoder_get_video_brief_async",
     "iiv_encode", "iiv_encode_streams",
     "iiv_encoder_check", "iiv_encoder_profile", "iiv_encoder_profile_read", "iiv_encoder_input_stats",
     "iiv_encoder_launch_forms",
@@ -133,6 +133,8 @@ def lib():
     L.iiv_encoder_set_state_range.argtypes = [vp, i32, i32, i32, vp, sz]
     L.iiv_encoder_get_video_state.argtypes = [vp, i32, C.POINTER(VideoState)]
     L.iiv_encoder_get_video_brief.argtypes = [vp, i32, C.POINTER(VideoBrief)]
+    if hasattr(L, "iiv_encoder_get_video_brief_async") or "IIV_LIB" not in os.environ:
+        L.iiv_encoder_get_video_brief_async.argtypes = [vp, i32, C.POINTER(VideoBrief), vp]
     L.iiv_encoder_set_video_state.argtypes = [vp, i32, C.POINTER(VideoState)]
     L.iiv_encode.argtypes = [vp, vp, vp, i32, C.POINTER(Segment), i32, vp, vp]
     L.iiv_encode_streams.argtypes = [vp, vp, vp, i32, C.POINTER(Segment), C.POINTER(C.c_int32), vp, sz, vp]
@@ -155,7 +157,7 @@ def lib():
     if hasattr(L, "iiv_encoder_launch_forms") or "IIV_LIB" not in os.environ:
         L.iiv_encoder_launch_forms.argtypes = [vp, C.POINTER(C.c_int64)]
     for name in SYMBOLS:
-        if "IIV_LIB" in os.environ and name in ("iiv_encoder_launch_forms", "iiv_check_diff_weight_pieces", "iiv_encoder_info") and not hasattr(L, name):
+        if "IIV_LIB" in os.environ and name in ("iiv_encoder_launch_forms", "iiv_check_diff_weight_pieces", "iiv_encoder_info", "iiv_encoder_get_video_brief_async") and not hasattr(L, name):
             continue   # (an older build under IIV_LIB: tools/ab_libs.sh)
         getattr(L, name)  # AttributeError if the library lacks a declared symbol
     _lib = L
@@ -522,6 +524,11 @@ class Encoder:
         out = out if out is not None else VideoBrief()
         check(lib().iiv_encoder_get_video_brief(self._h, int(stream), C.byref(out)))
         return out
+
+    def get_video_brief_async(self, out, stream=0):
+        """The brief of the state as it will be behind the launches already enqueued, copied into `out` (a VideoBrief in
+        pinned memory) by the time the stream is synchronised (check())."""
+        check(lib().iiv_encoder_get_video_brief_async(self._h, int(stream), C.byref(out), stream_ptr()))
 
     def set_video_state(self, state, stream=0):
         check(lib().iiv_encoder_set_video_state(self._h, int(stream), C.byref(state)))

@@ -152,10 +152,14 @@ class Video:
             self._enc.set_fourth_offset(True)
         self._live = None  # the generator whose state the device currently holds
         self._vs = native.VideoState()   # one staging buffer for every state round trip
+        self._vb_mem = None              # the brief lives in pinned memory: it is also fetched behind a launch, asynchronously
         self._vb = native.VideoBrief()
+        self._brief_applied = True       # what self._vb says about the global RNG positions / out_of_work has reached the host
         self._rng_seen = None  # the global (random, np.random) states as this object last left or read them
         self._brief_fresh = False  # self._vb describes the device state as it stands
         self._dev_main = self._dev_aux = None   # the live generator's target on the device
+        self._up_main = self._up_aux = None     # ... and what was last copied there (a bank flip within a frame re-uses it)
+        self._ops_dev = self._ops_host = None   # opcode buffers: device, and pinned host memory the launch copies into
         # what the caller's pacing has shown so far (only the size of speculative launches depends on it)
         self._tick_now = None     # the latest tick() argument
         self._ops_done = 0        # opcodes consumed from settled chunks
@@ -192,7 +196,9 @@ class Video:
         self._out_of_work = value
         if not self._touched:  # the device's copy is the one the next launch reads
             self._enc.set_state(native.STATE_OUT_OF_WORK, np.array([int(bool(value[False])), int(bool(value[True]))], np.int32))
-            self._brief_fresh = False
+            # (the brief at hand stays good: the two flags are all that changed on the device, and they are known)
+            self._vb.out_of_work[0] = int(bool(value[False]))
+            self._vb.out_of_work[1] = int(bool(value[True]))
 
     @property
     def aux_memory_map(self):
@@ -298,33 +304,59 @@ class Video:
         self._brief_fresh = False
         self._rng_seen = (tuple(py.tolist()), raw)
 
+    def _pinned_brief(self):
+        """self._vb in page-locked memory (allocated with the first launch: torch is needed for it)"""
+        if self._vb_mem is None:
+            import ctypes
+            import torch
+            self._vb_mem = torch.empty(ctypes.sizeof(native.VideoBrief), dtype=torch.uint8).pin_memory()
+            self._vb = native.VideoBrief.from_address(self._vb_mem.data_ptr())
+        return self._vb
+
     def _sync_brief(self):
         """Settle the device state and bring home the small things: global RNG positions, out_of_work
-        (and the numbers encode_frame prints / asserts).  The arrays stay on the device."""
+        (and the numbers encode_frame prints / asserts).  The arrays stay on the device.  The brief itself usually is at
+        hand already: it travels behind every launch (_launch), valid as long as the launch's opcodes are all consumed."""
         self._settle(download=False)
         if self._host_current:
             return None  # nothing on the device is newer than what the host holds
-        if self._brief_fresh:
-            return self._vb
-        b = self._enc.get_video_brief(out=self._vb)
-        if not self._global_rng_moved():  # (else the caller's draws / reseed win: uploaded at the next launch)
-            self._set_global_rng(b)
-        self._out_of_work[False] = bool(b.out_of_work[0])
-        self._out_of_work[True] = bool(b.out_of_work[1])
-        self._brief_fresh = True
+        if not self._brief_fresh:
+            self._enc.get_video_brief(out=self._pinned_brief())
+            self._brief_fresh = True
+            self._brief_applied = False
+        b = self._vb
+        if not self._brief_applied:
+            if not self._global_rng_moved():  # (else the caller's draws / reseed win: uploaded at the next launch)
+                self._set_global_rng(b)
+            self._out_of_work[False] = bool(b.out_of_work[0])
+            self._out_of_work[True] = bool(b.out_of_work[1])
+            self._brief_applied = True
         return b
 
     def _launch(self, token, restart, n_ops, fetch=True):
         """[prologue +] n_ops greedy steps on the device state as it stands.  fetch=False: a replay of opcodes the caller has
         already consumed (after a roll-back): nothing to bring home and nothing that can fail -- the speculative launch they
         came from passed its check, and this is a prefix of it -- so the launch is only enqueued."""
+        import torch
         self._brief_fresh = False
-        ops = self._enc.encode(token.fm, token.fa, [(0, int(bool(token.is_aux)), int(restart), int(n_ops))])
+        n_ops = int(n_ops)
+        if self._ops_dev is None or self._ops_dev.shape[1] < n_ops:
+            cap = max(n_ops, 2048)
+            self._ops_dev = torch.empty((1, cap, 6), dtype=torch.uint8, device="cuda")
+            self._ops_host = torch.empty((cap, 6), dtype=torch.uint8).pin_memory()
+        ops = self._enc.encode(token.fm, token.fa, [(0, int(bool(token.is_aux)), int(restart), n_ops)], ops_out=self._ops_dev)
         self._host_current = False
         if not fetch:
             return None
+        # the opcodes and the brief of the state behind them ride home on the stream, one wait for everything: if the caller
+        # pulls all of them -- the rule when the launch was sized by its pacing -- the next generator starts without
+        # another round trip
+        self._ops_host[:n_ops].copy_(ops[0], non_blocking=True)
+        self._enc.get_video_brief_async(self._pinned_brief())
         self._enc.check()
-        return ops[0].cpu().numpy()
+        self._brief_fresh = True
+        self._brief_applied = False
+        return self._ops_host[:n_ops].numpy()
 
     def _settle(self, download=True):
         """Make the device state -- and, with download, the host's -- reflect exactly the opcodes consumed so far."""
@@ -336,6 +368,7 @@ class Video:
             # abandoned mid-chunk: restore the snapshot and replay only what was consumed
             self._enc.rollback()
             self._host_current = False
+            self._brief_fresh = False   # (what travelled behind the launch describes all of its opcodes)
             if p["consumed"]:
                 self._launch(p["token"], p["restart"], p["consumed"], fetch=False)
             elif p["restart"]:
@@ -420,9 +453,13 @@ class Video:
                 if paced and speculative:
                     chunk = max(1, self._paced_chunk())
                 if restart:
-                    self._dev_main.copy_(torch.from_numpy(token.main))
-                    if token.aux is not None:
+                    # (the generators of one frame share their target: only what differs from the last upload travels)
+                    if self._up_main is None or not np.array_equal(self._up_main, token.main):
+                        self._dev_main.copy_(torch.from_numpy(token.main))
+                        self._up_main = token.main
+                    if token.aux is not None and (self._up_aux is None or not np.array_equal(self._up_aux, token.aux)):
                         self._dev_aux.copy_(torch.from_numpy(token.aux))
+                        self._up_aux = token.aux
                 if speculative:
                     self._enc.snapshot()
                     try:

@@ -305,6 +305,10 @@ typedef struct iiv_video_brief {
     uint32_t rng_py[625], rng_np[625];
 } iiv_video_brief;
 int iiv_encoder_get_video_brief(iiv_encoder *enc, int stream_index, iiv_video_brief *host_out);
+/* The same, enqueued on `stream` behind the launches already there (an iiv_encode of a generator's opcodes: the brief then
+ * describes the state after them): nothing waits; *host_out is complete once the stream has been synchronised
+ * (iiv_encoder_check does).  host_out should be pinned memory. */
+int iiv_encoder_get_video_brief_async(iiv_encoder *enc, int stream_index, iiv_video_brief *host_out, void *stream);
 
 /* Copy / restore the complete state of every stream (screen, priorities, live
  * generator, both RNG streams) on the device.  A caller that must not run ahead of
