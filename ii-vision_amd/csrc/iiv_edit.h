@@ -102,133 +102,32 @@ template <int N> struct EditStep<N, N> {
     __device__ static inline void run(uint64_t, uint32_t, uint64_t, uint32_t, const uint16_t *, uint32_t &, uint32_t &) {}
 };
 
-// The same recurrence for strings delivered one pixel per byte and already paired:
-// byte j of xs[g] = a << 4 | b of pixel 4g + j (exactly the index into lut), so a step
-// needs one byte extract for the lookup, and its transposition test -- a_{k-1} == b_k and
-// a_k == b_{k-1} -- is "this byte equals the previous byte with its nibbles swapped".
-// G = number of 32-bit groups, LAST = pixels in the last group.
-template <int K, int N> struct EditStepBytes {
-    template <typename X>
-    __device__ static inline void run(const X &xs, const X &ys, const uint16_t *lut, uint32_t &e1, uint32_t &e2)
-    {
-        const uint32_t idx = (xs[K >> 2] >> (8 * (K & 3))) & 0xffu;
-        uint32_t e = e1 + (uint32_t)lut[idx];
-        if (K >= 1) {
-            const uint32_t prev_swapped = (ys[(K - 1) >> 2] >> (8 * ((K - 1) & 3))) & 0xffu;
-            const uint32_t t = e2 + 1;
-            if (idx == prev_swapped && t < e) e = t;
-        }
-        e2 = e1;
-        e1 = e;
-        EditStepBytes<K + 1, N>::run(xs, ys, lut, e1, e2);
-    }
-};
-template <int N> struct EditStepBytes<N, N> {
-    template <typename X>
-    __device__ static inline void run(const X &, const X &, const uint16_t *, uint32_t &, uint32_t &) {}
-};
-
-// pixel p of the string sits in byte p % 4 of group p / 4 (groups may be partly filled: the
-// caller lays the pixels out so that N consecutive byte slots are used)
-template <int N, int G>
-__device__ inline uint32_t edit_distance_bytes(const uint32_t (&src)[G], const uint32_t (&tgt)[G], const uint16_t *lut)
+// ---- HGR windows as dots: two small lookups (the prologue's diff weights, iiv_prologue.hip) ----------------
+// to_dots<kHGR> of a 14-bit window is the OR of what its low seven bits and its high seven bits paint, each taken
+// together with the palette bit of the byte itself (bit 10 of an even byte's window, bit 3 of an odd one's), which
+// decides where the body's doubled dots start (checked for every window of both parities by hgr_dot_lut_check,
+// iiv_tables.hip, at table build time).  Table layout, u32 entries holding `dots << 1` (bit 0 = "dot -1" = 0, as the
+// pair-term table wants it, iiv_tables.hip: dw_piece_kernel):
+//     even bytes: [0, 256) low part, index = bits 0..6 | palette bit << 7;   [256, 384) high part, index = bits 7..13
+//     odd bytes:  [384, 512) low part, index = bits 0..6;   [512, 768) high part, index = bits 7..13 | palette bit << 7
+constexpr int kHgrDotLutEntries = 768;
+__host__ __device__ inline uint32_t hgr_dot_slot_lo(uint32_t m, int odd)
 {
-    uint32_t xs[G], ys[G];
-#pragma unroll
-    for (int g = 0; g < G; g++) {
-        xs[g] = (src[g] << 4) | tgt[g];
-        ys[g] = (tgt[g] << 4) | src[g];  // xs with the nibbles of every byte swapped (one v_lshl_or each)
-    }
-    uint32_t e1 = 0, e2 = 0;
-    EditStepBytes<0, N>::run(xs, ys, lut, e1, e2);
-    return e1;
+    return odd ? 384u + (m & 0x7fu) : ((m & 0x7fu) | ((m >> 3) & 0x80u));
 }
-
-// Two distances at once in packed 16-bit arithmetic (every value of the recurrence is <= 18 x 113 < 2^11): the
-// two strings' steps share the v_pk_add / v_pk_min, only the two cost lookups stay separate.  The transposition
-// test becomes arithmetic: x = (this byte) ^ (previous byte with its nibbles swapped) is 0 exactly where the
-// transposition exists, and its cost is then 1 + 0x3fff * min(x, 1) -- a value no path through a missing
-// transposition can undercut (e2 + 0x4000 > e1 + any substitution cost, and nothing overflows 16 bits).
-typedef unsigned short edit_u16x2 __attribute__((ext_vector_type(2)));
-// byte KB of string a in bits 0..7, byte KB of string b in bits 16..23 (v_perm_b32: bytes 0..3 of the second
-// operand are selectors 0..3, of the first 4..7; 0x0c = the constant 0)
-template <int KB> __device__ static inline uint32_t edit_pair_bytes(uint32_t a, uint32_t b)
+__host__ __device__ inline uint32_t hgr_dot_slot_hi(uint32_t m, int odd)
 {
-    return __builtin_amdgcn_perm(b, a, 0x0c000c00u | (uint32_t)KB | ((uint32_t)(4 + KB) << 16));
+    return odd ? 512u + ((m >> 7) | ((m << 4) & 0x80u)) : 256u + (m >> 7);
 }
-template <int K, int N> struct EditStepPair {
-    template <typename X>
-    __device__ static inline void run(const X &xa, const X &ya, const X &xb, const X &yb, const uint16_t *lut, uint32_t prev_swapped,
-                                      edit_u16x2 &e1, edit_u16x2 &e2)
-    {
-        const uint32_t idx = edit_pair_bytes<(K & 3)>(xa[K >> 2], xb[K >> 2]);   // the two lookup indices, one per half
-        const uint32_t s = (uint32_t)lut[idx & 0xffu] | ((uint32_t)lut[idx >> 16] << 16);
-        edit_u16x2 e = e1 + __builtin_bit_cast(edit_u16x2, s);
-        if (K >= 1) {
-            // (inline assembly: written as min / multiply-add the compiler turns it into two compares, two
-            // selects and a repack)
-            uint32_t tc;
-            asm("v_pk_min_u16 %0, %1, %2\n\tv_pk_mad_u16 %0, %0, %3, %2" : "=&v"(tc) : "v"(idx ^ prev_swapped), "v"(0x00010001u), "v"(0x3fff3fffu));
-            e = __builtin_elementwise_min(e, e2 + __builtin_bit_cast(edit_u16x2, tc));
-        }
-        e2 = e1;
-        e1 = e;
-        EditStepPair<K + 1, N>::run(xa, ya, xb, yb, lut, K + 1 < N ? edit_pair_bytes<(K & 3)>(ya[K >> 2], yb[K >> 2]) : 0u, e1, e2);
-    }
-};
-template <int N> struct EditStepPair<N, N> {
-    template <typename X>
-    __device__ static inline void run(const X &, const X &, const X &, const X &, const uint16_t *, uint32_t, edit_u16x2 &, edit_u16x2 &) {}
-};
-template <int N, int G>
-__device__ inline void edit_distance_bytes_pair(const uint32_t (&src_a)[G], const uint32_t (&tgt_a)[G], const uint32_t (&src_b)[G],
-                                                const uint32_t (&tgt_b)[G], const uint16_t *lut, uint32_t &d_a, uint32_t &d_b)
+// a window that has slot `t`'s bits and no others (what the table's entry is computed from), and its parity
+__host__ __device__ inline uint32_t hgr_dot_slot_window(int t, int &odd)
 {
-    uint32_t xa[G], ya[G], xb[G], yb[G];
-#pragma unroll
-    for (int g = 0; g < G; g++) {
-        xa[g] = (src_a[g] << 4) | tgt_a[g];
-        ya[g] = (tgt_a[g] << 4) | src_a[g];
-        xb[g] = (src_b[g] << 4) | tgt_b[g];
-        yb[g] = (tgt_b[g] << 4) | src_b[g];
-    }
-    edit_u16x2 e1 = {0, 0}, e2 = {0, 0};
-    EditStepPair<0, N>::run(xa, ya, xb, yb, lut, 0u, e1, e2);
-    d_a = e1.x;
-    d_b = e1.y;
-}
-
-// HGR colour strings from three small lookups: pixels 0..5, 6..11 and 12..17 of a window's string
-// depend on only 7, 6 and 7 of its 14 bits (found by brute force over all 2 x 2^14 windows: flip a
-// bit, see which pixels can change -- the palette bit of the byte itself reaches every pixel of
-// its group, a neighbour's only the pixels next to it):
-//     even byte:  bits 0..5 and 10 | bits 4..8 and 10 | bits 7..13
-//     odd byte:   bits 0..6        | bits 3 and 5..9  | bits 3 and 8..13
-// hgr_group_index compresses a window to the index of group g; hgr_group_window is its inverse
-// with every other bit zero (a representative window for building the table).
-constexpr int kHgrGroupEntries = 320;  // 128 + 64 + 128 per parity
-__host__ __device__ constexpr int hgr_group_base(int g) { return g == 0 ? 0 : g == 1 ? 128 : 192; }
-__host__ __device__ inline uint32_t hgr_group_index(uint32_t m, int g, int odd)
-{
-    if (!odd) {
-        if (g == 0) return (m & 0x3fu) | ((m >> 4) & 0x40u);
-        if (g == 1) return ((m >> 4) & 0x1fu) | ((m >> 5) & 0x20u);
-        return m >> 7;
-    }
-    if (g == 0) return m & 0x7fu;
-    if (g == 1) return ((m >> 3) & 1u) | ((m >> 4) & 0x3eu);
-    return ((m >> 3) & 1u) | ((m >> 7) & 0x7eu);
-}
-__host__ __device__ inline uint32_t hgr_group_window(uint32_t idx, int g, int odd)
-{
-    if (!odd) {
-        if (g == 0) return (idx & 0x3fu) | ((idx & 0x40u) << 4);
-        if (g == 1) return ((idx & 0x1fu) << 4) | ((idx & 0x20u) << 5);
-        return idx << 7;
-    }
-    if (g == 0) return idx;
-    if (g == 1) return ((idx & 1u) << 3) | ((idx & 0x3eu) << 4);
-    return ((idx & 1u) << 3) | ((idx & 0x7eu) << 7);
+    const uint32_t u = (uint32_t)t;
+    odd = t >= 384;
+    if (t < 256) return (u & 0x7fu) | ((u & 0x80u) << 3);
+    if (t < 384) return (u - 256u) << 7;
+    if (t < 512) return u - 384u;
+    return (((u - 512u) & 0x7fu) << 7) | (((u - 512u) & 0x80u) >> 4);
 }
 
 template <int N>

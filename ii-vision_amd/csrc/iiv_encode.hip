@@ -69,8 +69,8 @@ struct Encoder {
     uint32_t *d_joint_l, *d_joint_r; // narrow form, content innermost, two byte values per word (IIV_CONTENT_JOINT; built on first use)
     void *d_brief;                   // iiv_encoder_get_video_brief's staging struct
     ulonglong2 *d_strings;  // colour string of every masked value (recurrence mode)
-    uint2 *d_hgr_slut;      // HGR: the three-lookup string table the prologue copies into LDS (iiv_edit.h)
-    uint32_t *d_dw_pieces;  // DHGR: the diff weights' pair-term table the prologue copies into LDS (iiv_tables.hip)
+    uint32_t *d_hgr_dots;   // HGR: the window -> dots lookups the prologue copies into LDS (iiv_edit.h: hgr_dot_slot_lo)
+    uint32_t *d_dw_pieces;  // the diff weights' pair-term table the prologue copies into LDS (iiv_tables.hip: dw_piece_kernel)
     uint16_t *d_sub;        // 16x16 substitute costs
     int dw_mode;            // IIV_DW_TABLE / IIV_DW_RECURRENCE
     int greedy_mode;        // IIV_GREEDY_WAVE / IIV_GREEDY_WORKGROUP / IIV_GREEDY_AUTO
@@ -258,7 +258,7 @@ void encoder_destroy(Encoder *e)
     if (e->d_states) (void)hipFree(e->d_states);
     if (e->d_snapshot) (void)hipFree(e->d_snapshot);
     if (e->d_strings) (void)hipFree(e->d_strings);
-    if (e->d_hgr_slut) (void)hipFree(e->d_hgr_slut);
+    if (e->d_hgr_dots) (void)hipFree(e->d_hgr_dots);
     if (e->d_dw_pieces) (void)hipFree(e->d_dw_pieces);
     if (e->d_sub) (void)hipFree(e->d_sub);
     if (e->d_left) (void)hipFree(e->d_left);
@@ -308,7 +308,7 @@ int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, c
     e->d_brief = nullptr;
     e->d_states = e->d_snapshot = nullptr;
     e->d_strings = nullptr;
-    e->d_hgr_slut = nullptr;
+    e->d_hgr_dots = nullptr;
     e->d_dw_pieces = nullptr;
     e->d_sub = nullptr;
     e->dw_mode = dm ? IIV_DW_RECURRENCE : IIV_DW_TABLE;
@@ -376,8 +376,8 @@ int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, c
         }
         if (dm) {
             if ((rc = build_strings(mode, dm, &e->d_strings, &e->d_sub, 0))) break;
-            if (mode == kHGR && (rc = build_hgr_string_lut(&e->d_hgr_slut, 0))) break;
-            if (mode == kDHGR && (rc = build_dw_piece_table(e->d_sub, &e->d_dw_pieces, 0))) break;
+            if (mode == kHGR && (rc = build_hgr_dot_lut(&e->d_hgr_dots, 0))) break;
+            if ((rc = build_dw_piece_table(mode, e->d_sub, &e->d_dw_pieces, 0))) break;
             if ((rc = hip_check(hipMalloc(&e->d_left, split_entries(mode, 0) * 4), "hipMalloc(split left)"))) break;
             if ((rc = hip_check(hipMalloc(&e->d_right, split_entries(mode, 1) * 4), "hipMalloc(split right)"))) break;
             if ((rc = build_split_tables(mode, e->d_strings, e->d_sub, e->d_left, e->d_right, 0))) break;
@@ -952,7 +952,7 @@ static int launch_round(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux,
     if (any_prologue) {
         if (e->profiling) { int prc = prof_begin(e, 0, st, slot); if (prc) return prc; }
         const PrologueArgs pa{e->d_states, d_main, d_aux, n_frames, e->n_streams, d_round, seg_stride, e->d_table, e->d_strings,
-                              e->d_sub, e->d_dwl, e->d_dwr, e->d_hgr_slut, e->d_dw_pieces};
+                              e->d_sub, e->d_dwl, e->d_dwr, e->d_hgr_dots, e->d_dw_pieces};
         int prc2 = launch_prologue(e->mode, e->dw_mode, pa, st);
         if (prc2) return prc2;
         if (e->profiling) { int prc = prof_end(e, slot, st); if (prc) return prc; }

@@ -30,9 +30,9 @@ int pixel_strings(int mode, uint32_t *d_dots, uint8_t *d_pixels, ulonglong2 *d_s
 int build_table(int mode, const int32_t dm[256], uint16_t *d_out, int symmetric, hipStream_t st);
 int build_store_table(int mode, const int32_t dm[256], uint16_t *d_out, hipStream_t st);
 int build_strings(int mode, const int32_t dm[256], ulonglong2 **d_strings, uint16_t **d_sub, hipStream_t st);
-int build_hgr_string_lut(uint2 **d_out, hipStream_t st);
+int build_hgr_dot_lut(uint32_t **d_out, hipStream_t st);   // HGR: windows -> dots, two lookups (iiv_edit.h: hgr_dot_slot_lo)
 int check_dw_piece_table(int mode, const int32_t dm[256], const uint16_t *d_table, unsigned long long *mismatches, hipStream_t st);
-int build_dw_piece_table(const uint16_t *d_sub, uint32_t **d_out, hipStream_t st);   // DHGR: [2 banks][4096] u32
+int build_dw_piece_table(int mode, const uint16_t *d_sub, uint32_t **d_out, hipStream_t st);   // DHGR: [2 banks][4096] u32; HGR: [4096]
 size_t split_entries(int mode, int right);
 int build_split_tables(int mode, const ulonglong2 *d_strings, const uint16_t *d_sub, uint32_t *d_left, uint32_t *d_right,
                        hipStream_t st);

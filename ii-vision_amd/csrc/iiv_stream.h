@@ -5,6 +5,7 @@
 #pragma once
 
 #include "iiv_device.h"
+#include "iiv_edit.h"
 
 #include <type_traits>
 
@@ -32,7 +33,35 @@ __host__ __device__ inline uint32_t wd_word(uint32_t row_left, uint32_t row_righ
 __host__ __device__ inline uint32_t wd_dw(uint32_t wd) { return (0u - wd) & ((1u << kWdDwBits) - 1u); }   // the diff weight back
 __host__ __device__ inline uint32_t wd_off_left(uint32_t wd) { return wd >> kWdLeftShift; }
 __host__ __device__ inline uint32_t wd_off_right(uint32_t wd) { return (wd >> kWdRightShift) & 0x3ffu; }
-constexpr uint32_t kDwPieceBias = 512;   // added to every entry of the DHGR prologue's pair-term table (its terms can be negative)
+constexpr uint32_t kDwPieceBias = 512;   // added to every entry of the prologue's pair-term table (its terms can be negative)
+// An HGR diff weight as the sum of its nine pair terms (iiv_tables.hip: dw_piece_kernel): the two windows as dots (two
+// lookups each, iiv_edit.h: hgr_dot_slot_lo), then per pixel pair i the six dots 2i-1 .. 2i+4 of both as the index
+// cur6 * kHgrPieceStride + tgt6 into G, whose word holds the pair's two rotation classes (even bytes: class i & 1; odd
+// bytes, whose phase differs by 2, the other one).  `dots` / `g` = the two tables wherever the caller keeps them (the
+// prologue: LDS; the exhaustive check, iiv_tables.hip: dw_piece_check_hgr_kernel: HBM) -- one function, so that what is
+// checked against every entry of the full table is what the prologue runs.
+// Why the stride is 67 and not 64: HGR's dots come in equal pairs (HGRBitmap._double_pixels, screen.py:712-739), so six
+// consecutive dots take 8 or 16 of their 64 values, and with rows of 64 words the LDS bank of a lookup -- word index mod
+// 32 -- is five of the TARGET's dots alone: 32 lanes fell on 8 banks, 5.6 LDS cycles per 32-lane group instead of the
+// 3.5 of a uniformly random gather (measured: SQ_LDS_BANK_CONFLICT 815 cycles per wave, 4 per LDS instruction).  With
+// rows of 67 words the bank is (3 x cur6 + tgt6) mod 32, which spreads the doubled patterns of both windows over all
+// banks (3.5 cycles, simulated over random screens for every stride from 64 to 95); the multiply-add that forms the
+// address replaces a shift-or, so it costs no instruction.
+constexpr uint32_t kHgrPieceStride = 67;
+constexpr uint32_t kHgrPieceWords = 4288;   // >= 63 * 67 + 64, a multiple of four (copied to LDS 16 B per lane)
+__device__ __forceinline__ uint32_t hgr_dw_pieces_sum(const uint32_t *__restrict__ dots, const unsigned char *__restrict__ g, uint32_t cm, uint32_t tm, int odd)
+{
+    const uint32_t Dc = dots[hgr_dot_slot_lo(cm, odd)] | dots[hgr_dot_slot_hi(cm, odd)];
+    const uint32_t Dt = dots[hgr_dot_slot_lo(tm, odd)] | dots[hgr_dot_slot_hi(tm, odd)];
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const uint32_t cur6 = __builtin_amdgcn_ubfe(Dc, 2 * i, 6);
+        const uint32_t tgt6x4 = (i == 0 ? Dt << 2 : i == 1 ? Dt : Dt >> (2 * i - 2)) & 0xfcu;
+        acc += *reinterpret_cast<const uint16_t *>(g + (__umul24(cur6, 4u * kHgrPieceStride) + tgt6x4) + 2 * ((i & 1) ^ odd));
+    }
+    return acc - 9u * kDwPieceBias;
+}
 constexpr int kMaxValue = 2047;  // every table value and diff weight must fit 11 bits
 
 struct StreamState {
@@ -395,8 +424,8 @@ struct PrologueArgs {
     const ulonglong2 *strings;      // colour-string LUT
     const uint16_t *sub;            // 16 x 16 substitution costs
     const uint32_t *dwl, *dwr;      // split diff-weight table (IIV_DW_SPLIT)
-    const uint2 *hgr_slut;          // HGR: three-lookup string table
-    const uint32_t *dw_pieces;      // DHGR: the diff weights' pair terms, [2 banks][4096] (iiv_tables.hip: dw_piece_kernel)
+    const uint32_t *hgr_dots;       // HGR: windows -> dots, [kHgrDotLutEntries] (iiv_tables.hip: hgr_dot_lut_kernel)
+    const uint32_t *dw_pieces;      // the diff weights' pair terms, DHGR [2 banks][4096], HGR [4096] (iiv_tables.hip: dw_piece_kernel)
 };
 int launch_prologue(int mode, int dw_mode, const PrologueArgs &a, hipStream_t st);
 struct WorkgroupArgs {

@@ -599,59 +599,60 @@ int pixel_strings(int mode, uint32_t *d_dots, uint8_t *d_pixels, ulonglong2 *d_s
                          : pixel_strings_impl<kHGR>(d_dots, d_pixels, d_strings, st);
 }
 
-// The table behind hgr_group_index (iiv_edit.h): entry (parity, group g, index) = the six pixels
-// 6g .. 6g + 5 of a representative window's string, one pixel per byte, already in the byte slots
-// they have among the five words of an 18-pixel string (group 0: words 0, 1; group 1: words 1, 2;
-// group 2: words 3, 4), so a string is three entries OR-ed together.
-__global__ __launch_bounds__(64) void hgr_string_lut_kernel(uint2 *__restrict__ out)
+// The HGR prologue's dot lookups (iiv_edit.h: hgr_dot_slot_lo / _hi): entry t = to_dots of a window that has slot t's bits
+// and no others, shifted up by one.
+__global__ __launch_bounds__(64) void hgr_dot_lut_kernel(uint32_t *__restrict__ out)
 {
     const int t = blockIdx.x * 64 + threadIdx.x;
-    if (t >= 2 * kHgrGroupEntries) return;
-    const int odd = t / kHgrGroupEntries, e = t % kHgrGroupEntries;
-    const int g = e < 128 ? 0 : e < 192 ? 1 : 2;
-    const uint32_t m = hgr_group_window((uint32_t)(e - hgr_group_base(g)), g, odd);
-    uint64_t lo;
-    uint32_t hi;
-    colour_string<kHGR>(m, odd, lo, hi);
-    uint32_t w[5] = {0, 0, 0, 0, 0};
-    for (int p = 6 * g; p < 6 * g + 6; p++) {
-        const uint32_t px = p < 16 ? (uint32_t)(lo >> (4 * p)) & 0xfu : (hi >> (4 * (p - 16))) & 0xfu;
-        w[p >> 2] |= px << (8 * (p & 3));
-    }
-    const int first = g == 0 ? 0 : g == 1 ? 1 : 3;
-    out[t] = make_uint2(w[first], w[first + 1]);
+    if (t >= kHgrDotLutEntries) return;
+    int odd;
+    const uint32_t m = hgr_dot_slot_window(t, odd);
+    out[t] = to_dots<kHGR>(m, odd) << 1;
 }
-
-int build_hgr_string_lut(uint2 **d_out, hipStream_t st)
+// ... and that OR-ing the two parts gives to_dots for EVERY window of both parities (counted, not assumed)
+__global__ __launch_bounds__(256) void hgr_dot_lut_check_kernel(const uint32_t *__restrict__ lut, unsigned long long *__restrict__ mismatches)
 {
-    IIV_HIP(hipMalloc(d_out, 2 * kHgrGroupEntries * sizeof(uint2)));
-    hipLaunchKernelGGL(hgr_string_lut_kernel, dim3((2 * kHgrGroupEntries + 63) / 64), dim3(64), 0, st, *d_out);
-    return hip_check(hipGetLastError(), "hgr_string_lut_kernel launch");
+    const int idx = blockIdx.x * 256 + threadIdx.x;   // odd << 14 | window
+    if (idx >= (2 << 14)) return;
+    const int odd = idx >> 14;
+    const uint32_t m = (uint32_t)idx & 0x3fffu;
+    if ((lut[hgr_dot_slot_lo(m, odd)] | lut[hgr_dot_slot_hi(m, odd)]) != (to_dots<kHGR>(m, odd) << 1)) atomicAdd(mismatches, 1ull);
 }
 
-// ------------------------------------------------------------------ diff weights as a sum of local terms (DHGR prologue)
+int build_hgr_dot_lut(uint32_t **d_out, hipStream_t st)
+{
+    IIV_HIP(hipMalloc(d_out, kHgrDotLutEntries * sizeof(uint32_t)));
+    hipLaunchKernelGGL(hgr_dot_lut_kernel, dim3((kHgrDotLutEntries + 63) / 64), dim3(64), 0, st, *d_out);
+    return hip_check(hipGetLastError(), "hgr_dot_lut_kernel launch");
+}
+
+// ------------------------------------------------------------------ diff weights as a sum of local terms (the prologue's default)
 // The recurrence E[k] = min(E[k-1] + s_k, E[k-2] + 1 if pixels (k-1, k) transpose) (make_data_tables.py:92-108; iiv_edit.h)
 // collapses to a SUM for the strings it is applied to.  A colour string is a sliding 4-dot window, so a_{k-1}, a_k, a_{k+1}
 // cannot be X, Y, X with X != Y (the step k-1 -> k replaces the dot of one position class, the step k -> k+1 that of the
 // next): two transpositions never overlap, E[k-1] = E[k-2] + s_{k-1} wherever pixels (k-1, k) transpose, and
 //     distance = sum over k of g_k,    g_k = s_k, or min(s_k, 1 - s_{k-1}) where pixels (k-1, k) transpose.
 // g_k depends on dots k-1 .. k+3 of both windows, so two pixels' terms are one lookup by 6 + 6 dots -- five lookups and
-// five additions per DHGR distance instead of ten dependent steps of the recurrence.  (Checked against the recurrence for
-// every pair of windows: iiv_check_dw_piece_table / tests/test_gpu_tables.py, both palettes and random matrices.)
+// five additions per DHGR distance instead of ten dependent steps of the recurrence, nine per HGR distance instead of
+// eighteen (round 6: HGR's windows are turned into their 21 dots first, two small lookups each -- iiv_edit.h:
+// hgr_dot_slot_lo -- and from there on a dot is a dot: the SAME table form serves both modes).  (Checked against the
+// recurrence for every pair of windows: iiv_check_diff_weight_pieces / tests/test_gpu_tables.py, both modes, both palettes
+// and random matrices.)
 // Table: G[bank][cur6 << 6 | tgt6] = (g-sum of the pixel pair with rotation ph_e) | (... with rotation ph_e + 2) << 16, each
-// plus kDwPieceBias; ph_e = the phase of the bank's even bytes (its odd bytes' differs by 2), bit j of cur6 / tgt6 = dot
-// k - 1 + j, the pair being pixels (k, k + 1).  A window's dot -1 is 0 in both strings, which makes the term a pixel -1
-// would contribute vanish (a transposition of pixels (-1, 0) then needs equal colours all round).
-__global__ __launch_bounds__(256) void dw_piece_kernel(const uint16_t *__restrict__ sub, uint32_t *__restrict__ out)
+// plus kDwPieceBias; ph_e = the phase of the bank's even bytes (its odd bytes' differs by 2: DHGR [1, 0, 3, 2], HGR [1, 3]),
+// bit j of cur6 / tgt6 = dot k - 1 + j, the pair being pixels (k, k + 1).  A window's dot -1 is 0 in both strings, which makes
+// the term a pixel -1 would contribute vanish (a transposition of pixels (-1, 0) then needs equal colours all round).
+// DHGR: two banks (aux, then main), G[bank][cur6 << 6 | tgt6]; HGR: one, G[cur6 * kHgrPieceStride + tgt6] (iiv_stream.h).
+__global__ __launch_bounds__(256) void dw_piece_kernel(int mode, const uint16_t *__restrict__ sub, uint32_t *__restrict__ out)
 {
     __shared__ uint16_t lut[256];
     load_cost_lut(lut, sub, threadIdx.x);
     __syncthreads();
     const int idx = blockIdx.x * 256 + threadIdx.x;   // bank << 12 | cur6 << 6 | tgt6
-    if (idx >= 2 * 4096) return;
+    if (idx >= (mode == kDHGR ? 2 : 1) * 4096) return;
     const int bank = idx >> 12;
     const uint32_t cur6 = (idx >> 6) & 63u, tgt6 = idx & 63u;
-    const int ph_e = phase_of(kDHGR, byte_offset<kDHGR>(0, bank));
+    const int ph_e = mode == kDHGR ? phase_of(kDHGR, byte_offset<kDHGR>(0, bank)) : phase_of(kHGR, 0);
     uint32_t v = 0;
     for (int c = 0; c < 2; c++) {
         const int r = (ph_e + 2 * c) & 3;   // rotation of pixel k; k - 1 has r - 1, k + 1 has r + 1 (colours.py:100-134)
@@ -671,13 +672,17 @@ __global__ __launch_bounds__(256) void dw_piece_kernel(const uint16_t *__restric
         }
         v |= (uint32_t)(g + (int)kDwPieceBias) << (16 * c);
     }
-    out[idx] = v;
+    // (HGR: rows of kHgrPieceStride words, iiv_stream.h -- the LDS banks of its doubled dots; the gaps stay zero)
+    out[mode == kDHGR ? (uint32_t)idx : cur6 * kHgrPieceStride + tgt6] = v;
 }
 
-int build_dw_piece_table(const uint16_t *d_sub, uint32_t **d_out, hipStream_t st)
+int build_dw_piece_table(int mode, const uint16_t *d_sub, uint32_t **d_out, hipStream_t st)
 {
-    IIV_HIP(hipMalloc(d_out, 2 * 4096 * sizeof(uint32_t)));
-    hipLaunchKernelGGL(dw_piece_kernel, dim3(32), dim3(256), 0, st, d_sub, *d_out);
+    const int n = (mode == kDHGR ? 2 : 1) * 4096;
+    const size_t words = mode == kDHGR ? (size_t)n : (size_t)kHgrPieceWords;
+    IIV_HIP(hipMalloc(d_out, words * sizeof(uint32_t)));
+    IIV_HIP(hipMemsetAsync(*d_out, 0, words * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(dw_piece_kernel, dim3(n / 256), dim3(256), 0, st, mode, d_sub, *d_out);
     return hip_check(hipGetLastError(), "dw_piece_kernel launch");
 }
 
@@ -700,11 +705,22 @@ __global__ __launch_bounds__(256) void dw_piece_check_kernel(const uint32_t *__r
     if (acc - 5u * kDwPieceBias != (uint32_t)table[idx]) atomicAdd(mismatches, 1ull);
 }
 
+// every entry of the full symmetric HGR table (2 x 2^28) against the sum of its nine pair terms: the prologue's own function
+// (iiv_stream.h: hgr_dw_pieces_sum) on the tables where they lie
+__global__ __launch_bounds__(256) void dw_piece_check_hgr_kernel(const uint32_t *__restrict__ pieces, const uint32_t *__restrict__ dots,
+                                                                 const uint16_t *__restrict__ table, unsigned long long *__restrict__ mismatches)
+{
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;   // ((o << 14) + current) << 14) + target
+    if (idx >= ((size_t)2 << 28)) return;
+    const uint32_t tm = idx & 16383u, cm = (idx >> 14) & 16383u;
+    const int odd = (int)(idx >> 28);
+    if (hgr_dw_pieces_sum(dots, reinterpret_cast<const unsigned char *>(pieces), cm, tm, odd) != (uint32_t)table[idx]) atomicAdd(mismatches, 1ull);
+}
+
 int check_dw_piece_table(int mode, const int32_t dm[256], const uint16_t *d_table, unsigned long long *mismatches, hipStream_t st)
 {
-    if (mode != kDHGR) return set_error(IIV_ERR_INVALID, "the pair-term table exists for DHGR only");
     uint16_t sub[256], *d_sub = nullptr;
-    uint32_t *d_p = nullptr;
+    uint32_t *d_p = nullptr, *d_dots = nullptr;
     unsigned long long *d_cnt = nullptr;
     substitute_costs(dm, sub);
     int rc = IIV_OK;
@@ -713,14 +729,21 @@ int check_dw_piece_table(int mode, const int32_t dm[256], const uint16_t *d_tabl
         if ((rc = hip_check(hipMemcpy(d_sub, sub, sizeof(sub), hipMemcpyHostToDevice), "copy sub"))) break;
         if ((rc = hip_check(hipMalloc(&d_cnt, 8), "hipMalloc(count)"))) break;
         if ((rc = hip_check(hipMemsetAsync(d_cnt, 0, 8, st), "memset"))) break;
-        if ((rc = build_dw_piece_table(d_sub, &d_p, st))) break;
-        hipLaunchKernelGGL(dw_piece_check_kernel, dim3((unsigned)(((size_t)4 << 26) / 256)), dim3(256), 0, st, d_p, d_table, d_cnt);
+        if ((rc = build_dw_piece_table(mode, d_sub, &d_p, st))) break;
+        if (mode == kDHGR) {
+            hipLaunchKernelGGL(dw_piece_check_kernel, dim3((unsigned)(((size_t)4 << 26) / 256)), dim3(256), 0, st, d_p, d_table, d_cnt);
+        } else {
+            if ((rc = build_hgr_dot_lut(&d_dots, st))) break;
+            hipLaunchKernelGGL(hgr_dot_lut_check_kernel, dim3((2 << 14) / 256), dim3(256), 0, st, d_dots, d_cnt);
+            hipLaunchKernelGGL(dw_piece_check_hgr_kernel, dim3((unsigned)(((size_t)2 << 28) / 256)), dim3(256), 0, st, d_p, d_dots, d_table, d_cnt);
+        }
         if ((rc = hip_check(hipGetLastError(), "dw_piece_check_kernel launch"))) break;
         if ((rc = hip_check(hipMemcpyAsync(mismatches, d_cnt, 8, hipMemcpyDeviceToHost, st), "copy count"))) break;
         rc = hip_check(hipStreamSynchronize(st), "sync");
     } while (0);
     if (d_sub) (void)hipFree(d_sub);
     if (d_p) (void)hipFree(d_p);
+    if (d_dots) (void)hipFree(d_dots);
     if (d_cnt) (void)hipFree(d_cnt);
     return rc;
 }

@@ -270,8 +270,8 @@ def check_split_diff_table(mode, dm, table):
 
 
 def check_diff_weight_pieces(mode, dm, table):
-    """Entries of the full symmetric table that differ from the sum of pixel-pair terms the DHGR prologue
-    evaluates instead of the recurrence (include/iivision.h: iiv_check_diff_weight_pieces)."""
+    """Entries of the full symmetric table that differ from the sum of pixel-pair terms the prologue
+    evaluates instead of the recurrence (include/iivision.h: iiv_check_diff_weight_pieces); both modes."""
     dm = np.ascontiguousarray(dm, dtype=np.int32).reshape(256)
     n = C.c_ulonglong(0)
     check(lib().iiv_check_diff_weight_pieces(mode, hptr(dm), dptr(table), C.byref(n), stream_ptr()))

@@ -150,14 +150,16 @@ int iiv_build_narrow_store_table(int mode, const int32_t dm[256], const uint16_t
 int iiv_check_split_diff_table(int mode, const int32_t dm[256], const uint16_t *d_table,
                                unsigned long long *mismatches, void *stream);
 
-/* What the prologue's default diff-weight mode (IIV_DW_RECURRENCE) evaluates in DHGR: for the colour strings of
+/* What the prologue's default diff-weight mode (IIV_DW_RECURRENCE) evaluates: for the colour strings of
  * this machine -- sliding 4-dot windows, in which two transpositions can never overlap -- the edit-distance
  * recurrence of make_data_tables.py:92-108 is a plain SUM of per-pixel terms, each a function of two adjacent
- * pixels of both strings, so one distance is five lookups of pixel-pair terms (6 + 6 dots each) in a 16 KiB
- * table held in LDS (csrc/iiv_tables.hip: dw_piece_kernel).  This call builds that table from dm and compares
- * the sum, formed as the prologue forms it, with EVERY entry of d_table (iiv_build_table(..., symmetric = 1),
- * 4 x 2^26 entries); *mismatches receives the number of differing entries.  DHGR only (IIV_ERR_INVALID for HGR,
- * whose prologue runs the recurrence itself). */
+ * pixels of both strings, so one distance is five (DHGR, 10 pixels) or nine (HGR, 18 pixels) lookups of
+ * pixel-pair terms (6 + 6 dots each) in a 16 KiB table held in LDS (csrc/iiv_tables.hip: dw_piece_kernel).  An HGR
+ * window is first turned into its 21 dots (HGRBitmap.to_dots, screen.py:743-789) by two 128/256-entry lookups
+ * (csrc/iiv_edit.h: hgr_dot_slot_lo).  This call builds the tables from dm and compares the sum, formed as the
+ * prologue forms it, with EVERY entry of d_table (iiv_build_table(..., symmetric = 1): 4 x 2^26 entries DHGR,
+ * 2 x 2^28 HGR; HGR also: the two-lookup dots against to_dots for every window); *mismatches receives the number of
+ * differing entries. */
 int iiv_check_diff_weight_pieces(int mode, const int32_t dm[256], const uint16_t *d_table,
                                  unsigned long long *mismatches, void *stream);
 

@@ -162,19 +162,20 @@ def test_split_diff_weight_table_is_exact(native, device_tables, dms, mode, pal)
     assert native.check_split_diff_table(mode, dms[pal], other) > 0
 
 
+@pytest.mark.parametrize("mode", [1, 0])
 @pytest.mark.parametrize("pal", [5, 0])
-def test_diff_weights_as_sums_of_pair_terms_are_exact(native, device_tables, dms, pal):
-    """What the DHGR prologue evaluates by default (csrc/iiv_tables.hip: dw_piece_kernel): in a sliding-window colour
+def test_diff_weights_as_sums_of_pair_terms_are_exact(native, device_tables, dms, pal, mode):
+    """What the prologue evaluates by default (csrc/iiv_tables.hip: dw_piece_kernel): in a sliding-window colour
     string two transpositions never overlap, so the edit-distance recurrence is a SUM of per-pixel terms and a
-    distance is five lookups of pixel-pair terms.  The sum, formed with the prologue's own index arithmetic, must
-    equal the full symmetric table for EVERY (offset, current window, target window): 4 x 2^26 entries, compared on
-    the device.  (Random matrices: test_arbitrary_diff_matrices.)"""
-    table, _ = device_tables.get(1, pal)
-    assert native.check_diff_weight_pieces(1, dms[pal], table) == 0
-    other, _ = device_tables.get(1, 0 if pal == 5 else 5)
-    assert native.check_diff_weight_pieces(1, dms[pal], other) > 0     # (the check can fail)
-    with pytest.raises(native.IIVError):
-        native.check_diff_weight_pieces(0, dms[pal], table)            # HGR runs the recurrence itself
+    distance is five (DHGR) or nine (HGR: over the windows' dots, two lookups per window) lookups of pixel-pair terms.
+    The sum, formed by the prologue's own function / index arithmetic, must equal the full symmetric table for EVERY
+    (offset, current window, target window): 4 x 2^26 (DHGR) and 2 x 2^28 (HGR) entries, compared on the device; the
+    HGR run also compares the two-lookup dots with to_dots for every window.  (Random matrices:
+    test_arbitrary_diff_matrices.)"""
+    table, _ = device_tables.get(mode, pal)
+    assert native.check_diff_weight_pieces(mode, dms[pal], table) == 0
+    other, _ = device_tables.get(mode, 0 if pal == 5 else 5)
+    assert native.check_diff_weight_pieces(mode, dms[pal], other) > 0     # (the check can fail)
 
 
 def test_encoder_rejects_values_beyond_its_key_fields(native, device_tables):
@@ -328,8 +329,7 @@ def test_arbitrary_diff_matrices(native, O, mode, seed):
     exp, n_bad = native.build_narrow_store_table(mode, dm, dense)
     assert n_bad == 0 and bool((exp == dense).all())
     assert native.check_split_diff_table(mode, dm, table) == 0
-    if mode == 1:
-        assert native.check_diff_weight_pieces(mode, dm, table) == 0
+    assert native.check_diff_weight_pieces(mode, dm, table) == 0
     frames = _synth(mode, 2, 77 + seed, coherent=True)
     fm = torch.from_numpy(frames[None, :, 0].copy()).cuda()
     fa = torch.from_numpy(frames[None, :, 1].copy()).cuda() if mode == 1 else None
