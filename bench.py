@@ -13,12 +13,19 @@ of every clip; the defaults (20 steps x 50 frames) make each clip 1000 frames lo
 
 Inputs (targets, tables, stream state) are resident in HBM before the timed region.  The timed
 region is exactly K steps, bracketed by barrier + torch.cuda.synchronize() on both sides; the
-reported time is the MAX over ranks.
+reported time is the MAX over ranks.  Between the W warm-up steps and the timed region runs an
+untimed EVENTS leg (min(K, 3) of the same steps) in which the library records a HIP event pair
+around every kernel launch on the launch stream: the per-kernel launch durations of the roofline
+objects come from it, and the timed region runs without any event recording.
 
 Extra objects on the JSON line:
   roofline            greedy_wave_kernel (dominant): algorithmic bytes per launch (534 B per opcode,
-                      SURVEY.md 8d) / mean launch duration from HIP events recorded on the launch
-                      stream, against the 8 TB/s HBM peak; traffic from profiles/pmc_latest.json.
+                      SURVEY.md 8d) / mean launch duration from the events leg, against the 8 TB/s
+                      HBM peak.  `traffic`, `issue` and roofline_prologue's counter_* figures are
+                      quoted from the committed counter run profiles/pmc_latest.json ONLY when it
+                      carries this library's build id (iiv_version(); `build_id` in the line) and
+                      profiled the kernel instantiation that ran most launches here; otherwise they
+                      are null and traffic_source says "stale: ..." (tests/test_bench_counters.py).
   cpu_baseline        the oracle (C port of the reference path, one thread) timed on this host on a
                       bounded sample of the same workload; it also checks the GPU's opcodes of clip 0.
   vs_reference_python GPU / port-on-this-box x (port / reference Python, measured in the build
@@ -360,8 +367,11 @@ class GpuBackend:
         return self.batch.enc.profile_read()
 
     def launch_forms(self):
-        """greedy launches of the timed region by kernel form (iiv_encoder_launch_forms)"""
+        """greedy launches of the profiled (events) leg by kernel form (iiv_encoder_launch_forms)"""
         return self.batch.enc.launch_forms()
+
+    def build_id(self):
+        return self.native.build_id()
 
     def input_stats(self):
         """(share of the steps the nonces decided, form of the one-wave kernel the encoder has settled on) -- the encoder
@@ -434,7 +444,7 @@ def _run(args, backend_cls, quiet):
     # S-iid and S-img frames are to each other anyway; for S-coh / S-static that wrap would put one complete redraw into the
     # timed region, so those clips are as long as warm-up + timed region and never wrap.
     wraps = not (args.coherent or args.static)
-    n_frames = args.steps * F if wraps else (args.steps + args.warmup) * F
+    n_frames = args.steps * F if wraps else (args.steps + args.warmup + events_leg_steps(args.steps)) * F
     S = args.streams
     if S <= 0:
         per_clip = n_frames * 8192 * (2 if dhgr else 1) + 300 * 1024 + F * OPS_PER_FRAME * 6   # frames + stream state (292 KB) + opcodes
@@ -497,7 +507,7 @@ def _run(args, backend_cls, quiet):
             "palette": args.palette,
             "streams_per_gpu": S,
             **({"greedy_form": be.input_stats()[1], "nonce_decided_share_of_steps": round(be.input_stats()[0], 4),
-                "real_opcodes_per_stream_and_launch": round(be.batch.enc.real_opcodes_per_launch, 1)}
+                "real_opcodes_per_stream_and_launch": round(getattr(getattr(getattr(be, "batch", None), "enc", None), "real_opcodes_per_launch", 0.0), 1)}
                if hasattr(be, "input_stats") and be.uses_wave_kernel() else {}),
             "frames_per_step": F,
             "resident_clip_frames": n_frames,
@@ -513,11 +523,16 @@ def _run(args, backend_cls, quiet):
                               "frac": fps / n_gpus * BYTES_PER_FRAME[args.mode] / 1e9 / HBM_PEAK_GBS, "per": "GPU"},
         "diff_weights": "table-gather" if args.dw_table or args.dw == "table" else args.dw,
         "table_build_s": t_tab,
+        "build_id": be.build_id() if hasattr(be, "build_id") else None,   # iiv_version(): what committed counter runs must carry to be quoted
     }
 
     if rank == 0:
-        out.update(_roofline_objects(be, args, prof, op_count, seg_count, S, elapsed,
+        ev = leg["events"]
+        out.update(_roofline_objects(be, args, prof, ev["op_count"], ev["seg_count"], S, ev["elapsed"],
                                      live_ceiling=be.is_gpu and not args.no_extras))
+        out["events_leg"] = {"steps": ev["steps"], "ms_per_step": 1000.0 * ev["elapsed"] / max(ev["steps"], 1),
+                             "note": "untimed, between warm-up and timed region: the same steps with a HIP event pair around every kernel "
+                                     "launch; the roofline objects' launch durations come from it, `value` from the timed region (no events)"}
         port_fps = None
         want = (lambda name: True) if args.extras == "all" else (lambda name, _w=set(args.extras.split(",")): name in _w)
         if n_gpus == 1 and not args.no_extras and be.is_gpu:
@@ -565,32 +580,56 @@ def _run(args, backend_cls, quiet):
     return out
 
 
+def events_leg_steps(steps):
+    """Steps of the untimed leg that runs with HIP events around every kernel launch (the per-kernel split of the roofline
+    objects), between the warm-up and the timed region."""
+    return min(int(steps), 3)
+
+
 def timed_leg(be, steps, warmup, barrier=lambda: None):
-    """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides."""
+    """W untimed warm-up steps, an untimed EVENTS leg, then exactly K steps bracketed by barrier + synchronize on both sides.
+    The events leg (events_leg_steps(K) steps of the same work) is where the library records a HIP event pair around every
+    kernel launch on the launch stream (iiv_encoder_profile): the kernels' average launch durations -- roofline.achieved,
+    avg_launch_ms, kernel_time_share -- come from it, and the timed region that `value` is computed from runs with no
+    event recording at all (round 5 recorded them inside it)."""
     first_ops = None   # stream 0's opcodes of the first step, checked against the oracle by _cpu_baseline
     for i in range(warmup):
         segs0 = be.step()
         if i == 0:
             first_ops = be.first_ops(segs0)
     be.check()
+    # ---- the events leg
     be.profile(True)
+    barrier()
+    be.synchronize()
+    e0 = time.perf_counter()
+    ev_ops, ev_segs = 0, 0
+    for i in range(events_leg_steps(steps)):
+        segs = be.step()
+        if first_ops is None and i == 0:   # (only when there is no warm-up step; async D2D copy)
+            first_ops = be.first_ops(segs)
+        ev_ops += sum(s[3] for s in segs)
+        ev_segs += len(segs)
+    be.synchronize()
+    e1 = time.perf_counter()
+    prof = be.profile_read()
+    be.profile(False)
+    be.check()
+    # ---- the timed region
     barrier()
     be.synchronize()
     t0 = time.perf_counter()
     op_count, seg_count = 0, 0
     for i in range(steps):
         segs = be.step()
-        if first_ops is None and i == 0:   # (only when there is no warm-up step; async D2D copy)
-            first_ops = be.first_ops(segs)
         op_count += sum(s[3] for s in segs)
         seg_count += len(segs)
     be.synchronize()
     barrier()
     t1 = time.perf_counter()
     be.check()
-    prof = be.profile_read()
-    be.profile(False)
-    return {"elapsed": t1 - t0, "prof": prof, "op_count": op_count, "seg_count": seg_count, "first_ops": first_ops}
+    return {"elapsed": t1 - t0, "prof": prof, "op_count": op_count, "seg_count": seg_count, "first_ops": first_ops,
+            "events": {"steps": events_leg_steps(steps), "elapsed": e1 - e0, "op_count": ev_ops, "seg_count": ev_segs}}
 
 
 def _gather_ceiling_live(S, mode="DHGR", shared=False):
@@ -631,76 +670,92 @@ def _input_kind(args):
     return "iid"
 
 
-def _pmc_traffic(mode, S, kind="iid", fourth=False, field="greedy_hbm_bytes_per_launch_per_stream", kernel_field="kernel"):
-    """HBM bytes per greedy kernel launch from the committed rocprofv3 PMC summary
-    (profiles/pmc_latest.json) and where that number comes from -- it is NOT measured in this run.
-    The file holds bytes per launch AND PER STREAM for each mode and input kind it was collected on ("DHGR", "HGR":
-    S-iid; "DHGR:img": S-img; tools/profile_summary.py); the figure reported here is that times this run's stream
-    count, so that it compares with algorithmic_bytes_per_launch on the same mode, input and number of streams.
-    A leg on an input (or with an option) no counter run was made for reports null, not another input's bytes."""
-    p = os.path.join(ROOT, "profiles", "pmc_latest.json")
+PMC_LATEST = os.path.join(ROOT, "profiles", "pmc_latest.json")
+
+
+def expected_greedy_kernel(mode, form, fourth=False):
+    """The instantiation name tools/profile_summary.py records (`greedy_wave_kernel<mode, streams per workgroup, fourth>`) of
+    the one-wave kernel form that ran most launches of this run: 1 = DHGR, 0 = HGR; plain form 1 stream per workgroup, the
+    LDS-shared form 8 (DHGR) / 16 (HGR)."""
+    m = 1 if mode == "DHGR" else 0
+    w = 1 if form != "shared" else (8 if m else 16)
+    return "greedy_wave_kernel<%d, %d, %s>" % (m, w, "true" if fourth else "false")
+
+
+def _pmc_entry(mode, kind="iid", fourth=False, build_id=None, kernel=None):
+    """The committed counter run (profiles/pmc_latest.json, tools/profile_summary.py) for this mode / input -- or why it must
+    not be quoted: (entry or None, source text, status) with status "ok", "none" (no run of this mode / input / option is
+    committed) or "stale" (the run was taken with another build of the library -- its build_id is not iiv_version()'s -- or
+    its kernel is not the instantiation that ran most launches here).  The counters are NOT measured in this run; a kernel
+    change that is not followed by a new counter run makes them stale, and a stale figure is reported as null."""
     key = mode if kind == "iid" else "%s:%s" % (mode, kind)
     try:
-        with open(p) as f:
+        with open(os.environ.get("IIV_PMC_LATEST", PMC_LATEST)) as f:
             allkeys = json.load(f)
-        if fourth or key not in allkeys:
-            return None, "profiles/pmc_latest.json holds no counter run for %s%s (it has: %s)" % (
-                key, " with the fourth offset" if fourth else "", ", ".join(sorted(allkeys)))
-        d = allkeys[key]
-        return d[field] * S, \
-            "profiles/pmc_latest.json (%s at %d streams, bench args %s; per-stream bytes x %d streams): a committed " \
-            "counter run, not this run" % (d.get(kernel_field, "?"), d.get("streams", 0), " ".join(d.get("bench_args", [])), S)
     except Exception:
-        return None, None
-
-
-def _pmc_issue(mode, kind="iid", fourth=False):
-    """The `issue` object of the committed counter run for this mode / input (tools/profile_summary.py: issue_of): what the SQ
-    counters say binds the greedy kernel -- instructions per opcode and wave, instructions per clock and SIMD, vector-pipe
-    busy fraction, waves per SIMD.  None when no counter run of this mode / input / option is committed."""
-    key = mode if kind == "iid" else "%s:%s" % (mode, kind)
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
-            d = json.load(f)
-        return None if fourth else d.get(key, {}).get("issue")
-    except Exception:
-        return None
+        return None, None, "none"
+    if fourth or key not in allkeys:
+        return None, "profiles/pmc_latest.json holds no counter run for %s%s (it has: %s)" % (
+            key, " with the fourth offset" if fourth else "", ", ".join(sorted(allkeys))), "none"
+    d = allkeys[key]
+    if build_id is not None and d.get("build_id") != build_id:
+        return None, "stale: profiles/pmc_latest.json's %s run was taken with build %s, this library is build %s (re-run tools/round_evidence.sh)" % (
+            key, d.get("build_id", "<unstamped>"), build_id), "stale"
+    if kernel is not None and d.get("kernel") != kernel:
+        return None, "stale: profiles/pmc_latest.json's %s run profiled %s, this run's launches were %s" % (key, d.get("kernel"), kernel), "stale"
+    src = "profiles/pmc_latest.json (%s at %d streams, build %s, bench args %s; per-stream bytes x this run's streams): a committed " \
+          "counter run of this build, not this run" % (d.get("kernel", "?"), d.get("streams", 0), d.get("build_id", "?"), " ".join(d.get("bench_args", [])))
+    return d, src, "ok"
 
 
 def _roofline_objects(be, args, prof, op_count, seg_count, S, elapsed, live_ceiling):
-    """roofline (greedy kernel, dominant), roofline_access_pattern, roofline_prologue, kernel_time_share of one
-    timed leg, from the HIP events the library records around its launches on the launch stream."""
+    """roofline (greedy kernel, dominant), access_pattern_reference, roofline_prologue, kernel_time_share of one leg, from the
+    HIP events the library records around its launches on the launch stream (timed_leg's events leg: op_count, seg_count
+    and elapsed are that leg's).  achieved / frac are THIS run's measurement (SURVEY 8(d) algorithmic bytes over the launch
+    time the events give); what a committed counter run adds sits under counter_* keys and `traffic`, is tagged with its
+    build id, and is null -- traffic_source says "stale: ..." -- when that run is not of this build and kernel."""
     out = {}
     g_ms, g_n = prof["greedy_ms"], max(prof["greedy_launches"], 1)
     p_ms, p_n = prof["prologue_ms"], max(prof["prologue_launches"], 1)
-    greedy_bytes = float(op_count) * S * BYTES_PER_OPCODE       # all launches of the timed region
+    greedy_bytes = float(op_count) * S * BYTES_PER_OPCODE       # all launches of the leg
     achieved = greedy_bytes / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
-    traffic, traffic_source = _pmc_traffic(args.mode, S, _input_kind(args), getattr(args, "fourth", False))
-    issue = _pmc_issue(args.mode, _input_kind(args), getattr(args, "fourth", False)) if be.uses_wave_kernel() else None
+    fourth = getattr(args, "fourth", False)
+    bid = be.build_id() if hasattr(be, "build_id") else None
+    form = be.input_stats()[1] if hasattr(be, "input_stats") and be.uses_wave_kernel() else None
+    forms = be.launch_forms() if hasattr(be, "launch_forms") else None
+    if forms:   # the form that ran most launches of the leg
+        form = max(("plain", "shared", "team", "workgroup"), key=lambda k: forms.get(k, 0))
+    kernel = expected_greedy_kernel(args.mode, form, fourth) if (be.uses_wave_kernel() and form in ("plain", "shared")) else None
+    entry, traffic_source, status = _pmc_entry(args.mode, _input_kind(args), fourth, bid, kernel) if be.uses_wave_kernel() else (None, None, "none")
+    traffic = entry["greedy_hbm_bytes_per_launch_per_stream"] * S if entry else None
     out["roofline"] = {
         "kernel": "greedy_wave_kernel" if be.uses_wave_kernel() else "greedy_kernel",
-        # What binds the kernel is NOT the quantity the HBM fraction below measures: a step is ~310 instructions per wave, and at
-        # 4-7 waves per SIMD the SIMD's vector issue slot is two thirds to three quarters taken (`issue.valu_busy_frac`, at the
-        # 4 clocks per wave64 instruction this chip sustains) and its scalar slot likewise; 24 waves per CU run no faster than
-        # 16 (profiles/r05_occupancy_timing_experiment.txt), HBM (`traffic_frac`) is under 0.4.  achieved / peak / frac stay
-        # the SURVEY 8(d) HBM figure (algorithmic bytes over launch time), the contract's yardstick for the path.
+        "kernel_instantiation": kernel,
+        # What binds the kernel is NOT the quantity the HBM fraction below measures: a step is ~310 instructions per wave; at the
+        # rate a register-only loop of the same vector : scalar mix issues at this residency (tools/issue_probe.hip,
+        # profiles/r06_issue_probe.txt) issuing them takes `issue.issue_floor_frac` of the launch, the rest is dependent latency
+        # the resident waves do not cover; HBM (`traffic_frac`) is under 0.4.  achieved / peak / frac stay the SURVEY 8(d) HBM
+        # figure (algorithmic bytes over launch time), the contract's yardstick for the path.
         "bound": "issue",
         "frac_is": "algorithmic HBM bytes per launch / launch time / the 8 TB/s peak (SURVEY 8d) -- the contract's yardstick, not the binding resource",
-        "issue": issue,
+        "issue": entry.get("issue") if entry else None,
         "achieved": achieved,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
+        "measured_by": "HIP events around every launch on the launch stream, in an untimed leg of %s between warm-up and timed region" % (
+            "the same steps" if not hasattr(be, "is_gpu") or be.is_gpu else "a stand-in"),
         "peak_measured_read": HBM_MEASURED_READ_GBS,
         "traffic": traffic,
         "traffic_source": traffic_source,
+        "counters": status,
         "algorithmic_bytes_per_launch": greedy_bytes / g_n,
         "avg_launch_ms": g_ms / g_n,
         "launches": prof["greedy_launches"],
         "lookups_per_s": float(op_count) * S * 256 / (g_ms * 1e-3) if g_ms > 0 else 0.0,
-        # HBM bytes the counters saw (committed run) per launch / this run's launch time, against the peak: how busy HBM really is
+        # HBM bytes the counters saw (committed run of this build) per launch / this run's launch time, against the peak: how busy HBM really is
         "traffic_frac": (traffic / (g_ms / g_n * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and g_ms > 0) else None,
-        "launches_by_form": be.launch_forms() if hasattr(be, "launch_forms") else None,
+        "launches_by_form": forms,
     }
     if getattr(args, "static", False):
         out["roofline"]["note"] = ("S-static: most opcodes are out-of-work padding (video.py:249-251), written 64 at a time without "
@@ -710,7 +765,6 @@ def _roofline_objects(be, args, prof, op_count, seg_count, S, elapsed, live_ceil
         # 1 KiB row + 8 divergent 2-byte table loads per opcode -- with no arithmetic at all.  It is a reference pattern, not a
         # ceiling (the kernel's LDS-shared form does some of those loads from LDS and can exceed it): no `peak`, no `frac`.
         loads = float(op_count) * S * 512 / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
-        form = be.input_stats()[1] if hasattr(be, "input_stats") else "plain"   # what the encoder settled on for this input
         ref, src = _gather_ceiling_live(S, args.mode, False) if live_ceiling else (None, None)
         if ref is None:
             ref, src = ((GATHER_CEILING_GLOADS_HGR, "tools/gather_ceiling D 14336 HGR, a run on an MI355X committed as a constant, not this run")
@@ -724,38 +778,45 @@ def _roofline_objects(be, args, prof, op_count, seg_count, S, elapsed, live_ceil
                     "measured yardstick, not an upper bound",
         }
     pro_bytes = float(seg_count) * S * BYTES_PER_PROLOGUE
+    p_ach = pro_bytes / (p_ms * 1e-3) / 1e9 if p_ms > 0 else 0.0
+    # the prologue of the same counter run; checked against the instantiation this run launched (mode, diff-weight form)
+    p_kernel = "prologue_kernel<%d, %d>" % (1 if args.mode == "DHGR" else 0, {"table": 0, "recurrence": 1, "split": 2}.get(
+        "table" if getattr(args, "dw_table", False) else getattr(args, "dw", "recurrence"), 1))
+    p_entry, p_src, p_status = entry, traffic_source, status
+    if p_entry is not None and p_entry.get("prologue_kernel") != p_kernel:
+        p_entry, p_status = None, "stale"
+        p_src = "stale: profiles/pmc_latest.json profiled %s, this run launched %s" % (entry.get("prologue_kernel"), p_kernel)
+    if p_entry is None and p_status == "none" and not be.uses_wave_kernel():   # (the prologue is the same whatever the greedy kernel)
+        p_entry, p_src, p_status = _pmc_entry(args.mode, _input_kind(args), fourth, bid, None)
+        if p_entry is not None and p_entry.get("prologue_kernel") != p_kernel:
+            p_entry, p_src, p_status = None, "stale: profiles/pmc_latest.json profiled %s, this run launched %s" % (p_entry.get("prologue_kernel"), p_kernel), "stale"
+    p_traffic = p_entry["prologue_hbm_bytes_per_launch_per_stream"] * S if (p_entry and "prologue_hbm_bytes_per_launch_per_stream" in p_entry) else None
+    c_ach = (p_traffic / (p_ms / p_n * 1e-3) / 1e9) if (p_traffic and p_ms > 0) else None
     out["roofline_prologue"] = {
         "kernel": "prologue_kernel",
+        "kernel_instantiation": p_kernel,
         "bound": "hbm",
-        "achieved": pro_bytes / (p_ms * 1e-3) / 1e9 if p_ms > 0 else 0.0,
+        # this run's measurement: SURVEY 8(d)'s 147 456 algorithmic bytes per call over the launch time the events give
+        "achieved": p_ach,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
+        "frac": p_ach / HBM_PEAK_GBS,
+        "frac_is": "SURVEY 8(d) algorithmic bytes per call / this run's launch time (HIP events) / the 8 TB/s peak",
         "avg_launch_ms": p_ms / p_n,
         "launches": prof["prologue_launches"],
-    }
-    # (frac below = the counters' real HBM traffic over the peak; the SURVEY 8(d) per-call figure, which the kernel no longer
-    # moves -- 16-bit priorities, recomputed diff weights -- is kept beside it as algorithmic_frac)
-    out["roofline_prologue"]["algorithmic_frac"] = out["roofline_prologue"]["achieved"] / HBM_PEAK_GBS
-    # what the counters saw of it (committed run), and the yardstick that fits a kernel whose traffic is half reads, half
-    # writes: the box's measured copy rate (a streaming copy kernel, read + write bytes per second), not its nominal peak
-    p_traffic, p_src = _pmc_traffic(args.mode, S, _input_kind(args), getattr(args, "fourth", False),
-                                    "prologue_hbm_bytes_per_launch_per_stream", "prologue_kernel")
-    out["roofline_prologue"].update({
-        "algorithmic_bytes_per_launch": pro_bytes / p_n, "traffic": p_traffic, "traffic_source": p_src,
-        "traffic_frac": (p_traffic / (p_ms / p_n * 1e-3) / 1e9 / HBM_PEAK_GBS) if (p_traffic and p_ms > 0) else None,
+        "algorithmic_bytes_per_launch": pro_bytes / p_n,
+        # what the counters of a committed run OF THIS BUILD saw (the kernel moves fewer bytes than the SURVEY figure: 16-bit
+        # priorities, recomputed diff weights), over this run's launch time; null when that run is stale
+        "traffic": p_traffic,
+        "traffic_source": p_src,
+        "counters": p_status,
+        "counter_achieved": c_ach,
+        "counter_frac": (c_ach / HBM_PEAK_GBS) if c_ach else None,
         "peak_measured_copy": HBM_MEASURED_COPY_GBS,
-        "traffic_over_measured_copy": (p_traffic / (p_ms / p_n * 1e-3) / 1e9 / HBM_MEASURED_COPY_GBS) if (p_traffic and p_ms > 0) else None,
-    })
-    rp = out["roofline_prologue"]
-    rp["algorithmic_achieved"] = rp["achieved"]
-    if rp["traffic_frac"] is not None:
-        rp["achieved"] = rp["traffic"] / (p_ms / p_n * 1e-3) / 1e9
-        rp["frac"] = rp["traffic_frac"]
-        rp["frac_is"] = "HBM bytes per launch seen by the counters (committed run: traffic_source) / this run's launch time / the 8 TB/s peak"
-    else:
-        rp["frac"] = rp["algorithmic_frac"]
-        rp["frac_is"] = "SURVEY 8(d) algorithmic bytes per call / launch time / peak (no committed counter run for this mode / input)"
-    out["kernel_time_share"] = {"greedy": g_ms / (1000 * elapsed), "prologue": p_ms / (1000 * elapsed)}
+        "counter_traffic_over_measured_copy": (c_ach / HBM_MEASURED_COPY_GBS) if c_ach else None,
+    }
+    out["kernel_time_share"] = {"greedy": g_ms / (1000 * elapsed), "prologue": p_ms / (1000 * elapsed),
+                                "of": "the events leg (HIP events around every launch add host work the timed region does not have)"}
     return out
 
 
@@ -804,7 +865,8 @@ def _hgr_leg(be, args, local_rank, world, steps=6, warmup=1, mode="HGR", fourth=
                        "the first (video.py:146,180-186) -- NOT the reference's stream, off by default; what it buys in picture "
                        "error per frame: profiles/r03_fourth_offset.txt")
     else:
-        out.update(_roofline_objects(h, a2, leg["prof"], leg["op_count"], leg["seg_count"], S, leg["elapsed"], live_ceiling=True))
+        ev = leg["events"]
+        out.update(_roofline_objects(h, a2, leg["prof"], ev["op_count"], ev["seg_count"], S, ev["elapsed"], live_ceiling=True))
     h.batch.close()
     return out
 

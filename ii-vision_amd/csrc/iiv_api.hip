@@ -49,7 +49,12 @@ static int check_dm(int mode, const int32_t dm[256])
 
 extern "C" {
 
-const char *iiv_version(void) { return "iivision-gfx950 0.1"; }
+#ifndef IIV_BUILD_ID
+#define IIV_BUILD_ID "unknown"
+#endif
+// "iivision-gfx950 <version> build <id>": id = hash of the csrc/ sources, headers and compiler flags this library was built
+// from (csrc/Makefile: BUILD_ID) -- what a committed counter run must carry to be quoted beside a bench line of this build
+const char *iiv_version(void) { return "iivision-gfx950 0.2 build " IIV_BUILD_ID; }
 const char *iiv_last_error(void) { return iiv::g_err; }
 
 int iiv_device_count(void)

@@ -70,19 +70,32 @@ struct WaveLds {                // per stream: 5568 B
     uint32_t pdone[256];        // byte already emitted as a primary (its diff weight counts as 0)
     uint32_t mt[624 + 256];     // random's current MT19937 block + the first 256 words of the next one
 };
+struct WaveLdsBits {            // per stream, MT19937 in registers (HGR's LDS-shared form): 2048 B
+    uint32_t nz[256];
+    uint32_t pdone[256];
+};
 // What the LDS-shared form keeps in LDS per workgroup, and how many streams share it:
 //   DHGR: the L1 halves of BOTH byte offsets of the bank (2 x 16 KiB), eight streams, two workgroups per CU;
-//   HGR:  the L1 half of the EVEN byte offset only (64 KiB: both would be 128), sixteen streams, one workgroup per CU
-//         -- two of a step's eight table loads come from LDS.  HGR's step IS bound by its loads (0.97 of the ceiling of
-//         its access pattern), and that ceiling drops from 3.12 to 2.56 ms per 12288-stream launch this way
-//         (tools/gather_ceiling D 12288 HGR with IIV_GATHER_E=1).
+//   HGR:  round 6: the L1 halves of BOTH byte offsets (2 x 64 KiB), sixteen streams, one workgroup per CU: four of a
+//         step's eight table loads come from LDS.  HGR's step IS bound by its loads, and the ceiling of its access
+//         pattern drops from 3.61 (all of them through the L1 / TA) over 3.35 (one half in LDS: rounds 3-5) to 2.14 ms
+//         per 14336-stream launch this way (tools/gather_ceiling D 14336 HGR with IIV_GATHER_E=1, variant E2).  128 KiB of
+//         the CU's 160 leave 2 KiB per stream -- the two bitmaps -- so random's MT19937 block lives in eleven
+//         REGISTERS per lane there (kMtRegs below).
+//         (IIV_SHARED_HGR_HALVES=1: round 5's form, the even offset's half only and MT19937 in LDS.)
+#ifndef IIV_SHARED_HGR_HALVES
+#define IIV_SHARED_HGR_HALVES 2
+#endif
 template <int MODE> struct SharedCfg {
-    static constexpr int kOffsets = MODE == kDHGR ? 2 : 1;                                  // byte offsets whose L1 lives in LDS
+    static constexpr int kOffsets = MODE == kDHGR ? 2 : IIV_SHARED_HGR_HALVES;              // byte offsets whose L1 lives in LDS
     static constexpr int kHalfBytes = 2 << (SplitTraits<MODE>::kLeftCBits + SplitTraits<MODE>::kLeftRowBits);   // one offset's L1
     static constexpr int kL1Bytes = kOffsets * kHalfBytes;
     static constexpr int kPad = kL1Bytes;
     static constexpr int kW = MODE == kDHGR ? IIV_SHARED_W : IIV_SHARED_W_HGR;
-    static constexpr int kLds = kPad + kW * (int)sizeof(WaveLds);
+    static constexpr bool kMtRegs = MODE == kHGR && kOffsets == 2;                          // MT19937 in registers, not in LDS
+    static constexpr int kWaveBytes = kMtRegs ? (int)sizeof(WaveLdsBits) : (int)sizeof(WaveLds);
+    static constexpr int kLds = kPad + kW * kWaveBytes;
+    static_assert(kLds <= 160 * 1024, "a workgroup's LDS");
 };
 
 __device__ static inline WaveLds *own_wave_lds()
@@ -112,10 +125,15 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
     const int lane0 = W == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
     const int wave = W == 1 ? 0 : IIV_SGPR(threadIdx.x >> 6);
     // W == 1: static (constant LDS offsets); W > 1: carved from dyn_lds behind the shared table
+    // kMtRegs: random's MT19937 block in eleven registers per lane instead of LDS (HGR's LDS-shared form, SharedCfg)
+    constexpr bool kMtRegs = W > 1 && SC::kMtRegs;
     uint32_t *nz, *pdone, *mt;
     if constexpr (W == 1) {
         __shared__ uint32_t nz_s[256], pdone_s[256], mt_s[624 + 256];
         nz = nz_s, pdone = pdone_s, mt = mt_s;
+    } else if constexpr (kMtRegs) {
+        WaveLdsBits *wl = reinterpret_cast<WaveLdsBits *>(reinterpret_cast<char *>(dyn_lds) + SC::kPad) + wave;
+        nz = wl->nz, pdone = wl->pdone, mt = nullptr;
     } else {
         WaveLds *wl = reinterpret_cast<WaveLds *>(reinterpret_cast<char *>(dyn_lds) + SC::kPad) + wave;
         nz = wl->nz, pdone = wl->pdone, mt = wl->mt;
@@ -160,7 +178,8 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
         nz[i] = S.nzbits[i];
         pdone[i] = S.pdone[i];
     }
-    for (int i = lane; i < 624; i += 64) mt[i] = S.mt_py[i];
+    if constexpr (!kMtRegs)
+        for (int i = lane; i < 624; i += 64) mt[i] = S.mt_py[i];
     if (W == 1) __syncthreads(); else wave_lds_sync();
     // A step reads nonces at mt_idx + t, t <= 256 (one per candidate, then <= 2 for the
     // re-queued bytes), so it can run at most 256 words into the next block: only that much
@@ -201,21 +220,49 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
         for (int k = 0; k < 4; k++) mt[lane + 64 * k] = ahead[lane + 64 * k];
         wave_lds_sync();
     };
-    gen_ahead();
     int mt_idx = IIV_SGPR(S.mt_py_idx);
-    if (mt_idx >= 624) {
-        move_head();
-        gen_rest();
+    // ---- kMtRegs: the block in registers (iiv_stream.h: MtRegs), nothing of it in LDS.
+    // The fast path of a step does not LOOK at a nonce: it only counts draws, and the nonce of a re-queued entry is needed
+    // once its key is read back (phase B, a later launch).  So a re-queued entry waits in a register queue -- lane q of
+    // (q_key, q_idx): its key without the nonce, and which draw its nonce is, counted from the start of the block the
+    // REGISTERS hold -- and the registers do not even follow the draws: `mt_behind` counts the blocks mt_idx has moved on
+    // since (a step that uses up a block adds 624 to nothing but that counter).  mt_service catches up: it finishes the
+    // queued entries of the registers' block (one gather across the registers, coalesced stores of the keys), twists,
+    // and so on, block by block -- when the queue is nearly full (every ~25 steps on S-iid: eight or nine blocks in one
+    // go), before the exact path reads nonces, before phase B and at the end.  Draws are in order, so the queue is sorted
+    // by q_idx and what is resolved is always a prefix.  The exact path is the one place that reads nonces at once -- up
+    // to 256, straight from the registers; if they reach into the next block it takes the current block's share first
+    // and has mt_service move the registers one block AHEAD (mt_behind = -1) for the rest; that same step's draws then
+    // carry mt_idx past 624 and the count back to 0.
+    MtRegs mtr;
+    const MtLaneConsts mtk(lane);
+    uint32_t q_key = 0;
+    int q_idx = 0, n_pend = 0, mt_behind = 0;
+    constexpr int kQueueTrash = 63, kQueueHigh = 56;   // lane 63 takes the writes of bytes that are not re-queued
+    if constexpr (kMtRegs) {
+        mt_regs_load(mtr, S.mt_py, lane);
+        if (mt_idx >= 624) {
+            mt_regs_twist(mtr, mtk);
+            mt_idx -= 624;
+        }
+    } else {
         gen_ahead();
-        mt_idx -= 624;
+        if (mt_idx >= 624) {
+            move_head();
+            gen_rest();
+            gen_ahead();
+            mt_idx -= 624;
+        }
     }
     // after a block switch only words 0..255 of the current block are in place until twist_now()
     bool twist_pending = false;
     auto twist_now = [&]() {
-        if (__builtin_expect(twist_pending, 0)) {
-            gen_rest();
-            gen_ahead();
-            twist_pending = false;
+        if constexpr (!kMtRegs) {
+            if (__builtin_expect(twist_pending, 0)) {
+                gen_rest();
+                gen_ahead();
+                twist_pending = false;
+            }
         }
     };
 
@@ -339,6 +386,49 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
     uint32_t pkey_v = 0;          // lanes 1, 2 (FOUR: and 3): the keys pushed by the latest step (track only)
     int push_f1 = 0, push_f2 = 0, push_f3 = 0, push_base = 0;
     static_assert(kPushedCap >= 3 * 7680 + 8, "a generator's steps have distinct primaries: <= 7680 steps x <= 3 pushes");
+    // kMtRegs: queue entries [a, b) finished -- their nonces are words q_idx - off of the block in the registers -- and
+    // stored (entry q belongs to slot n_pushed - n_pend + q of pushed[]); returns the keys, lane q = entry q
+    auto mt_resolve = [&](int a, int b, int off) -> uint32_t {
+        const int lo = __builtin_amdgcn_readlane(q_idx, a) - off, hi = __builtin_amdgcn_readlane(q_idx, b - 1) - off;
+        const bool in = lane >= a && lane < b;
+        const uint32_t w = mt_regs_gather(mtr, in ? q_idx - off : lo, lo, hi);
+        const uint32_t key = q_key | ((mt_temper(w) >> 24) << 13);
+        const uint32_t slot = in ? (uint32_t)(n_pushed - n_pend + lane) * 4u : 0x7ffffff0u;
+        __builtin_amdgcn_raw_buffer_store_b32(key, rsrc_s, (int)slot, (int)offsetof(StreamState, pushed), 0);
+        return key;
+    };
+    // lane k's entry (keys: the winners' lanes) -> queue lane n_pend + pos (pos = the re-queued entries in front of it), or
+    // the trash lane if it is not re-queued; its nonce is draw first + pos of the current block
+    auto mt_enqueue = [&](uint32_t keys, int k, int fk, int pos, int first) {
+        const uint32_t key0 = (uint32_t)__builtin_amdgcn_readlane((int)keys, k);
+        const int at = fk ? n_pend + pos : kQueueTrash;
+        asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+            : "+v"(q_key), "+v"(q_idx)
+            : "s"(key0), "s"(first + pos), "s"(at));
+    };
+    // catch up until the registers hold block `target` relative to the one mt_idx counts in (0: that block; -1: the one
+    // after it), finishing every queued entry of the blocks passed and of the block arrived at.  Returns the keys finished
+    // LAST (lane q = entry q of the queue as it then stood: what phase B's bookkeeping reads right after a step).
+    auto mt_service = [&](int target) -> uint32_t {
+        uint32_t keys = 0;
+        for (;;) {
+            const int r = (int)__popcll(__ballot(lane < n_pend && q_idx < 624));
+            if (r > 0) {
+                keys = mt_resolve(0, r, 0);
+                if (r < n_pend) {   // the entries left over move down to lane 0
+                    const int from = ((lane + r) & 63) << 2;
+                    q_key = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)q_key);
+                    q_idx = __builtin_amdgcn_ds_bpermute(from, q_idx);
+                }
+                n_pend -= r;
+            }
+            if (mt_behind <= target) break;
+            mt_regs_twist(mtr, mtk);
+            mt_behind--;
+            q_idx -= 624;
+        }
+        return keys;
+    };
     auto apply = [&](auto track, uint32_t e, uint32_t W1, uint32_t W2, uint32_t W3, int C) {
         const int p = (e >> 8) & 31, x = e & 255;
         const uint32_t c = (e >> 16) & 0xffu;
@@ -374,6 +464,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
         if (FOUR) asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(ob3) : "s"(W3), "s"(ob_n));
         int ln = lane;
         asm volatile("" : "+v"(ln));   // (keeps `lane < 3` from becoming one more hoisted, spilled mask)
+        uint32_t pk0_v = 0;            // kMtRegs: lanes 1..3, the re-queued entry's key without its nonce
         if (ln < (FOUR ? 4 : 3)) {
             const uint32_t off = w_v & 255u, val = w_v >> 8;
             // (buffer stores into this stream's state: field offsets in scalar registers instead of 64-bit pointers added per lane)
@@ -386,26 +477,56 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
             atomicOr(&pdone[p * 8 + (x >> 5)], 1u << (x & 31));   // (the primary's diff weight counts as 0 from here on; from all lanes: idempotent)
             // the re-queued entry (video.py:178), its nonce the next word behind the candidates'; a byte that is not
             // re-queued aims beyond the buffer
-            const uint32_t nonce = mt_temper(mt[mt_idx + C + (int)k_v]) >> 24;
-            const uint32_t pkey = ((2047u - val) << 21) | (nonce << 13) | loc;
-            const uint32_t slot = val != 0u ? (uint32_t)(n_pushed + (int)k_v) * 4u : 0x7ffffff0u;
-            __builtin_amdgcn_raw_buffer_store_b32(pkey, rsrc_s, (int)slot, (int)offsetof(StreamState, pushed), 0);
-            if (decltype(track)::value) pkey_v = pkey;
+            if constexpr (!kMtRegs) {
+                const uint32_t nonce = mt_temper(mt[mt_idx + C + (int)k_v]) >> 24;
+                const uint32_t pkey = ((2047u - val) << 21) | (nonce << 13) | loc;
+                const uint32_t slot = val != 0u ? (uint32_t)(n_pushed + (int)k_v) * 4u : 0x7ffffff0u;
+                __builtin_amdgcn_raw_buffer_store_b32(pkey, rsrc_s, (int)slot, (int)offsetof(StreamState, pushed), 0);
+                if (decltype(track)::value) pkey_v = pkey;
+            } else {
+                pk0_v = ((2047u - val) << 21) | loc;   // the nonce later: the entry goes into the register queue below
+            }
+        }
+        if constexpr (kMtRegs) {
+            const int first = mt_behind * 624 + mt_idx + C;   // (counted from the block in the registers)
+            mt_enqueue(pk0_v, 1, f1, 0, first);
+            mt_enqueue(pk0_v, 2, f2, f1, first);
+            if (FOUR) mt_enqueue(pk0_v, 3, f3, f1 + f2, first);
+            n_pend += f1 + f2 + f3;
         }
         if (decltype(track)::value) push_f1 = f1, push_f2 = f2, push_f3 = f3, push_base = n_pushed;
         mt_idx += C + f1 + f2 + f3;
         draws += (uint32_t)(C + f1 + f2 + f3);
         n_pushed += f1 + f2 + f3;
+        if constexpr (kMtRegs) {
+            if (decltype(track)::value) {
+                // phase B wants the finished keys now (lane q = this step's q-th push; its queue holds nothing else): the
+                // current block's, and if the draws reached beyond it, one block on for the others
+                pkey_v = mt_service(0);
+                if (n_pend > 0) {
+                    const int r = (FOUR ? f1 + f2 + f3 : f1 + f2) - n_pend;   // finished in the first round
+                    const uint32_t k2 = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane - r) & 63) << 2, (int)mt_service(-1));
+                    pkey_v = lane < r ? pkey_v : k2;
+                }
+            } else if (__builtin_expect(n_pend > kQueueHigh, 0)) {
+                (void)mt_service(0);
+            }
+        }
         done++;
         ob_n++;
         if (__builtin_expect(ob_n == 64, 0)) flush_ops();
         if (__builtin_expect(mt_idx >= 624, 0)) {
-            // the next block becomes the current one: its head moves down now, the rest of it
-            // and the new head are generated later, while table loads are in flight
-            // (twist_now), at the latest before a step reads past word 255
-            move_head();
-            mt_idx -= 624;
-            twist_pending = true;
+            if constexpr (kMtRegs) {
+                mt_idx -= 624;   // (the registers follow when somebody needs them: mt_service)
+                mt_behind++;
+            } else {
+                // the next block becomes the current one: its head moves down now, the rest of it
+                // and the new head are generated later, while table loads are in flight
+                // (twist_now), at the latest before a step reads past word 255
+                move_head();
+                mt_idx -= 624;
+                twist_pending = true;
+            }
         }
     };
 
@@ -527,10 +648,40 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
             int run = mt_idx;
 #pragma unroll
             for (int q = 0; q < 4; q++) run += prefix_popc(cand[q]);
+            uint32_t word[4];
+            if constexpr (kMtRegs) {
+                // the candidates' draws mt_idx .. mt_idx + C - 1 out of the registers: the current block's share, then -- if they
+                // reach beyond it -- the queue resolved, the next block made, and its share
+                int at[4];
+                bool mine[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    at[r] = run;
+                    mine[r] = (cand[r] >> lane) & 1ull;
+                    run += mine[r] ? 1 : 0;
+                }
+                const int last = mt_idx + (C > 0 ? C - 1 : 0), last0 = last < 623 ? last : 623;
+                if (mt_behind != 0) (void)mt_service(0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) word[r] = mt_regs_gather(mtr, mine[r] && at[r] < 624 ? at[r] : mt_idx, mt_idx, last0);
+                if (__builtin_expect(last >= 624, 0)) {
+                    (void)mt_service(-1);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const uint32_t w2 = mt_regs_gather(mtr, mine[r] && at[r] >= 624 ? at[r] - 624 : 0, 0, last - 624);
+                        word[r] = at[r] >= 624 ? w2 : word[r];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    word[r] = mt[run];
+                    run += (int)((cand[r] >> lane) & 1ull);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const uint32_t nonce = mt_temper(mt[run]) >> 24;
-                run += (int)((cand[r] >> lane) & 1ull);
+                const uint32_t nonce = mt_temper(word[r]) >> 24;
                 key[r] = (int)(((uint32_t)(ke[r] >> 4) & 0xffff0000u) | (nonce << 8) | (y0 + r));   // video.py:159
             }
             // the two smallest (delta, nonce, offset): in the lane, then the one-pass fused-DPP top-2 of the fast path
@@ -717,6 +868,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
     // converges -- a static background -- every opcode comes from here, and the bag holds two entries per
     // opcode emitted so far.)
     if (done < n_ops && !err && !exhausted) {
+        if constexpr (kMtRegs) (void)mt_service(0);   // (every queued key into pushed[]: it is read back from here on)
         uint32_t ck = INF, ci = 0;
         for (int i = lane; i < n_pushed; i += 64) {
             const uint32_t k = S.pushed[i];
@@ -787,9 +939,10 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
             const uint32_t ni = (uint32_t)__builtin_amdgcn_readlane((int)mi, (int)__builtin_ctzll(__ballot(mk == nk)));
             writelane(ck, nk, wl);
             writelane(ci, ni, wl);
-            if (push_f1) cache_merge((uint32_t)__builtin_amdgcn_readlane((int)pkey_v, 1), (uint32_t)push_base);
-            if (push_f2) cache_merge((uint32_t)__builtin_amdgcn_readlane((int)pkey_v, 2), (uint32_t)(push_base + push_f1));
-            if (FOUR && push_f3) cache_merge((uint32_t)__builtin_amdgcn_readlane((int)pkey_v, 3), (uint32_t)(push_base + push_f1 + push_f2));
+            // (pkey_v: the pushed keys in lanes 1, 2, 3 by winner -- kMtRegs: in lanes 0, 1, 2 by push)
+            if (push_f1) cache_merge((uint32_t)__builtin_amdgcn_readlane((int)pkey_v, kMtRegs ? 0 : 1), (uint32_t)push_base);
+            if (push_f2) cache_merge((uint32_t)__builtin_amdgcn_readlane((int)pkey_v, kMtRegs ? push_f1 : 2), (uint32_t)(push_base + push_f1));
+            if (FOUR && push_f3) cache_merge((uint32_t)__builtin_amdgcn_readlane((int)pkey_v, kMtRegs ? push_f1 + push_f2 : 3), (uint32_t)(push_base + push_f1 + push_f2));
         }
     }
 
@@ -803,12 +956,15 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
         done = n_ops;
     }
     twist_now();
+    if constexpr (kMtRegs) (void)mt_service(0);   // (the registers at the block mt_idx counts in, every queued key stored)
     if (W == 1) __syncthreads(); else wave_lds_sync();
     for (int i = lane; i < 256; i += 64) {
         S.nzbits[i] = nz[i];
         S.pdone[i] = pdone[i];
     }
-    for (int i = lane; i < 624; i += 64) S.mt_py[i] = mt[i];
+    if constexpr (kMtRegs) mt_regs_store(mtr, S.mt_py, lane);
+    else
+        for (int i = lane; i < 624; i += 64) S.mt_py[i] = mt[i];
     if (lane == 0) {
         S.mt_py_idx = mt_idx;
         S.head = head;

@@ -312,7 +312,46 @@ __device__ static inline void mt_twist_wave(const uint32_t *__restrict__ src, ui
 // read at all (its words are still written out for the nonce lookups, but nothing waits for those writes); the form that
 // re-read every block from LDS took one wave ~1.1 k cycles per block beside fifteen waves whose gathers queue in front
 // of its reads -- 14 k cycles for the thirteen blocks of a prologue call, more than the other waves need to score.
-__device__ static inline void mt_generate_wave(const uint32_t *__restrict__ blk0, uint32_t *__restrict__ gen, int n_blocks, int lane)
+// (the block update itself: mt_regs_twist below -- one wave, the block in its registers)
+struct MtRegs {
+    uint32_t A[4], B[4], C[3];   // lane l: words l + 64 g (A), 227 + l + 64 g (B), 454 + l + 64 g (C)
+};
+// the lane constants of the update: the two rotations' bpermute addresses and where their results apply
+struct MtLaneConsts {
+    int addr7, addr42;
+    bool lt22, lt57;
+    __device__ explicit MtLaneConsts(int lane) : addr7(((lane + 7) & 63) << 2), addr42(((lane + 42) & 63) << 2), lt22(lane < 22), lt57(lane < 57) {}
+};
+__device__ static inline void mt_regs_load(MtRegs &m, const uint32_t *__restrict__ blk, int lane)
+{
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const int j = lane + 64 * g;
+        m.A[g] = m.B[g] = 0;
+        if (g < 3 || j < 227) {
+            m.A[g] = blk[j];
+            m.B[g] = blk[227 + j];
+        }
+        if (g < 3) {
+            m.C[g] = 0;
+            if (g < 2 || j < 170) m.C[g] = blk[454 + j];
+        }
+    }
+}
+__device__ static inline void mt_regs_store(const MtRegs &m, uint32_t *__restrict__ dst, int lane)
+{
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const int j = lane + 64 * g;
+        if (g < 3 || j < 227) {
+            dst[j] = m.A[g];
+            dst[227 + j] = m.B[g];
+        }
+        if (g < 2 || (g == 2 && j < 170)) dst[454 + j] = m.C[g];
+    }
+}
+// the next block, in place
+__device__ __forceinline__ void mt_regs_twist(MtRegs &m, const MtLaneConsts &k)
 {
     auto mix = [](uint32_t x, uint32_t y) -> uint32_t {   // iiv_device.h: mt_mix
         const uint32_t v = (x & 0x80000000u) | (y & 0x7fffffffu);
@@ -326,57 +365,70 @@ __device__ static inline void mt_generate_wave(const uint32_t *__restrict__ blk0
     };
     auto lane0 = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, 0); };
     auto rot = [](uint32_t v, int addr) -> uint32_t { return (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v); };
-    uint32_t A[4], B[4], C[3];
+    uint32_t(&A)[4] = m.A, (&B)[4] = m.B, (&C)[3] = m.C;
+    // old[j + 397]: chain j + 170 of B (j < 57), chain j - 57 of C (beyond)
+    const uint32_t rb2 = rot(B[2], k.addr42), rb3 = rot(B[3], k.addr42);
+    const uint32_t rc0 = rot(C[0], k.addr7), rc1 = rot(C[1], k.addr7), rc2 = rot(C[2], k.addr7);
+    uint32_t X[4];
+    X[0] = k.lt22 ? rb2 : k.lt57 ? rb3 : rc0;
+    X[1] = k.lt57 ? rc0 : rc1;
+    X[2] = k.lt57 ? rc1 : rc2;
+    X[3] = rc2;
+    uint32_t nA[4], nB[4], nC[3];
+    // first third: new[j] = old[j + 397] ^ mix(old[j], old[j + 1]); old[227] is B's chain 0
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+        nA[g] = X[g] ^ mix(A[g], g < 3 ? up1(A[g], lane0(A[g < 3 ? g + 1 : 0]), std::integral_constant<int, 63>{}) : up1(A[g], lane0(B[0]), std::integral_constant<int, 34>{}));
+    // second third: new[227 + j] = new[j] ^ mix(old[227 + j], old[228 + j]); old[454] is C's chain 0
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+        nB[g] = nA[g] ^ mix(B[g], g < 3 ? up1(B[g], lane0(B[g < 3 ? g + 1 : 0]), std::integral_constant<int, 63>{}) : up1(B[g], lane0(C[0]), std::integral_constant<int, 34>{}));
+    // third third: new[454 + j] = new[227 + j] ^ mix(old[454 + j], old[455 + j]); "old[624]" is the new word 0
+#pragma unroll
+    for (int g = 0; g < 3; g++)
+        nC[g] = nB[g] ^ mix(C[g], g < 2 ? up1(C[g], lane0(C[g < 2 ? g + 1 : 0]), std::integral_constant<int, 63>{}) : up1(C[g], lane0(nA[0]), std::integral_constant<int, 41>{}));
 #pragma unroll
     for (int g = 0; g < 4; g++) {
-        const int j = lane + 64 * g;
-        A[g] = B[g] = 0;
-        if (g < 3 || j < 227) {
-            A[g] = blk0[j];
-            B[g] = blk0[227 + j];
-        }
-        if (g < 3) {
-            C[g] = 0;
-            if (g < 2 || j < 170) C[g] = blk0[454 + j];
+        A[g] = nA[g];
+        B[g] = nB[g];
+        if (g < 3) C[g] = nC[g];
+    }
+}
+// word idx[lane] (0 .. 623) of the block, per lane: a gather across the wave's registers -- word i sits in register
+// code(i) = 4 t + (j >> 6), t = its third, j = i - 227 t, lane j & 63 -- by one ds_bpermute (the LDS crossbar, no LDS
+// memory) and one select per register; registers outside [code(lo), code(hi)] (lo <= hi: scalar bounds of the indices
+// that matter) are skipped.  A lane whose index does not matter may pass anything in 0 .. 623.
+__device__ static inline uint32_t mt_regs_gather(const MtRegs &m, int idx, int lo, int hi)
+{
+    auto code_of = [](int i, int &j) -> int {
+        const int t = (i >= 227 ? 1 : 0) + (i >= 454 ? 1 : 0);
+        j = i - 227 * t;
+        return 4 * t + (j >> 6);
+    };
+    int j, jl, jh;
+    const int code = code_of(idx, j);
+    const int c_lo = code_of(lo, jl), c_hi = code_of(hi, jh);
+    const int addr = (j & 63) << 2;
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+        if (k >= c_lo && k <= c_hi) {   // (scalar branch)
+            const uint32_t src = k < 4 ? m.A[k] : k < 8 ? m.B[k - 4] : m.C[k - 8];
+            const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)src);
+            r = code == k ? v : r;
         }
     }
-    const int addr7 = ((lane + 7) & 63) << 2, addr42 = ((lane + 42) & 63) << 2;
-    const bool lt22 = lane < 22, lt57 = lane < 57;
+    return r;
+}
+
+__device__ static inline void mt_generate_wave(const uint32_t *__restrict__ blk0, uint32_t *__restrict__ gen, int n_blocks, int lane)
+{
+    MtRegs m;
+    mt_regs_load(m, blk0, lane);
+    const MtLaneConsts kc(lane);
     for (int k = 0; k < n_blocks; k++) {
-        uint32_t *dst = gen + k * 624;
-        // old[j + 397]: chain j + 170 of B (j < 57), chain j - 57 of C (beyond)
-        const uint32_t rb2 = rot(B[2], addr42), rb3 = rot(B[3], addr42);
-        const uint32_t rc0 = rot(C[0], addr7), rc1 = rot(C[1], addr7), rc2 = rot(C[2], addr7);
-        uint32_t X[4];
-        X[0] = lt22 ? rb2 : lt57 ? rb3 : rc0;
-        X[1] = lt57 ? rc0 : rc1;
-        X[2] = lt57 ? rc1 : rc2;
-        X[3] = rc2;
-        uint32_t nA[4], nB[4], nC[3];
-        // first third: new[j] = old[j + 397] ^ mix(old[j], old[j + 1]); old[227] is B's chain 0
-#pragma unroll
-        for (int g = 0; g < 4; g++)
-            nA[g] = X[g] ^ mix(A[g], g < 3 ? up1(A[g], lane0(A[g < 3 ? g + 1 : 0]), std::integral_constant<int, 63>{}) : up1(A[g], lane0(B[0]), std::integral_constant<int, 34>{}));
-        // second third: new[227 + j] = new[j] ^ mix(old[227 + j], old[228 + j]); old[454] is C's chain 0
-#pragma unroll
-        for (int g = 0; g < 4; g++)
-            nB[g] = nA[g] ^ mix(B[g], g < 3 ? up1(B[g], lane0(B[g < 3 ? g + 1 : 0]), std::integral_constant<int, 63>{}) : up1(B[g], lane0(C[0]), std::integral_constant<int, 34>{}));
-        // third third: new[454 + j] = new[227 + j] ^ mix(old[454 + j], old[455 + j]); "old[624]" is the new word 0
-#pragma unroll
-        for (int g = 0; g < 3; g++)
-            nC[g] = nB[g] ^ mix(C[g], g < 2 ? up1(C[g], lane0(C[g < 2 ? g + 1 : 0]), std::integral_constant<int, 63>{}) : up1(C[g], lane0(nA[0]), std::integral_constant<int, 41>{}));
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const int j = lane + 64 * g;
-            if (g < 3 || j < 227) {
-                dst[j] = nA[g];
-                dst[227 + j] = nB[g];
-            }
-            if (g < 2 || (g == 2 && j < 170)) dst[454 + j] = nC[g];
-            A[g] = nA[g];
-            B[g] = nB[g];
-            if (g < 3) C[g] = nC[g];
-        }
+        mt_regs_twist(m, kc);
+        mt_regs_store(m, gen + k * 624, lane);
     }
     wave_lds_sync();
 }

@@ -164,6 +164,12 @@ def lib():
     return L
 
 
+def build_id():
+    """The library's build id (include/iivision.h: iiv_version): a hash of the sources and flags it was built from."""
+    v = lib().iiv_version().decode("ascii", "replace")
+    return v.split(" build ", 1)[1] if " build " in v else "unknown"
+
+
 def check(rc):
     if rc == OK:
         return

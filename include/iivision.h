@@ -35,6 +35,9 @@ extern "C" {
 #define IIV_HGR 0
 #define IIV_DHGR 1
 
+/* "iivision-gfx950 <version> build <id>"; <id> = a hash of the sources and flags the library was built from
+ * (csrc/Makefile: BUILD_ID).  bench.py prints it and quotes committed counter runs (profiles/pmc_latest.json) only when they
+ * carry the same id. */
 const char *iiv_version(void);
 const char *iiv_last_error(void);
 int iiv_device_count(void);

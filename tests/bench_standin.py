@@ -65,3 +65,13 @@ class CpuStandIn:
 
     def uses_wave_kernel(self):
         return True
+
+    # what bench.py checks a committed counter run against (tests/test_bench_counters.py)
+    def build_id(self):
+        return os.environ.get("IIV_STANDIN_BUILD_ID", "standin00000")
+
+    def launch_forms(self):
+        return {"plain": 0, "shared": 7, "team": 0, "workgroup": 0}
+
+    def input_stats(self):
+        return 0.02, "shared"

@@ -91,9 +91,9 @@ def test_bench_main_runs_in_two_ranks():
     assert cfg0["streams_per_gpu"] < 12288
     assert v0 == v1 and v0 > 0
     assert cfg0["palette"] == "IIGS" and "IIGS" in cfg0["workload"] and "2 GPU" in cfg0["parallelism"]
-    # disjoint seeds and clips per rank; warm-up + timed steps ran; state was checked on both sides
+    # disjoint seeds and clips per rank; warm-up + events leg + timed steps ran; state was checked on both sides
     assert log0["seeds"][0] != log1["seeds"][0] and log0["clips"][2] != log1["clips"][2]
-    assert log0["steps"] == log1["steps"] == 4 and log0["checks"] == 2 and log0["sync"] >= 2
+    assert log0["steps"] == log1["steps"] == 1 + 3 + 3 and log0["checks"] == 3 and log0["sync"] >= 4
     # exactly one JSON line, from rank 0, with the contract's keys
     assert line1 == ""
     d = json.loads(line0)

@@ -193,6 +193,43 @@ __global__ __launch_bounds__(64 * W) void pattern_shared_l1_hgr_kernel(const uin
     sink[stream * 64 + lane] = acc;
 }
 
+// Variant E2 for HGR (round 6): the L1 tables of BOTH byte offsets (128 KiB) shared in LDS by sixteen one-wave streams (one
+// workgroup per CU, 2 KiB of LDS left per stream: the two bitmaps, MT19937 in registers): four of the eight gathers are ds_read_u16.
+template <int W>
+__global__ __launch_bounds__(64 * W) void pattern_shared_l1x2_hgr_kernel(const uint16_t *__restrict__ left, const uint16_t *__restrict__ right,
+                                                                         const uint16_t *__restrict__ dense, const uint4 *__restrict__ rows,
+                                                                         int n_ops, int n_streams, uint32_t *__restrict__ sink)
+{
+    extern __shared__ uint32_t lds[];   // [0, 32768): L1 of offsets 0 and 1
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        const uint4 *src0 = reinterpret_cast<const uint4 *>(left);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds);
+        for (int i = threadIdx.x; i < 8192; i += 64 * W) dst[i] = src0[i];
+    }
+    __syncthreads();
+    const int stream = blockIdx.x * W + wave;
+    if (stream >= n_streams) return;
+    const uint16_t *l16 = reinterpret_cast<const uint16_t *>(lds);
+    const uint4 *my = rows + (size_t)stream * n_ops * 64 + lane;
+    uint32_t acc = 0, h = stream * 2654435761u + 977u;
+    uint4 next = my[0];
+    for (int op = 0; op < n_ops; op++) {
+        const uint4 row = next;
+        if (op + 1 < n_ops) next = my[(size_t)(op + 1) * 64];
+        h = h * 1664525u + 1013904223u;
+        const uint32_t c = (h >> 16) & 255u;
+        const uint32_t cl = c & 63u, cr = c >> 2;
+        const uint16_t *le = l16 + (cl << 9), *lo = l16 + (((1u << 6) | cl) << 9);
+        const uint16_t *re = right + (cr << 9), *ro = right + (((1u << 6) | cr) << 9);
+        uint32_t b0 = re[(row.x >> 9) & 0x1ffu], b1 = ro[(row.y >> 9) & 0x1ffu], b2 = re[(row.z >> 9) & 0x1ffu], b3 = ro[(row.w >> 9) & 0x1ffu];
+        uint32_t a1 = lo[row.y & 511u], a3 = lo[row.w & 511u];
+        uint32_t a0 = le[row.x & 511u], a2 = le[row.z & 511u];
+        acc += (a0 + b0) ^ (a1 + b1) ^ (a2 + b2) ^ (a3 + b3);
+    }
+    sink[stream * 64 + lane] = acc;
+}
+
 // Variant G: the store value as a sum of FOUR pixel-group terms (DESIGN 3.10 applied to the store table: groups of 2 / 3 / 3 / 2
 // pixels depend on 5 / 7 / 7 / 6 target dots and 2 / 5 / 6 / 3 content bits -- 128 + 4096 + 8192 + 512 entries per offset
 // class, 25.3 KiB, both classes of a bank 50.5 KiB), all of it in LDS, shared by the W one-wave streams of one workgroup
@@ -377,6 +414,22 @@ static int run_d_only(int waves, bool hgr)
             float ms2;
             (void)hipEventElapsedTime(&ms2, a, b);
             printf("# E-HGR W=%d (one offset's L1 in LDS, 1 workgroup per CU): %.4f ms per launch  err=%d\n", w, ms2 / reps, (int)hipGetLastError());
+        }
+        {
+            (void)hipFuncSetAttribute((const void *)pattern_shared_l1x2_hgr_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            auto le2 = [&] {
+                hipLaunchKernelGGL(pattern_shared_l1x2_hgr_kernel<16>, dim3((waves + 15) / 16), dim3(1024), 131072 + 16 * 2048, 0, (const uint16_t *)left,
+                                   (const uint16_t *)right, dense, rows, n_ops, waves, sink);
+            };
+            le2();
+            (void)hipDeviceSynchronize();
+            (void)hipEventRecord(a);
+            for (int r = 0; r < reps; r++) le2();
+            (void)hipEventRecord(b);
+            (void)hipEventSynchronize(b);
+            float ms3;
+            (void)hipEventElapsedTime(&ms3, a, b);
+            printf("# E2-HGR W=16 (both offsets' L1 in LDS, 160 KiB, 1 workgroup per CU): %.4f ms per launch  err=%d\n", ms3 / reps, (int)hipGetLastError());
         }
         printf("D %d %.4f %.1f\n", waves, ms, (double)waves * n_ops * 512 / ms * 1e-6);
         return 0;

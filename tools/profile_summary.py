@@ -26,6 +26,22 @@ PASSES = [
 ]
 
 
+# tools/issue_probe.hip on an MI355X (profiles/r06_issue_probe.txt): shader clocks of one SIMD per wave64 instruction at
+# w resident waves per SIMD -- the greedy step's 161 : 118 vector : scalar mix interleaved, and general vector instructions
+# alone (v_mad / v_min / DPP / v_readlane / v_cndmask ...; v_add_u32 alone issues faster)
+PROBE_MIX_CLK = {1: 4.71, 2: 2.94, 3: 1.96, 4: 1.99, 6: 1.65, 7: 1.41, 8: 1.49}
+PROBE_VALU_CLK = {1: 4.14, 2: 4.08, 3: 2.72, 4: 3.04, 6: 2.69, 7: 2.31, 8: 2.52}
+
+
+def build_id():
+    sys.path.insert(0, os.path.join(ROOT, "ii-vision_amd", "transcoder"))
+    try:
+        import _iiv_native
+        return _iiv_native.build_id()
+    except Exception:
+        return "unknown"
+
+
 def run(cmd, cwd):
     subprocess.run(cmd, cwd=cwd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
 
@@ -111,10 +127,11 @@ def main():
         return agg[k][c] / max(len(cnt[k][c]), 1) if c in agg[k] else None
 
     def issue_of(k):
-        """What the SQ counters say binds the kernel: instructions per opcode and wave, instructions per
-        clock and SIMD, how busy the vector pipe is, waves resident per SIMD.  One wave per stream; 256 CUs x 4 SIMDs; a wave64
-        vector instruction occupies its SIMD for 4 clocks as measured on this chip (2 by MI355X_MICROARCH.md's constants table: both
-        figures are written); shader clock 2.4 GHz."""
+        """What the SQ counters say binds the kernel: instructions per opcode and wave,
+        instructions per clock and SIMD, and the ISSUE FLOOR of that instruction stream at its residency, from the
+        register-only probe tools/issue_probe.hip (profiles/r06_issue_probe.txt): clocks of one SIMD per wave64
+        instruction at w resident waves per SIMD -- the step's own vector : scalar mix, and vector instructions alone.
+        One wave per stream; 256 CUs x 4 SIMDs; shader clock 2.4 GHz (the probe read 2.35-2.40 GHz under load)."""
         valu, salu = per_dispatch(k, "SQ_INSTS_VALU"), per_dispatch(k, "SQ_INSTS_SALU")
         if valu is None or salu is None or not streams or not ops_per_launch or k not in avg_ns:
             return None
@@ -124,24 +141,36 @@ def main():
         import re
         w = int(re.search(r"<\s*\d\s*,\s*(\d+)", k).group(1)) if re.search(r"<\s*\d\s*,\s*(\d+)", k) else 1
         waves = per_dispatch(k, "SQ_WAVES")
+        # persistent workgroups (W > 1): every launched wave is resident; the plain form (W = 1) launches one wave per stream, 28 resident per CU
+        wps = (waves / 1024.0) if (w > 1 and waves) else 7.0
+        wkey = min(PROBE_MIX_CLK, key=lambda x: abs(x - wps))
+        mix_clk, valu_clk = PROBE_MIX_CLK[wkey], PROBE_VALU_CLK[wkey]
+        step_clocks = clocks * 1024.0 / steps                      # clocks of one SIMD per step it retires
+        floor_clocks = (valu + salu) / steps * mix_clk            # what issuing the step's vector + scalar instructions takes it
         return {
-            "source": "tools/profile_summary.py: rocprofv3 --pmc SQ_* passes + --kernel-trace --stats of the same command",
+            "source": "tools/profile_summary.py: rocprofv3 --pmc SQ_* passes + --kernel-trace --stats of the same command; issue rates: "
+                      "profiles/r06_issue_probe.txt (tools/issue_probe.hip, register-only loops)",
             "kernel": k, "launch_ms_under_rocprof": avg_ns[k] * 1e-6, "opcodes_per_stream_and_launch": ops_per_launch,
             "valu_per_opcode_wave": valu / steps, "salu_per_opcode_wave": salu / steps, "other_per_opcode_wave": other / steps,
             "instr_per_clk_per_simd": (valu + salu + other) / (clocks * 1024.0),
-            # the vector pipe's share at the issue rate MEASURED on this chip -- one wave64 VALU instruction per 4.0 clocks and SIMD
-            # on pure vector work (profiles/r05_ingest_probe.txt: the ordered-dither ingest kernel, 641 VALU x 60 waves per frame at
-            # 16.0 M frames/s) -- beside the guide's 2-clock figure
-            "valu_busy_frac": valu * 4.0 / (clocks * 1024.0),
-            "valu_busy_frac_at_2clk_per_instr": valu * 2.0 / (clocks * 1024.0),
-            "valu_clocks_per_instr_measured": 4.0,
             "waves_per_dispatch": waves,
-            # persistent workgroups (W > 1): every launched wave is resident; the plain form (W = 1) launches one wave per stream, 28 resident per CU
-            "waves_per_simd": (waves / 1024.0) if (w > 1 and waves) else 7.0,
+            "waves_per_simd": wps,
+            "probe_waves_per_simd_used": wkey,
+            "probe_clocks_per_instr_step_mix": mix_clk,
+            "probe_clocks_per_instr_valu": valu_clk,
+            # the vector pipe's share of the launch at the probed rate for this residency (one figure: the probe settles it)
+            "valu_busy_frac": valu * valu_clk / (clocks * 1024.0),
+            "clocks_per_step_and_simd": step_clocks,
+            "issue_floor_clocks_per_step_and_simd": floor_clocks,
+            "issue_floor_frac": floor_clocks / step_clocks,
+            "reading": "issue_floor_frac of the launch is the SIMDs issuing the step's vector and scalar instructions at the rate a "
+                       "register-only loop of the same mix sustains at this residency; the rest is dependent latency (DPP / SGPR "
+                       "round trips, LDS and table-word waits) that the resident waves do not cover",
             "wait_any_frac_of_wave_cycles": (per_dispatch(k, "SQ_WAIT_ANY") / per_dispatch(k, "SQ_WAVE_CYCLES")) if per_dispatch(k, "SQ_WAVE_CYCLES") and per_dispatch(k, "SQ_WAIT_ANY") is not None else None,
             "clock_hz_assumed": 2.4e9,
         }
     latest_path = os.path.join(out, "pmc_latest.json")
+    bid = build_id()
     try:
         latest = json.load(open(latest_path))
         if not any(k.split(":")[0] in ("DHGR", "HGR") for k in latest):
@@ -156,10 +185,11 @@ def main():
         a = agg[main_k]
         fetch = a["FETCH_SIZE"] / max(len(cnt[main_k]["FETCH_SIZE"]), 1)
         write = a["WRITE_SIZE"] / max(len(cnt[main_k]["WRITE_SIZE"]), 1)
-        # the key names mode and synthetic input: "DHGR" / "HGR" are S-iid, "DHGR:img" is S-img (bench._pmc_traffic)
+        # the key names mode and synthetic input: "DHGR" / "HGR" are S-iid, "DHGR:img" is S-img (bench._pmc_entry)
         kind = "img" if "--img" in bench_args else "coherent" if "--coherent" in bench_args else "static" if "--static" in bench_args else "iid"
         latest[mode if kind == "iid" else "%s:%s" % (mode, kind)] = {
             "source": "tools/profile_summary.py (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+            "build_id": bid,   # iiv_version() of the library the counters were taken with: bench.py quotes them for this build only
             "kernel": main_k,
             "kernel_note": "template arguments: <mode (1 = DHGR), streams per workgroup (1 = plain form, 8 / 16 = LDS-shared form), fourth offset>; "
                            "the instantiation with the most dispatches in the profiled run",
