@@ -107,6 +107,9 @@ def parse_args(argv=None):
     ap.add_argument("--mode", choices=["DHGR", "HGR"], default="DHGR")
     ap.add_argument("--palette", choices=sorted(PALETTE_IDS), default="NTSC",
                     help="NTSC (main.py's default) or IIGS = the //gs RGB palette of BASELINE config 5")
+    ap.add_argument("--config", type=int, choices=[3, 4, 5], default=0,
+                    help="preset named after BASELINE.json's configs: 3 = HGR NTSC 280x192, 4 = DHGR NTSC 560x192 (the default "
+                         "workload), 5 = DHGR with the //gs RGB palette, the 8-GPU configuration (same as --palette IIGS); sets --mode / --palette")
     ap.add_argument("--coherent", action="store_true", help="S-coh input instead of S-iid")
     ap.add_argument("--img", action="store_true", help="S-img input (dithered moving bars) instead of S-iid")
     ap.add_argument("--img-distinct", type=int, default=0, help="with --img: render this many distinct clips and tile them over the streams (0 = all distinct)")
@@ -150,7 +153,14 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default=os.environ.get("IIV_BENCH_BACKEND", ""),
                     help="tests only: 'module:Class' standing in for GpuBackend (tests/bench_standin.py runs main() "
                          "without a device; the product path has no CPU fallback)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.config == 3:
+        args.mode, args.palette = "HGR", "NTSC"
+    elif args.config == 4:
+        args.mode, args.palette = "DHGR", "NTSC"
+    elif args.config == 5:
+        args.mode, args.palette = "DHGR", "IIGS"
+    return args
 
 
 def _resolve_backend(spec):
@@ -189,6 +199,62 @@ def visible_gpus():
         except Exception:
             return None
     return n
+
+
+def _cpulist(text):
+    """'0-3,8,10-11' -> {0, 1, 2, 3, 8, 10, 11}"""
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def pin_to_gpu_numa_node(local_rank):
+    """Before any GPU call: pin this rank to the CPUs of its GPU's NUMA node (one process per GPU drives ~270 launches per
+    step from one host thread; on an 8-GPU node the GPUs hang off different sockets, and a rank scheduled on the far one pays
+    the hop on every launch and every pinned-memory copy).  GPU `local_rank` = the local_rank-th GPU node of the KFD
+    topology (through HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES if they are lists of indices); its NUMA node is
+    /sys/class/drm/renderD<drm_render_minor>/device/numa_node; the CPUs are that node's cpulist cut with what this process may
+    run on.  Returns what it did -- {"numa_node", "cpus", "n_cpus", "pinned"} -- and never fails the run: anything it
+    cannot read leaves the affinity alone and says why.  (IIV_BENCH_SYSFS: another root for /sys, tests only.)"""
+    import glob
+    root = os.environ.get("IIV_BENCH_SYSFS", "/sys")
+    info = {"numa_node": None, "cpus": None, "n_cpus": None, "pinned": False}
+    try:
+        gpus = []
+        for f in sorted(glob.glob(root + "/class/kfd/kfd/topology/nodes/*/properties"), key=lambda p: int(p.split("/")[-2])):
+            props = dict(l.split()[:2] for l in open(f) if len(l.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                gpus.append(int(props.get("drm_render_minor", "-1")))
+        idx = local_rank
+        for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+            v = os.environ.get(var)
+            if v:
+                ids = [x.strip() for x in v.split(",") if x.strip() != ""]
+                if local_rank < len(ids) and ids[local_rank].isdigit():
+                    idx = int(ids[local_rank])
+                break
+        if idx >= len(gpus) or gpus[idx] < 0:
+            info["why"] = "no KFD GPU node %d under %s" % (idx, root)
+            return info
+        node = int(open("%s/class/drm/renderD%d/device/numa_node" % (root, gpus[idx])).read().strip())
+        info["numa_node"] = node
+        if node < 0:
+            info["why"] = "the GPU reports no NUMA node"
+            return info
+        cpus = _cpulist(open("%s/devices/system/node/node%d/cpulist" % (root, node)).read()) & os.sched_getaffinity(0)
+        if not cpus:
+            info["why"] = "none of NUMA node %d's CPUs is available to this process" % node
+            return info
+        os.sched_setaffinity(0, cpus)
+        info.update({"cpus": ",".join(str(c) for c in sorted(cpus)) if len(cpus) <= 8 else "%d..%d" % (min(cpus), max(cpus)),
+                     "n_cpus": len(cpus), "pinned": True})
+    except Exception as e:   # (no sysfs, no permission: run unpinned)
+        info["why"] = repr(e)
+    return info
 
 
 def launch_ranks(args, argv):
@@ -424,6 +490,10 @@ def _run(args, backend_cls, quiet):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (the launcher's rank count and --gpus must agree)" % (args.gpus, world))
+    # N > 1: every rank on the CPUs of its GPU's NUMA node, before anything touches the GPU (IIV_BENCH_PIN=1 / 0 forces / forbids it)
+    pin = None
+    if os.environ.get("IIV_BENCH_PIN", "1" if world > 1 else "0") == "1":
+        pin = pin_to_gpu_numa_node(0 if REHEARSE else local_rank)
     be = backend_cls(args, local_rank, world)
     # the process group exists for N > 1 only; IIV_BENCH_FORCE_DIST=1 creates it for one rank too, so that
     # the process-group initialisation (gloo, or RCCL with --dist-backend nccl), the barrier and the scalar reductions can be exercised on a 1-GPU box
@@ -473,6 +543,9 @@ def _run(args, backend_cls, quiet):
     seed_lo = all_ranks(float(seeds[0][0]), cdev, world, use_dist)     # first / last stream seed of every rank: disjoint ranges
     seed_hi = all_ranks(float(seeds[-1][0]), cdev, world, use_dist)
     elapsed = max_over_ranks(leg["elapsed"], cdev, world, use_dist)
+    # where every rank pinned itself (NUMA node, number of CPUs; -1 / 0: it ran unpinned)
+    pin_node = all_ranks(float(pin["numa_node"] if pin and pin["pinned"] else -1), cdev, world, use_dist)
+    pin_cpus = all_ranks(float(pin["n_cpus"] if pin and pin["pinned"] else 0), cdev, world, use_dist)
 
     frames_done = args.steps * F * S * n_gpus
     fps = frames_done / elapsed
@@ -487,7 +560,12 @@ def _run(args, backend_cls, quiet):
         "launcher": os.environ.get("IIV_BENCH_LAUNCHED_BY") or ("torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "env" if world > 1 else None),
         "per_rank_frames_per_s": {"min": args.steps * F * S / max(rank_elapsed), "max": args.steps * F * S / min(rank_elapsed),
                                   "ranks": len(rank_elapsed)},
+        "per_rank_ms_per_step": {"min": 1000.0 * min(rank_elapsed) / args.steps, "max": 1000.0 * max(rank_elapsed) / args.steps,
+                                 "all": [round(1000.0 * e / args.steps, 3) for e in rank_elapsed]},
         "per_rank_stream_seeds": [[int(a), int(b)] for a, b in zip(seed_lo, seed_hi)],
+        # NUMA node and CPU count every rank pinned itself to before its first GPU call (pin_to_gpu_numa_node; -1 / 0 = unpinned;
+        # single-GPU runs do not pin unless IIV_BENCH_PIN=1); rank 0's own record in full
+        "per_rank_cpu_affinity": {"numa_node": [int(x) for x in pin_node], "n_cpus": [int(x) for x in pin_cpus], "rank0": pin},
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1000.0 * elapsed / args.steps,

@@ -79,12 +79,37 @@ def _bench_worker(rank, world, port, q, argv):
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         out = bench.main(argv, backend_cls=factory)
+    made[0].log["affinity"] = sorted(os.sched_getaffinity(0))
     q.put((rank, out["value"], out["config"], made[0].log, buf.getvalue()))
 
 
-def test_bench_main_runs_in_two_ranks():
-    argv = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--frames-per-step", "4", "--palette", "IIGS"]
+def _fake_sysfs(root):
+    """A two-GPU, two-socket machine as bench.pin_to_gpu_numa_node reads it: KFD node 0 is the CPU, nodes 1 and 2 are GPUs
+    whose render nodes sit on NUMA nodes 0 and 1, four CPUs each (this container has eight)."""
+    def put(path, text):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            f.write(text)
+    put(root + "/class/kfd/kfd/topology/nodes/0/properties", "cpu_cores_count 8\nsimd_count 0\ndrm_render_minor 0\n")
+    for g in (1, 2):
+        put(root + "/class/kfd/kfd/topology/nodes/%d/properties" % g, "cpu_cores_count 0\nsimd_count 1024\ndrm_render_minor %d\n" % (127 + g))
+        put(root + "/class/drm/renderD%d/device/numa_node" % (127 + g), "%d\n" % (g - 1))
+        put(root + "/devices/system/node/node%d/cpulist" % (g - 1), "%d-%d\n" % (4 * (g - 1), 4 * (g - 1) + 3))
+
+
+def test_bench_main_runs_in_two_ranks(tmp_path, monkeypatch):
+    _fake_sysfs(str(tmp_path))
+    monkeypatch.setenv("IIV_BENCH_SYSFS", str(tmp_path))   # (the spawned ranks inherit it)
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    argv = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--frames-per-step", "4", "--config", "5"]
     (r0, v0, cfg0, log0, line0), (r1, v1, cfg1, log1, line1) = _spawn(_bench_worker, 2, (argv,))
+    # every rank pinned itself to the CPUs of its GPU's NUMA node before anything else, and the line says so
+    if len(os.sched_getaffinity(0)) >= 8:
+        assert log0["affinity"] == [0, 1, 2, 3] and log1["affinity"] == [4, 5, 6, 7]
+        d_ = json.loads(line0)
+        assert d_["per_rank_cpu_affinity"]["numa_node"] == [0, 1] and d_["per_rank_cpu_affinity"]["n_cpus"] == [4, 4]
+        assert d_["per_rank_cpu_affinity"]["rank0"]["pinned"] and d_["per_rank_cpu_affinity"]["rank0"]["cpus"] == "0,1,2,3"
     # both ranks settled on the clip count the smaller rank can hold (MIN over ranks), and the
     # whole-job value counts both GPUs
     assert cfg0["streams_per_gpu"] == cfg1["streams_per_gpu"] == log0["clips"][0] == log1["clips"][0]
@@ -103,6 +128,9 @@ def test_bench_main_runs_in_two_ranks():
     # (the greedy kernel's HBM fraction is the contract's yardstick; what binds it -- instruction issue -- is labelled as such)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["roofline"]["bound"] == "issue" and d["roofline"]["unit"] == "GB/s"
     assert d["dist_backend"] == "gloo" and d["world_size"] == 2
+    assert len(d["per_rank_ms_per_step"]["all"]) == 2 and d["per_rank_ms_per_step"]["min"] <= d["per_rank_ms_per_step"]["max"]
+    a, b = d["per_rank_stream_seeds"]
+    assert a[1] < b[0] or b[1] < a[0]          # disjoint seed ranges
 
 
 def test_bench_gpus_flag_starts_the_ranks_itself():
