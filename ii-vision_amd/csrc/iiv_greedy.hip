@@ -380,6 +380,9 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
     // (phase B keeps per-lane minima of the re-queued bag up to date: `track` hands it the keys a step pushes)
 #ifdef IIV_STAMPS
     int n_ties = 0, n_tie_members = 0, n_ties_small = 0;
+    // (what the nonces have to order at a tie: the bytes sharing the smallest delta if there are two or more of them, else
+    // those sharing the second -- how many, and how many a LANE holds at most)
+    int n_rel = 0, n_rel_single = 0, n_rel_double = 0;
 #endif
     bool prev_tie = false;        // the previous step's two winners shared their delta: expect the same of this one
     int n_exact = 0;              // steps of this launch that took the exact-nonce path (tie_stats: what the host picks the kernel form by)
@@ -599,6 +602,29 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
             }
             return __ballot(m < (1u << kWdDwShift) - 1u) != 0ull;
         };
+#ifdef IIV_STAMPS
+        {   // diagnostic build: how often the nonces decide, and among how many bytes -- computed beside the step, whatever path it takes
+            int D1 = k1, D2 = k2;
+            wave_top2_i32(D1, D2);
+            if (D1 < 0 && D2 < 0 && ((D1 >> kWdDwShift) == (D2 >> kWdDwShift) || shared_delta(D2))) {
+                int n1 = 0;
+#pragma unroll
+                for (int r = 0; r < 4; r++) n1 += (int)__popcll(__ballot(ke[r] < 0 && (ke[r] >> kWdDwShift) == (D1 >> kWdDwShift)));
+                n_ties++;
+                n_tie_members += n1;
+                if (n1 <= 2) n_ties_small++;
+                // what the nonces have to order: the bytes at the smallest delta if two or more share it, else those at the second
+                const int dR = n1 >= 2 ? (D1 >> kWdDwShift) : (D2 >> kWdDwShift);
+                int lane_cnt = 0;
+#pragma unroll
+                for (int r = 0; r < 4; r++) lane_cnt += (ke[r] < 0 && (ke[r] >> kWdDwShift) == dR) ? 1 : 0;
+                const unsigned long long b1 = __ballot(lane_cnt >= 1), b2 = __ballot(lane_cnt >= 2), b3 = __ballot(lane_cnt >= 3), b4 = __ballot(lane_cnt >= 4);
+                n_rel += IIV_SGPR(__popcll(b1) + __popcll(b2) + __popcll(b3) + __popcll(b4));
+                n_rel_single += IIV_SGPR(b2 == 0ull ? 1 : 0);
+                n_rel_double += IIV_SGPR((b2 != 0ull && b3 == 0ull) ? 1 : 0);
+            }
+        }
+#endif
         // the wave's two smallest eligible keys in one fused-DPP pass (iiv_wave.h)
         int K1 = k1, K2 = k2;
         if (!tie) wave_top2_i32(K1, K2); else K1 = K2 = 0;
@@ -620,16 +646,6 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
                 }
             }
         }
-#ifdef IIV_STAMPS
-        if (tie) {   // diagnostic build: how often the nonces decide, and among how many bytes (those sharing the smallest delta)
-            int n1 = 0;
-#pragma unroll
-            for (int r = 0; r < 4; r++) n1 += (int)__popcll(__ballot(ke[r] < 0 && (ke[r] >> kWdDwShift) == (K1 >> kWdDwShift)));
-            n_ties++;
-            n_tie_members += n1;
-            if (n1 <= 2) n_ties_small++;
-        }
-#endif
         // (the LDS-shared form is dispatched to input whose steps the nonces rarely decide: lay the exact path out of line there)
         if (W > 1 ? __builtin_expect(tie, 0) : tie) {
             // the reference's (delta, nonce, offset) heap order with every candidate's nonce
@@ -990,6 +1006,8 @@ __global__ __launch_bounds__(64 * W, W == 1 ? IIV_WAVE_OCC : MODE == kHGR ? (W +
         S.stamps[29] = wave_r0;   // start / end on the constant 100 MHz counter all XCDs share
         S.stamps[30] = __builtin_amdgcn_s_memrealtime();
         S.stamps[31] = (unsigned long long)n_ties | ((unsigned long long)n_ties_small << 20) | ((unsigned long long)n_tie_members << 40);
+        S.stamps[20] = (unsigned long long)n_rel;
+        S.stamps[21] = (unsigned long long)n_rel_single | ((unsigned long long)n_rel_double << 32);
         S.stamps[28] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 /* XCC_ID */) | (0 << 6) | (31 << 11)) << 32) |
                        (unsigned)__builtin_amdgcn_s_getreg((4 /* HW_ID */) | (0 << 6) | (31 << 11));
 #endif

@@ -80,3 +80,6 @@ tt = full[:, 31]
 nt, nsmall, nmem = (tt & 0xfffff).sum(), ((tt >> 20) & 0xfffff).sum(), (tt >> 40).sum()
 print("        ties (the nonces decide the two extra offsets): %.1f %% of the opcodes; bytes sharing the smallest delta at a tie: %.1f on average; "
       "ties with <= 2 such bytes: %.0f %%" % (100.0 * nt / max(full[:, 26].sum(), 1), nmem / max(nt, 1), 100.0 * nsmall / max(nt, 1)))
+rel, single, double = full[:, 20].sum(), (full[:, 21] & 0xffffffff).sum(), (full[:, 21] >> 32).sum()
+print("        what the nonces order at a tie (the bytes at the smallest delta if >= 2 share it, else those at the second): %.1f bytes on average; "
+      "no lane holds two of them at %.0f %% of the ties, none holds three at another %.0f %%" % (rel / max(nt, 1), 100.0 * single / max(nt, 1), 100.0 * double / max(nt, 1)))
