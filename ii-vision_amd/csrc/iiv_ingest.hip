@@ -229,16 +229,32 @@ __global__ __launch_bounds__(256) void ingest_kernel(int n, const uint8_t *__res
 // wavefront, a workgroup barrier per pixel step -- ran 0.19 M HGR frames/s; a first one-wave-per-frame DHGR form of this
 // round, 64 rows two pixels apart with dynamic phases, 2.9 M; this form 5.9 M HGR.)
 constexpr int kDiffWaves = 2;   // waves per block
+// Round 6: the source rows come through LDS.  A lane walks its row 42 bytes per seven steps, and sixty lanes of a wave
+// walk sixty rows: every load instruction touched sixty cache lines, each line was fetched again for each of the ~3
+// groups it holds (a CU's waves keep 150 KB of lines in use, its L1 holds 32), and the kernel ran at half the rate it has
+// when every lane reads the same row (4.0 against 7.6 M DHGR frames/s: profiles/r06_diffusion_experiments.txt).  Now a
+// lane's row is a stream of 64-byte blocks (aligned relative to the frame, whose size is a multiple of 64): three of
+// them -- the one its next group starts in and the two behind it -- are in LDS, filled by LDS-DMA loads
+// (global_load_lds_dwordx4: sixteen bytes per lane and instruction straight into LDS, no registers), a block requested
+// whole and at once, at least one seven-step iteration before the first group that needs it.  One instruction's
+// destination is wave-uniform (base + lane x 16), so the layout is [slot 0..2][16-byte chunk 0..3][lane][16 B] and the
+// lanes that fill the same slot in an iteration go together under an execution mask.  12 KiB per wave.
+#ifndef IIV_DIFF_STAGE
+#define IIV_DIFF_STAGE 1
+#endif
 // waves per SIMD the error-diffusion kernel's registers are held to: DHGR runs 11 % faster at five (96 VGPRs, six dwords
 // spilled) than at the four it gets unasked (110 VGPRs); HGR does not (-1 %); six (80 VGPRs) costs both a quarter
 #ifndef IIV_DIFF_OCC
-#define IIV_DIFF_OCC(MODE) ((MODE) == kDHGR ? 5 : 4)
+#define IIV_DIFF_OCC(MODE) (IIV_DIFF_STAGE ? 3 : (MODE) == kDHGR ? 5 : 4)   // (staged: 12 KiB of LDS per wave hold it to three anyway)
 #endif
 template <int MODE>
 __global__ __launch_bounds__(64 * kDiffWaves, IIV_DIFF_OCC(MODE)) void ingest_diffusion_kernel(int n, const uint8_t *__restrict__ rgb_frames, const IngestPalette P,
                                                                            uint8_t *__restrict__ main_mem, uint8_t *__restrict__ aux_mem)
 {
     __shared__ int ring_s[kDiffWaves][3][16][4];
+#if IIV_DIFF_STAGE
+    __shared__ __attribute__((aligned(16))) uint32_t stage_s[kDiffWaves][12][64][4];   // [slot x 4 + chunk][lane][16 B]
+#endif
     __shared__ uint32_t pal_s[16];    // DHGR: R | G << 8 | B << 16 of the sixteen colour values
     __shared__ uint32_t rgb_s[8];     // R | G << 8 | B << 16 of colour4[pb][pattern]: black, violet | blue, green | orange, white
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -276,11 +292,14 @@ __global__ __launch_bounds__(64 * kDiffWaves, IIV_DIFF_OCC(MODE)) void ingest_di
     int pbA = 0, pbB = 0;
     uint32_t bytesAB = 0;                 // HGR: the two screen bytes of the group, as they fill; DHGR: its 28 dots
     // source group of sequence position tt (clamped into the frame)
-    auto load_group = [&](int tt, uint32_t (&w)[11]) {
+    [[maybe_unused]] auto load_group = [&](int tt, uint32_t (&w)[11]) {
         int v = tt < 0 ? 0 : tt;
         int qq = v / 20, gg = v - 20 * qq;
         int rw = 20 * qq + i;
         if (rw > 191) rw = 191, gg = 0;
+#ifdef IIV_EXP_DIFF_SAMEROW
+        rw = 0;   // (timing experiment only: every lane reads row 0 -- what the kernel costs without its row-strided reads)
+#endif
         const size_t off = (size_t)rw * 840 + (size_t)gg * 42;
         const uint32_t *p32 = reinterpret_cast<const uint32_t *>(frame + (off & ~(size_t)3));
         uint32_t raw[11];
@@ -310,13 +329,113 @@ __global__ __launch_bounds__(64 * kDiffWaves, IIV_DIFF_OCC(MODE)) void ingest_di
     bool active = false;
     int row = i;
     size_t outp = 0;
+#if IIV_DIFF_STAGE
+    // ---- the staged source stream of this lane (byte offsets are relative to its frame; blocks = 64 bytes)
+    // reader: where the group it reads next starts, and the slot of that byte's block; what it has moved past is refilled
+    uint32_t (*stage)[64][4] = stage_s[wv];
+    const int last_pass_row = 180 + i < 192 ? 180 + i : 160 + i;   // this lane's last row
+    int rd_row = i, rd_off = i * 840, rd_slot = 0;
+    // fetcher: the next block to request -- its offset, how many blocks of its row are still to come (itself included),
+    // its row, its slot
+    auto blocks_of_row = [](int rw) -> int { return ((rw * 840 + 839) >> 6) - ((rw * 840) >> 6) + 1; };
+    int fe_row = i, fe_off = (i * 840) & ~63, fe_left = blocks_of_row(i), fe_slot = 0, fe_need = 3;
+    auto fetch_round = [&]() {
+        // every lane that still needs a block requests its next one: the lanes aiming at the same slot together
+#pragma unroll
+        for (int sl = 0; sl < 3; sl++) {
+            const bool go = fe_need > 0 && fe_slot == sl;
+            if (__ballot(go) == 0ull) continue;
+            if (go) {
+                const uint8_t *src = frame + fe_off;
+#pragma unroll
+                for (int c = 0; c < 4; c++) __builtin_amdgcn_global_load_lds(src + 16 * c, &stage[sl * 4 + c][0][0], 16, 0, 0);
+                fe_need--;
+                fe_slot = fe_slot == 2 ? 0 : fe_slot + 1;
+                if (--fe_left == 0) {
+                    fe_row = fe_row + 20 <= last_pass_row ? fe_row + 20 : fe_row;   // (behind its last row a lane reads that row again: never used)
+                    fe_off = (fe_row * 840) & ~63;
+                    fe_left = blocks_of_row(fe_row);
+                } else {
+                    fe_off += 64;
+                }
+            }
+        }
+    };
+    // the eleven dwords of the group at rd_off, funnel-shifted to start at its first byte: four 16-byte chunks from LDS,
+    // a window of twelve of their sixteen dwords chosen by the start's dword inside its chunk
+    auto read_group = [&](uint32_t (&w)[11]) {
+        const int o = rd_off & 63;                        // the start inside its block (even)
+        const int nx_slot = rd_slot == 2 ? 0 : rd_slot + 1;
+        uint32_t D[16];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int t = (o & ~15) + 16 * k;             // chunk k of the window: byte offset from the block's start (< 128)
+            const int sl = t < 64 ? rd_slot : nx_slot;
+            const uint4 v = *reinterpret_cast<const uint4 *>(&stage[sl * 4 + ((t >> 4) & 3)][lane][0]);
+            D[4 * k] = v.x, D[4 * k + 1] = v.y, D[4 * k + 2] = v.z, D[4 * k + 3] = v.w;
+        }
+        // (bitwise selects on opaque masks: written as `sd & 2 ? D[j + 2] : D[j]` the compiler stores the sixteen dwords to
+        // SCRATCH and loads the window back at a dynamic offset)
+        uint32_t m2 = 0u - (((uint32_t)o >> 3) & 1u), m1 = 0u - (((uint32_t)o >> 2) & 1u);
+        asm volatile("" : "+v"(m2), "+v"(m1));
+        uint32_t E[14], F[12];
+#pragma unroll
+        for (int j = 0; j < 14; j++) E[j] = (D[j + 2] & m2) | (D[j] & ~m2);   // v_bfi_b32
+#pragma unroll
+        for (int j = 0; j < 12; j++) F[j] = (E[j + 1] & m1) | (E[j] & ~m1);
+        const uint32_t sh = ((uint32_t)o & 2u) * 8u;
+#pragma unroll
+        for (int j = 0; j < 10; j++) w[j] = __builtin_amdgcn_alignbit(F[j + 1], F[j], sh);
+        w[10] = F[10] >> sh;
+    };
+    // the reader moves on to group g (>= 1) of this lane's sequence; the blocks it leaves behind become requests
+    auto advance_reader = [&](int g) {
+        if (g < 1) return;                                // (in front of its first group a lane reads group 0 again and again)
+        const int gg = g % 20, rw = 20 * (g / 20) + i;
+        if (rw > last_pass_row) return;                   // (behind its last row: it stays where it is; nothing of it is used)
+        const int old_blk = rd_off >> 6;
+        int d;
+        if (gg == 0) {                                    // a new row: the rest of the old row's blocks, then the new row's first
+            const int old_last = (rd_row * 840 + 839) >> 6;
+            d = old_last - old_blk + 1;
+            rd_row = rw;
+            rd_off = rw * 840;
+        } else {
+            rd_off += 42;
+            d = (rd_off >> 6) - old_blk;
+        }
+        rd_slot = rd_slot + d;
+        rd_slot = rd_slot >= 3 ? rd_slot - 3 : rd_slot;
+        fe_need += d;
+    };
+    auto staged_wait = []() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    // (the order below keeps a block's request one whole iteration in front of its first read: a group is read where the
+    // reader STANDS, then the reader moves on to the next group and what it left behind is requested -- at a row's end that
+    // can be two blocks at once, and the next row's second block is then among the new requests)
+    fetch_round();
+    fetch_round();
+    fetch_round();
+    staged_wait();
+    read_group(cur);
+    advance_reader(tt + 1);
+    fetch_round();
+    fetch_round();
+    staged_wait();
+    read_group(nxt);
+    advance_reader(tt + 2);
+    fetch_round();
+    fetch_round();
+#else
     load_group(tt, cur);
     load_group(tt + 1, nxt);
+#endif
     auto step = [&](auto Pc) {
         constexpr int PH = decltype(Pc)::value;
         // what arrived: D(pixel + 5) of the row above, into its slot; lane 0 of a frame slot takes it from the ring
         {
-            // (every lane reads the ring -- a branch per step costs more than three LDS words; only lanes 0 / 20 / 40 keep them)
+            // (every lane reads the ring -- a branch per step costs more than three LDS words; only lanes 0 / 20 / 40 keep them.
+            // Round 6, measured and removed: the ring word requested here but taken at the start of the NEXT step -- its slot
+            // of the queue is first looked at two steps later -- and no fence per step: 4.94 against 4.97 M frames/s, same box)
             const int s = 7 * tt + PH - 135;         // lane 19's sequence index of that D
             const int *slot = ring[s & 15];
             int s0 = slot[0], s1 = slot[1], s2 = slot[2];
@@ -430,11 +549,23 @@ __global__ __launch_bounds__(64 * kDiffWaves, IIV_DIFF_OCC(MODE)) void ingest_di
         step(std::integral_constant<int, 3>{});
         step(std::integral_constant<int, 4>{});
         step(std::integral_constant<int, 5>{});
+#if IIV_DIFF_STAGE
+        // what was requested at the end of the previous iteration has landed by now (six steps later).  HERE, not at the read
+        // below: behind step 6 the wait would also cover the row's stores that step has just issued
+        staged_wait();
+#endif
         step(std::integral_constant<int, 6>{});
 #pragma unroll
         for (int j = 0; j < 11; j++) cur[j] = nxt[j];
         tt++;
+#if IIV_DIFF_STAGE
+        read_group(nxt);          // group tt + 1: where the reader stands (its blocks: waited for in front of step 6)
+        advance_reader(tt + 2);
+        fetch_round();            // the blocks left behind: at most two per lane (a row's end)
+        if (__ballot(fe_need > 0) != 0ull) fetch_round();
+#else
         load_group(tt + 1, nxt);
+#endif
     }
 }
 
@@ -449,10 +580,12 @@ int frames_to_memory_maps(int mode, const uint8_t palette_rgb[48], int n, const 
     if (rc) return rc;
     if (dither == IIV_DITHER_DIFFUSION) {
         const dim3 grid((unsigned)((n + 3 * kDiffWaves - 1) / (3 * kDiffWaves)));
+        // (IIV_EXP_DIFF_LDS_PAD: timing experiments only -- extra dynamic LDS per workgroup caps the waves resident per CU)
+        static const int lds_pad = getenv("IIV_EXP_DIFF_LDS_PAD") ? atoi(getenv("IIV_EXP_DIFF_LDS_PAD")) : 0;
         if (mode == kDHGR)
-            hipLaunchKernelGGL(ingest_diffusion_kernel<kDHGR>, grid, dim3(64 * kDiffWaves), 0, st, n, d_rgb, P, d_main, d_aux);
+            hipLaunchKernelGGL(ingest_diffusion_kernel<kDHGR>, grid, dim3(64 * kDiffWaves), (size_t)lds_pad, st, n, d_rgb, P, d_main, d_aux);
         else
-            hipLaunchKernelGGL(ingest_diffusion_kernel<kHGR>, grid, dim3(64 * kDiffWaves), 0, st, n, d_rgb, P, d_main, d_aux);
+            hipLaunchKernelGGL(ingest_diffusion_kernel<kHGR>, grid, dim3(64 * kDiffWaves), (size_t)lds_pad, st, n, d_rgb, P, d_main, d_aux);
         return hip_check(hipGetLastError(), "ingest diffusion kernel launch");
     }
     const size_t total = (size_t)n * 3840;
