@@ -1325,6 +1325,16 @@ def _ingest_and_e2e(be, args, resident_fps, emit_fps):
         out["emit_same_content"]["what"] = "iiv_encode -> iiv_emit_chunk -> pinned host memory on the e2e leg's own frames, converted beforehand"
         out["e2e"]["vs_emit_same_content"] = out["e2e"]["value"] / out["emit_same_content"]["value"]
         out["e2e_serial"]["vs_emit_same_content"] = out["e2e_serial"]["value"] / out["emit_same_content"]["value"]
+        # ... and the same for the frames error diffusion makes of the source (other content: other rate)
+        for k in range(K):
+            keep = bufs[0]
+            bufs[0] = pre[k]
+            convert(k, 0, native.DITHER_DIFFUSION)
+            bufs[0] = keep
+        torch.cuda.synchronize()
+        out["emit_same_content_diffusion"] = e2e(native.DITHER_DIFFUSION, False, pre=pre)
+        out["emit_same_content_diffusion"]["what"] = "the same on the error-diffusion frames of e2e_diffusion, converted beforehand"
+        out["e2e_diffusion"]["vs_emit_same_content"] = out["e2e_diffusion"]["value"] / out["emit_same_content_diffusion"]["value"]
         del pre
     except Exception as e:   # (e.g. not enough free HBM for the K pre-converted steps)
         out["emit_same_content"] = {"value": None, "error": repr(e)}
