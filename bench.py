@@ -977,11 +977,12 @@ def _dropin_video(args, n_frames=20):
                         if dhgr else screen.HGRBitmap(main_memory=main, palette=pal))
         return tgts[fr]
 
-    def run(budget):
+    def run(budget, lookahead=True):
         random.seed(1)
         np.random.seed(1)
         v = video.Video(FrameGrabber(), ticks_per_second=14700., palette=pal,
                         mode=video_mode.VideoMode.DHGR if dhgr else video_mode.VideoMode.HGR)
+        v.LOOKAHEAD = lookahead
         tgts = {}
         t0 = time.perf_counter()
         with contextlib.redirect_stdout(io.StringIO()):
@@ -1010,13 +1011,17 @@ def _dropin_video(args, n_frames=20):
                         if dhgr:
                             aux = not aux
                         stream_pos += 4
+        stats.update(getattr(v, "lookahead_stats", {}))
         return n_frames / (time.perf_counter() - t0)
 
+    stats = {}
     try:
         run(False)   # (warm-up: table build, first launches)
-        return {"value": run(False), "with_budget": run(True), "unit": "frames/s", "frames": n_frames,
+        return {"value": run(False), "lookahead": dict(stats), "without_lookahead": run(False, lookahead=False), "with_budget": run(True),
+                "unit": "frames/s", "frames": n_frames,
                 "what": "video.Video driven from Python as movie.Movie.encode drives it (tick() per audio sample, a generator per "
-                        "frame and bank flip, one next() per opcode), %s, one clip; with_budget: encode_frame(..., budget=k)" % args.mode}
+                        "frame and bank flip, one next() per opcode), %s, one clip; lookahead: the generators behind a bank flip enqueued ahead of the caller "
+                        "(Video.LOOKAHEAD) and what became of them; with_budget: encode_frame(..., budget=k)" % args.mode}
     except Exception as e:
         return {"value": None, "error": repr(e)}
 

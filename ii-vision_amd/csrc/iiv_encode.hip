@@ -79,9 +79,9 @@ struct Encoder {
     int content_choice;     // IIV_OPT_CONTENT_CHOICE
     int fourth_offset;      // IIV_OPT_FOURTH_OFFSET
     StreamState *d_states;
-    StreamState *d_snapshot;  // iiv_encoder_snapshot copy (lazily allocated)
+    StreamState *d_snapshot[2];  // iiv_encoder_snapshot copies (lazily allocated; slot 1: iiv_encoder_snapshot_slot)
     // generator bookkeeping: one entry while every stream has run the same schedule, else one per stream
-    std::vector<GenState> gens, snap_gens;
+    std::vector<GenState> gens, snap_gens[2];
     // launch descriptors: pinned staging ring -> device buffer, both grown on demand
     LaunchSeg *h_segs[2];
     hipEvent_t seg_ev[2];
@@ -256,7 +256,8 @@ void encoder_destroy(Encoder *e)
     if (e->d_perm) (void)hipFree(e->d_perm);
     if (e->d_packed) (void)hipFree(e->d_packed);
     if (e->d_states) (void)hipFree(e->d_states);
-    if (e->d_snapshot) (void)hipFree(e->d_snapshot);
+    for (int k = 0; k < 2; k++)
+        if (e->d_snapshot[k]) (void)hipFree(e->d_snapshot[k]);
     if (e->d_strings) (void)hipFree(e->d_strings);
     if (e->d_hgr_dots) (void)hipFree(e->d_hgr_dots);
     if (e->d_dw_pieces) (void)hipFree(e->d_dw_pieces);
@@ -306,7 +307,7 @@ int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, c
     e->d_left_t = e->d_right_t = nullptr;
     e->d_joint_l = e->d_joint_r = nullptr;
     e->d_brief = nullptr;
-    e->d_states = e->d_snapshot = nullptr;
+    e->d_states = e->d_snapshot[0] = e->d_snapshot[1] = nullptr;
     e->d_strings = nullptr;
     e->d_hgr_dots = nullptr;
     e->d_dw_pieces = nullptr;
@@ -404,22 +405,22 @@ int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, c
     return IIV_OK;
 }
 
-int encoder_snapshot(Encoder *e, hipStream_t st)
+int encoder_snapshot(Encoder *e, int slot, hipStream_t st)
 {
-    if (!e) return set_error(IIV_ERR_INVALID, "snapshot: null encoder");
+    if (!e || slot < 0 || slot > 1) return set_error(IIV_ERR_INVALID, "snapshot: null encoder or slot not 0 / 1");
     const size_t bytes = sizeof(StreamState) * (size_t)e->n_streams;
-    if (!e->d_snapshot) IIV_HIP(hipMalloc(&e->d_snapshot, bytes));
-    IIV_HIP(hipMemcpyAsync(e->d_snapshot, e->d_states, bytes, hipMemcpyDeviceToDevice, st));
-    e->snap_gens = e->gens;
+    if (!e->d_snapshot[slot]) IIV_HIP(hipMalloc(&e->d_snapshot[slot], bytes));
+    IIV_HIP(hipMemcpyAsync(e->d_snapshot[slot], e->d_states, bytes, hipMemcpyDeviceToDevice, st));
+    e->snap_gens[slot] = e->gens;
     return IIV_OK;
 }
 
-int encoder_rollback(Encoder *e, hipStream_t st)
+int encoder_rollback(Encoder *e, int slot, hipStream_t st)
 {
-    if (!e || !e->d_snapshot) return set_error(IIV_ERR_INVALID, "rollback: no snapshot");
+    if (!e || slot < 0 || slot > 1 || !e->d_snapshot[slot]) return set_error(IIV_ERR_INVALID, "rollback: no snapshot in that slot");
     const size_t bytes = sizeof(StreamState) * (size_t)e->n_streams;
-    IIV_HIP(hipMemcpyAsync(e->d_states, e->d_snapshot, bytes, hipMemcpyDeviceToDevice, st));
-    e->gens = e->snap_gens;
+    IIV_HIP(hipMemcpyAsync(e->d_states, e->d_snapshot[slot], bytes, hipMemcpyDeviceToDevice, st));
+    e->gens = e->snap_gens[slot];
     return IIV_OK;
 }
 
@@ -1154,13 +1155,25 @@ void iiv_encoder_destroy(iiv_encoder *enc)
 int iiv_encoder_snapshot(iiv_encoder *enc, void *stream)
 {
     if (!enc) return iiv::set_error(IIV_ERR_INVALID, "null encoder");
-    return iiv::encoder_snapshot(enc->impl, (hipStream_t)stream);
+    return iiv::encoder_snapshot(enc->impl, 0, (hipStream_t)stream);
 }
 
 int iiv_encoder_rollback(iiv_encoder *enc, void *stream)
 {
     if (!enc) return iiv::set_error(IIV_ERR_INVALID, "null encoder");
-    return iiv::encoder_rollback(enc->impl, (hipStream_t)stream);
+    return iiv::encoder_rollback(enc->impl, 0, (hipStream_t)stream);
+}
+
+int iiv_encoder_snapshot_slot(iiv_encoder *enc, int slot, void *stream)
+{
+    if (!enc) return iiv::set_error(IIV_ERR_INVALID, "null encoder");
+    return iiv::encoder_snapshot(enc->impl, slot, (hipStream_t)stream);
+}
+
+int iiv_encoder_rollback_slot(iiv_encoder *enc, int slot, void *stream)
+{
+    if (!enc) return iiv::set_error(IIV_ERR_INVALID, "null encoder");
+    return iiv::encoder_rollback(enc->impl, slot, (hipStream_t)stream);
 }
 
 int iiv_encoder_set_option(iiv_encoder *enc, int option, int value)

@@ -39,7 +39,7 @@ SYMBOLS = [
     "iiv_symmetrise_table", "iiv_store_table_from_table",
     "iiv_pack", "iiv_diff_weights", "iiv_compute_delta_pages",
     "iiv_encoder_create", "iiv_encoder_destroy", "iiv_encoder_set_option", "iiv_encoder_info",
-    "iiv_encoder_snapshot", "iiv_encoder_rollback", "iiv_encoder_get_state", "iiv_encoder_set_state",
+    "iiv_encoder_snapshot", "iiv_encoder_rollback", "iiv_encoder_snapshot_slot", "iiv_encoder_rollback_slot", "iiv_encoder_get_state", "iiv_encoder_set_state",
     "iiv_encoder_set_state_range", "iiv_encoder_get_video_state", "iiv_encoder_set_video_state",
     "iiv_encoder_get_video_brief", "iiv_encoder_get_video_brief_async",
     "iiv_encode", "iiv_encode_streams",
@@ -126,6 +126,8 @@ def lib():
         L.iiv_encoder_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.iiv_encoder_snapshot.argtypes = [vp, vp]
     L.iiv_encoder_rollback.argtypes = [vp, vp]
+    L.iiv_encoder_snapshot_slot.argtypes = [vp, i32, vp]
+    L.iiv_encoder_rollback_slot.argtypes = [vp, i32, vp]
     L.iiv_encoder_destroy.argtypes = [vp]
     L.iiv_encoder_destroy.restype = None
     L.iiv_encoder_get_state.argtypes = [vp, i32, i32, vp, sz]
@@ -591,11 +593,11 @@ class Encoder:
         # the rows as they were written: (n_streams, total, 6) over the front of the buffer
         return ops_out.view(-1)[:need].view(self.n_streams, total, 6)
 
-    def snapshot(self):
-        check(lib().iiv_encoder_snapshot(self._h, stream_ptr()))
+    def snapshot(self, slot=0):
+        check(lib().iiv_encoder_snapshot_slot(self._h, int(slot), stream_ptr()))
 
-    def rollback(self):
-        check(lib().iiv_encoder_rollback(self._h, stream_ptr()))
+    def rollback(self, slot=0):
+        check(lib().iiv_encoder_rollback_slot(self._h, int(slot), stream_ptr()))
 
     def check(self):
         bad = C.c_int(-1)

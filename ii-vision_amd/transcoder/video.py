@@ -35,6 +35,12 @@ pacing can be asked for -- 292 opcodes, the gap between two DHGR bank flips, or 
 step per next()) gets batched launches without a promise: N opcodes are produced from a
 device-side snapshot and rolled back + replayed if fewer were consumed.  Batched, many-stream encoding
 (what bench.py measures) goes through stream_batch.StreamBatch instead.
+
+Look-ahead (round 6, `Video.LOOKAHEAD`): behind a movie.py-paced DHGR generator whose opcodes end at a bank flip, the generator
+the caller will start next -- the other bank of the SAME target (movie.py:139-148) -- is enqueued at once, on a second
+snapshot, so that the device computes it while Python hands out this generator's opcodes.  If encode_frame() is then called
+with that target and bank (and nobody touched the state or the global generators in between) its launch has already run; if not,
+the snapshot is restored and nothing of it is observable.
 """
 
 import ctypes
@@ -95,6 +101,9 @@ class Video:
     #: iiv_encoder_get_video_brief); draws from / reseeds of random or np.random between two
     #: generators are noticed and carried to the device.
     STRICT_SYNC = False
+
+    #: True (default): run one generator ahead of a movie.py-paced caller (module docstring).  Speed only.
+    LOOKAHEAD = True
 
     def __init__(
             self,
@@ -165,6 +174,10 @@ class Video:
         self._ops_done = 0        # opcodes consumed from settled chunks
         self._flip_base = -1      # _ops_done at the last bank flip seen (movie.py's first socket frame holds 291 opcodes)
         self._last_bank = None    # is_aux of the latest generator that ran
+        # the generator enqueued ahead of the caller (LOOKAHEAD): None, or what it was launched for and where its results land
+        self._ahead = None
+        self.lookahead_stats = {"launched": 0, "adopted": 0, "undone": 0}   # (what became of the generators enqueued ahead)
+        self._ahead_bufs = None   # second set of opcode / brief buffers (the look-ahead's results must not overwrite the live generator's)
 
     # ---- the reference's public attributes; reading one settles any speculation first
     def _settled(name):  # noqa: N805
@@ -226,19 +239,31 @@ class Video:
             return True
         return False
 
-    def _paced_chunk(self):
-        """How many opcodes a movie.py-paced caller will pull before it starts another generator (SPECULATE = None)."""
+    def _paced_chunk(self, after=0, flipped=False, why=None):
+        """How many opcodes a movie.py-paced caller will pull before it starts another generator (SPECULATE = None).
+        after / flipped: the same question for the generator BEHIND the next `after` opcodes (flipped: it starts at a bank
+        flip) -- what the look-ahead is sized by.  why (a list): receives "flip" if the bank flip is what ends the count, "frame"
+        if the next frame does, None if neither is known."""
         dhgr = self.mode == VideoMode.DHGR
         n = 292 if dhgr else max(1, int(round(self.ticks_per_frame)))
+        reason = None
         if self._tick_now is not None:
             # pulls at ticks _tick_now, _tick_now + 1, ... up to the tick in front of the one that starts a frame
-            to_frame = int(-(-(self.ticks_per_frame * self.frame_number) // 1)) - int(self._tick_now)
+            to_frame = int(-(-(self.ticks_per_frame * self.frame_number) // 1)) - (int(self._tick_now) + after)
             if to_frame >= 1:
+                if not dhgr or to_frame < n:
+                    reason = "frame"
                 n = to_frame if not dhgr else min(n, to_frame)
-        if dhgr:
-            to_flip = 292 - (self._ops_done - self._flip_base)
-            if 1 <= to_flip < n:
+            elif after:
+                n, reason = 0, "frame"      # (the frame ends with the opcodes in front: no generator of this frame follows)
+        if dhgr and n > 0:
+            to_flip = 292 - ((self._ops_done + after) - (self._ops_done + after if flipped else self._flip_base))
+            if 1 <= to_flip <= n:
+                if to_flip < n or reason is None:
+                    reason = "flip"
                 n = to_flip
+        if why is not None:
+            why.append(reason)
         return min(n, 2048)
 
     # ------------------------------------------------------------------ device sync
@@ -317,7 +342,7 @@ class Video:
         """Settle the device state and bring home the small things: global RNG positions, out_of_work
         (and the numbers encode_frame prints / asserts).  The arrays stay on the device.  The brief itself usually is at
         hand already: it travels behind every launch (_launch), valid as long as the launch's opcodes are all consumed."""
-        self._settle(download=False)
+        self._settle(download=False, keep_ahead=self._brief_fresh)   # (a brief must be fetched: the device must stand where the caller is)
         if self._host_current:
             return None  # nothing on the device is newer than what the host holds
         if not self._brief_fresh:
@@ -358,15 +383,71 @@ class Video:
         self._brief_applied = False
         return self._ops_host[:n_ops].numpy()
 
-    def _settle(self, download=True):
-        """Make the device state -- and, with download, the host's -- reflect exactly the opcodes consumed so far."""
+    def _look_ahead(self, token, n_live, slot):
+        """Behind the live generator's launch (its n_live opcodes are in hand): if they end at a bank flip inside the frame,
+        enqueue the generator movie.py:139-148 starts next -- the other bank, the same target -- on snapshot `slot`, with the
+        opcodes and the brief of the state behind them copied to a second set of pinned buffers.  Nothing waits."""
+        import torch
+        why = []
+        self._paced_chunk(after=0, why=why)        # what ends the live generator's count as the pacing stands
+        # (the live chunk was sized by this very call before its launch; only a count that a bank flip ended has a successor
+        # inside the frame, and only if the caller's pacing is known)
+        if why[0] != "flip" or self._tick_now is None:
+            return
+        n = self._paced_chunk(after=n_live, flipped=True)
+        if n < 1:
+            return
+        if self._ahead_bufs is None:
+            self._ahead_bufs = dict(
+                ops_dev=torch.empty((1, 2048, 6), dtype=torch.uint8, device="cuda"),
+                ops_host=torch.empty((2048, 6), dtype=torch.uint8).pin_memory(),
+                vb_mem=torch.empty(ctypes.sizeof(native.VideoBrief), dtype=torch.uint8).pin_memory())
+        bufs = self._ahead_bufs
+        self._enc.snapshot(slot)
+        ops = self._enc.encode(token.fm, token.fa, [(0, int(not token.is_aux), 1, int(n))], ops_out=bufs["ops_dev"])
+        bufs["ops_host"][:n].copy_(ops[0], non_blocking=True)
+        vb = native.VideoBrief.from_address(bufs["vb_mem"].data_ptr())
+        self._enc.get_video_brief_async(vb)
+        self._host_current = False
+        self._ahead = dict(is_aux=not token.is_aux, main=token.main, aux=token.aux, n=int(n), slot=slot)
+        self.lookahead_stats["launched"] += 1
+
+    def _adopt(self, a):
+        """The generator enqueued ahead is the one the caller asked for: its launch has run (or is running); wait, check, and
+        swap the buffer sets so that the brief and the opcodes of this generator are the current ones."""
+        self._enc.check()          # (synchronises; raises what the reference's asserts would)
+        self.lookahead_stats["adopted"] += 1
+        bufs = self._ahead_bufs
+        self._pinned_brief()
+        bufs["ops_host"], self._ops_host = self._ops_host, bufs["ops_host"]
+        bufs["ops_dev"], self._ops_dev = self._ops_dev, bufs["ops_dev"]
+        bufs["vb_mem"], self._vb_mem = self._vb_mem, bufs["vb_mem"]
+        self._vb = native.VideoBrief.from_address(self._vb_mem.data_ptr())
+        self._host_current = False
+        self._brief_fresh = True
+        self._brief_applied = False
+        return self._ops_host[:a["n"]].numpy()
+
+    def _settle(self, download=True, keep_ahead=False):
+        """Make the device state -- and, with download, the host's -- reflect exactly the opcodes consumed so far.
+        keep_ahead: a generator enqueued ahead of the caller (LOOKAHEAD) stays in flight if the live generator's opcodes were
+        all consumed (the caller is about to ask for a generator: maybe this one); otherwise it is undone here."""
         p = self._pending
         self._pending = None
         if p is not None:
             self._ops_done += p["consumed"]
-        if p is not None and p["consumed"] < p["produced"]:
-            # abandoned mid-chunk: restore the snapshot and replay only what was consumed
-            self._enc.rollback()
+        partial = p is not None and p["consumed"] < p["produced"]
+        a = self._ahead
+        if a is not None and (partial or download or not keep_ahead):
+            self._ahead = None
+            self.lookahead_stats["undone"] += 1
+            if not partial:
+                # back to the state behind the live generator's opcodes (what self._vb describes, if it is fresh)
+                self._enc.rollback(a["slot"])
+                self._host_current = False
+        if partial:
+            # abandoned mid-chunk: restore the snapshot and replay only what was consumed (a look-ahead behind it goes with it)
+            self._enc.rollback(p["slot"])
             self._host_current = False
             self._brief_fresh = False   # (what travelled behind the launch describes all of its opcodes)
             if p["consumed"]:
@@ -392,7 +473,7 @@ class Video:
         """
         if is_aux and self._aux_memory_map is None:
             raise AttributeError("aux_memory_map")  # as the reference's HGR Video (video.py:79-80)
-        self._settle(download=False)
+        self._settle(download=False, keep_ahead=True)
         if self._host_current:
             memory_map = self._aux_memory_map if is_aux else self._memory_map
             update_priority = self._aux_update_priority if is_aux else self._update_priority
@@ -439,7 +520,19 @@ class Video:
                     raise RuntimeError("this encode_frame() generator cannot be resumed: another generator "
                                        "has run on this Video since (the reference's heap is not kept)")
                 prev_live = self._live
-                if restart or self._pending is not None:
+                adopt = None
+                if restart and self._ahead is not None:
+                    # is this the generator that was enqueued ahead?  Same bank, same target bytes, the live generator's
+                    # opcodes all consumed, nothing touched, nobody drew from the global generators since
+                    a = self._ahead
+                    ok = (paced and not self._touched and not self.STRICT_SYNC and a["is_aux"] == token.is_aux
+                          and (self._pending is None or self._pending["consumed"] == self._pending["produced"])
+                          and np.array_equal(a["main"], token.main)
+                          and (token.aux is None or np.array_equal(a["aux"], token.aux)) and not self._global_rng_moved())
+                    self._settle(download=False, keep_ahead=ok)
+                    if ok and self._ahead is a:
+                        adopt, self._ahead = a, None
+                elif restart or self._pending is not None or self._ahead is not None:
                     self._settle(download=False)  # the previous generator's speculation ends here
                 if self._touched or self.STRICT_SYNC:
                     self._settle()
@@ -460,16 +553,23 @@ class Video:
                     if token.aux is not None and (self._up_aux is None or not np.array_equal(self._up_aux, token.aux)):
                         self._dev_aux.copy_(torch.from_numpy(token.aux))
                         self._up_aux = token.aux
+                slot = 0
                 if speculative:
-                    self._enc.snapshot()
                     try:
-                        ops = self._launch(token, restart, chunk)
+                        if adopt is not None:
+                            slot = adopt["slot"]
+                            ops = self._adopt(adopt)
+                            chunk = len(ops)
+                        else:
+                            self._enc.snapshot(slot)
+                            ops = self._launch(token, restart, chunk)
                     except native.IIVAssertionError:
                         # one of the reference's asserts fires somewhere in this chunk -- maybe past
                         # what the caller will pull: step exactly from here on, so that it is raised
                         # by the next() that would raise it in the reference
-                        self._enc.rollback()
+                        self._enc.rollback(slot)
                         self._host_current = False
+                        self._brief_fresh = False
                         speculative, chunk = False, 1
                         continue
                 else:
@@ -480,8 +580,10 @@ class Video:
                     self._download()
                 rec = None
                 if speculative:
-                    rec = dict(token=token, restart=restart, consumed=0, produced=len(ops), prev_live=prev_live)
+                    rec = dict(token=token, restart=restart, consumed=0, produced=len(ops), prev_live=prev_live, slot=slot)
                     self._pending = rec
+                    if paced and self.LOOKAHEAD and self.mode == VideoMode.DHGR:
+                        self._look_ahead(token, len(ops), 1 - slot)
                 rows = ops.tolist()  # plain ints, converted once per chunk
                 for k in range(len(rows)):
                     if rec is not None:

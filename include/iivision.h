@@ -322,6 +322,12 @@ int iiv_encoder_get_video_brief_async(iiv_encoder *enc, int stream_index, iiv_vi
  * the computation is deterministic. */
 int iiv_encoder_snapshot(iiv_encoder *enc, void *stream);
 int iiv_encoder_rollback(iiv_encoder *enc, void *stream);
+/* The same with two slots (0: the one the calls above use; 1).  The drop-in Video (transcoder/video.py) runs one generator
+ * AHEAD of its caller: behind the launch of generator k it enqueues the generator movie.py:139-148 will ask for next -- the
+ * other bank of the same frame -- and needs the state in front of generator k (its caller may abandon k half way:
+ * video.py:72-93) and the state in front of generator k + 1 (the guess may be wrong) at the same time. */
+int iiv_encoder_snapshot_slot(iiv_encoder *enc, int slot, void *stream);
+int iiv_encoder_rollback_slot(iiv_encoder *enc, int slot, void *stream);
 
 /* One segment = what movie.py does between two generator creations:
  * `op_seq = video.encode_frame(target, is_aux)` (if restart) followed by n_ops

@@ -450,3 +450,8 @@ def test_movie_paced_generators_are_single_launches(O, oracle_tables, mode, n_fr
     assert (np.array(got, np.uint8) == np.concatenate(want)).all()
     assert calls["rollback"] == 0, calls
     assert calls["encode"] == len(segs), (calls, len(segs))
+    # DHGR: the generator behind every bank flip inside a frame was enqueued ahead of the caller (Video.LOOKAHEAD), every
+    # one of them was the one the caller then asked for, none had to be undone
+    st = v.lookahead_stats
+    n_flips = sum(1 for j in range(1, len(segs)) if segs[j][0] == segs[j - 1][0])
+    assert st["undone"] == 0 and st["adopted"] == st["launched"] == (n_flips if mode else 0), (st, n_flips)
