@@ -355,6 +355,8 @@ int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, c
             if ((rc = hip_check(hipMalloc(&e->d_perm, sizeof(int) * (size_t)n_streams), "hipMalloc(stream order)"))) break;
         }
         if ((rc = hip_check(hipMalloc(&e->d_packed, 4096 * 8), "hipMalloc(packed)"))) break;
+        // (the brief's staging struct: here, not on first use -- an allocation inside the asynchronous entry point would synchronise)
+        if ((rc = hip_check(hipMalloc(&e->d_brief, sizeof(iiv_video_brief)), "hipMalloc(brief)"))) break;
         if ((rc = hip_check(hipEventCreateWithFlags(&e->seg_ev[0], hipEventDisableTiming), "event"))) break;
         if ((rc = hip_check(hipEventCreateWithFlags(&e->seg_ev[1], hipEventDisableTiming), "event"))) break;
         if ((rc = hip_check(hipMalloc(&e->d_tie_stats, 3 * sizeof(unsigned long long)), "hipMalloc(tie statistics)"))) break;

@@ -686,7 +686,11 @@ def frames_to_memory_maps(mode, palette_rgb, rgb, dither=0, out=None):
     dither: 0..255 = amplitude of the 4x4 ordered dither, DITHER_DIFFUSION = error diffusion.
     out=(main, aux): write into these contiguous CUDA uint8 tensors of n * 8192 bytes each (any shape; aux ignored
     for HGR) instead of allocating -- e.g. a (streams, frames, 32, 256) slice of a batch's target frames.
-    Asynchronous on torch's current stream."""
+    Asynchronous on torch's current stream (since round 5; it used to synchronise): `rgb` and the `out` tensors must stay
+    alive and untouched until that stream has reached this call.  Tensors allocated and used on the same current stream are
+    safe as they are (the caching allocator re-uses a freed block on that stream only behind its pending work); tensors
+    that belong to ANOTHER stream -- a conversion on a side stream writing into the encoder's target buffers, as bench.py's
+    e2e leg does -- need tensor.record_stream(torch.cuda.current_stream()) or an event between the streams."""
     torch = _torch()
     if not (rgb.is_cuda and rgb.dtype == torch.uint8 and rgb.dim() == 4 and tuple(rgb.shape[1:]) == (192, 280, 3) and rgb.is_contiguous()):
         raise ValueError("rgb must be a contiguous CUDA uint8 tensor (n, 192, 280, 3)")

@@ -54,23 +54,60 @@ import screen
 from palette import Palette
 from video_mode import VideoMode
 
-_np_global = [None, None]
+_np_global = [None, None]   # [the bit generator the address below belongs to, that address or 0 = "use get_state / set_state"]
 
 
 def _np_rng_addr():
     """Address of the process-wide np.random MT19937 state -- key[624] (u32) then pos (i32), the words np.random.get_state()
     reports -- through numpy's own ctypes interface (BitGenerator.ctypes.state_address): reading and writing 2500 bytes there
-    costs under a microsecond where get_state() / set_state() cost ~50 each, twice per generator."""
+    costs under a microsecond where get_state() / set_state() cost ~50 each, twice per generator.  The layout is numpy's
+    private business (mt19937_state: uint32 key[624]; int pos), so the address is believed only after the bytes there have
+    been seen to BE what get_state() reports, before and after a draw that moves the position; if they are not, 0 is
+    returned and this module goes through get_state() / set_state() (slower, same results)."""
     bg = np.random.mtrand._rand._bit_generator
     if _np_global[0] is not bg:
         if type(bg).__name__ != "MT19937":
             raise RuntimeError("np.random's global generator is not the MT19937 the reference draws from")
-        _np_global[0], _np_global[1] = bg, int(bg.ctypes.state_address)
+        addr = 0
+        try:
+            cand = int(bg.ctypes.state_address)
+
+            def same():
+                _, key, pos = np.random.get_state()[:3]
+                raw = np.frombuffer(ctypes.string_at(cand, 2500), dtype=np.uint32)
+                return bool(np.array_equal(raw[:624], np.asarray(key, dtype=np.uint32)) and int(raw[624]) == int(pos))
+            saved = np.random.get_state()
+            ok = same()
+            np.random.random_sample()           # (moves pos, or refills the block)
+            ok = ok and same()
+            np.random.set_state(saved)          # (the caller's stream is where it was)
+            if ok and same():
+                addr = cand
+        except Exception:
+            addr = 0
+        _np_global[0], _np_global[1] = bg, addr
     return _np_global[1]
 
 
 def _np_rng_raw():
-    return ctypes.string_at(_np_rng_addr(), 2500)
+    """np.random's MT19937 words as 2500 bytes: key[624], pos"""
+    addr = _np_rng_addr()
+    if addr:
+        return ctypes.string_at(addr, 2500)
+    _, key, pos = np.random.get_state()[:3]
+    return np.asarray(key, dtype=np.uint32).tobytes() + np.array([pos], dtype=np.int32).tobytes()
+
+
+def _np_rng_write(words):
+    """the 625 words (ctypes array / buffer of 2500 bytes) become np.random's MT19937 state; has_gauss / cached_gaussian stay the caller's"""
+    addr = _np_rng_addr()
+    if addr:
+        with np.random.mtrand._rand._bit_generator.lock:   # (the generator's own lock: nobody draws while the words change)
+            ctypes.memmove(addr, words, 2500)
+        return
+    w = np.frombuffer(bytes(words), dtype=np.uint32)
+    old = np.random.get_state()
+    np.random.set_state((old[0], w[:624].copy(), int(w[624].astype(np.int32) if hasattr(w[624], "astype") else w[624]), old[3], old[4]))
 
 
 class Video:
@@ -311,7 +348,7 @@ class Video:
         """the device's random / np.random positions (st.rng_py, st.rng_np) become the process's"""
         py = tuple(np.frombuffer(st.rng_py, dtype=np.uint32).tolist())
         random.setstate((3, py, None))
-        ctypes.memmove(_np_rng_addr(), st.rng_np, 2500)   # (has_gauss / cached_gaussian are the caller's: untouched)
+        _np_rng_write(st.rng_np)
         self._rng_seen = (py, bytes(st.rng_np))
 
     def _global_rng_moved(self):

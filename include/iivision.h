@@ -312,7 +312,11 @@ typedef struct iiv_video_brief {
 int iiv_encoder_get_video_brief(iiv_encoder *enc, int stream_index, iiv_video_brief *host_out);
 /* The same, enqueued on `stream` behind the launches already there (an iiv_encode of a generator's opcodes: the brief then
  * describes the state after them): nothing waits; *host_out is complete once the stream has been synchronised
- * (iiv_encoder_check does).  host_out should be pinned memory. */
+ * (iiv_encoder_check does).  host_out should be pinned memory.
+ * Every brief of one encoder is assembled in ONE device staging struct before it is copied out: all (a)synchronous brief
+ * calls of an encoder must therefore be enqueued on one stream (stream order then keeps a later brief from overwriting
+ * one whose copy is still in flight) -- the same stream its iiv_encode calls use: an encoder is a one-stream object
+ * (see iiv_encoder_create). */
 int iiv_encoder_get_video_brief_async(iiv_encoder *enc, int stream_index, iiv_video_brief *host_out, void *stream);
 
 /* Copy / restore the complete state of every stream (screen, priorities, live

@@ -169,7 +169,8 @@ def main():
             "wait_any_frac_of_wave_cycles": (per_dispatch(k, "SQ_WAIT_ANY") / per_dispatch(k, "SQ_WAVE_CYCLES")) if per_dispatch(k, "SQ_WAVE_CYCLES") and per_dispatch(k, "SQ_WAIT_ANY") is not None else None,
             "clock_hz_assumed": 2.4e9,
         }
-    latest_path = os.path.join(out, "pmc_latest.json")
+    # (IIV_PMC_LATEST_OUT: one file that several runs -- DHGR, HGR, S-img -- merge their entries into: tools/round_evidence.sh)
+    latest_path = os.environ.get("IIV_PMC_LATEST_OUT") or os.path.join(out, "pmc_latest.json")
     bid = build_id()
     try:
         latest = json.load(open(latest_path))
