@@ -473,8 +473,6 @@ int encoder_set_option(Encoder *e, int option, int value)
         if (value != IIV_CONTENT_TARGET && !e->d_left)
             return set_error(IIV_ERR_INVALID, "the joint content choice reads the split store table, which is built "
                                                "from dm (none was given at creation)");
-        if (value != IIV_CONTENT_TARGET && e->fourth_offset)
-            return set_error(IIV_ERR_INVALID, "the joint content choice and the fourth offset are not implemented together");
         // (a store table that the narrow form does not reproduce -- not the one dm yields -- leaves only the split-table form)
         if (value == IIV_CONTENT_JOINT && !e->nt.exact) value = IIV_CONTENT_JOINT_SPLIT;
         if (value == IIV_CONTENT_JOINT && !e->d_joint_l) {
@@ -497,8 +495,6 @@ int encoder_set_option(Encoder *e, int option, int value)
         if (value && (!e->d_left || !e->nt.exact))
             return set_error(IIV_ERR_INVALID, "the fourth offset runs in the one-wave kernel, which reads the split store table "
                                                "built from dm (none was given at creation, or it does not reproduce the store table given)");
-        if (value && e->content_choice != IIV_CONTENT_TARGET)
-            return set_error(IIV_ERR_INVALID, "the joint content choice and the fourth offset are not implemented together");
         e->fourth_offset = value;
         return IIV_OK;
     }
@@ -970,7 +966,9 @@ static int launch_round(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux,
     // (f4's fourth offset: in the plain one-wave kernel only, whatever the kernel option says)
     // (e->nt.exact: the folded narrow form reproduced every entry of the caller's store table at creation -- always so for
     // tables built from the same dm; otherwise the dense-table workgroup kernel runs)
-    const bool use_wave = e->fourth_offset || (e->d_left && e->nt.exact && e->greedy_mode != IIV_GREEDY_WORKGROUP && e->content_choice == IIV_CONTENT_TARGET);
+    // (round 6: together with the joint content choice the fourth offset runs in the workgroup kernel, the joint choice's home)
+    const bool use_wave = e->content_choice == IIV_CONTENT_TARGET &&
+                          (e->fourth_offset || (e->d_left && e->nt.exact && e->greedy_mode != IIV_GREEDY_WORKGROUP));
     // few streams: a team of eight waves per stream scores the next entries of the list
     // concurrently (iiv_team.hip); from ~900 streams on, one wave per stream fills the GPU
     const bool use_team = use_wave && (e->greedy_mode == IIV_GREEDY_TEAM ||
@@ -1002,7 +1000,7 @@ static int launch_round(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux,
         const bool packed = e->content_choice == IIV_CONTENT_JOINT;
         const WorkgroupArgs wa{e->d_states, d_main, d_aux, n_frames, e->n_streams, d_round, seg_stride, e->d_store,
                                packed ? e->d_joint_l : e->d_left_t, packed ? e->d_joint_r : e->d_right_t, d_ops, ops_stride};
-        int wrc = launch_greedy_workgroup(e->mode, packed ? 2 : e->content_choice == IIV_CONTENT_JOINT_SPLIT ? 1 : 0, wa, st);
+        int wrc = launch_greedy_workgroup(e->mode, packed ? 2 : e->content_choice == IIV_CONTENT_JOINT_SPLIT ? 1 : 0, e->fourth_offset != 0, wa, st);
         if (wrc) return wrc;
         if (e->profiling) e->form_launches[3]++;
     }

@@ -493,6 +493,7 @@ struct WorkgroupArgs {
     size_t ops_stride;
 };
 // joint: 0 = the reference's content byte, 1 / 2 = the joint content choice scored from the split table / from the packed narrow form
-int launch_greedy_workgroup(int mode, int joint, const WorkgroupArgs &a, hipStream_t st);
+// fourth (with joint != 0 only): IIV_OPT_FOURTH_OFFSET together with the joint choice -- three extra offsets per opcode
+int launch_greedy_workgroup(int mode, int joint, bool fourth, const WorkgroupArgs &a, hipStream_t st);
 
 }  // namespace iiv

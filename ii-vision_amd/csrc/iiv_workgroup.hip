@@ -23,7 +23,10 @@ constexpr int kChunk = 8;  // initial-list entries whose store-table rows are ga
 // word (iiv_tables.hip: joint_pack_kernel) with packed 16-bit arithmetic -- two loads and five vector instructions per
 // byte of the page and PAIR of byte values; JOINT == 1: from the two-component split table, one byte value at a time
 // (round 2's form, kept as the independent second implementation: IIV_CONTENT_JOINT_SPLIT).
-template <int MODE, int JOINT>
+// FOUR (round 6, joint choice only: IIV_OPT_FOURTH_OFFSET together with IIV_CONTENT_JOINT): up to three extra offsets per
+// opcode; the joint score of a byte value then takes its THREE smallest negative deltas (oracle/iiv_oracle.c:
+// choose_content_joint).  Without the joint choice the fourth offset runs in the one-wave / team kernels.
+template <int MODE, int JOINT, bool FOUR = false>
 __global__ __launch_bounds__(256, JOINT ? 5 : 1) void greedy_kernel(StreamState *__restrict__ states,
                                                      const uint8_t *__restrict__ frames_main,
                                                      const uint8_t *__restrict__ frames_aux, int n_frames,
@@ -50,10 +53,11 @@ __global__ __launch_bounds__(256, JOINT ? 5 : 1) void greedy_kernel(StreamState 
     __shared__ __attribute__((aligned(16))) uint16_t dwf[8192];     // diff_weight | (priority != 0) << 15
     __shared__ uint32_t mt[2][624];
     __shared__ uint32_t xw_cnt[4];
-    __shared__ uint32_t xw_key[8];
+    __shared__ uint32_t xw_key[12];
     __shared__ unsigned long long xw_pop[4];
     __shared__ int xw_joint[4];
     __shared__ uint32_t xw_m12[JOINT ? 4 : 1][JOINT ? (1 << ModeTraits<MODE>::kContentBits) : 1];
+    __shared__ uint16_t xw_m3[(JOINT && FOUR) ? 4 : 1][(JOINT && FOUR) ? (1 << ModeTraits<MODE>::kContentBits) : 1];
     constexpr int CH = JOINT ? 1 : kChunk;  // (a joint step knows its content only after scoring every value)
 
     const int tid = threadIdx.x;
@@ -248,7 +252,9 @@ __global__ __launch_bounds__(256, JOINT ? 5 : 1) void greedy_kernel(StreamState 
 #pragma unroll
                 for (int j = 0; j < NP; j++) nd[j] = __builtin_bit_cast(v2s, lrow[64 * j]) + __builtin_bit_cast(v2s, rrow[64 * j]);
             };
-            int m1[NS], m2[NS];  // per byte value: the two smallest negative deltas (m1 <= m2 <= 0)
+            int m1[NS], m2[NS], m3[NS];  // per byte value: the two (FOUR: three) smallest negative deltas (m1 <= m2 <= m3 <= 0)
+#pragma unroll
+            for (int j = 0; j < NS; j++) m3[j] = 0;
             if constexpr (JOINT == 2) {
                 // per lane, once per step: where the rows of its byte of the quarter start (byte offsets into the two packed
                 // tables) and its diff weight plus the bias of the sums -- a trip then needs three v_readlane per byte and no
@@ -259,9 +265,9 @@ __global__ __launch_bounds__(256, JOINT ? 5 : 1) void greedy_kernel(StreamState 
                 const int db_m = dw_m + (int)kNarrowBias;   // (diff weights are < 2^12: iiv_stream.h, kWdDwShift)
                 const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc((void *)left_t, 0, (int)(joint_left_entries<MODE>() * 4), 0x00020000);
                 const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)right_t, 0, (int)(joint_right_entries<MODE>() * 4), 0x00020000);
-                v2s q1[NP], q2[NP];
+                v2s q1[NP], q2[NP], q3[NP];
 #pragma unroll
-                for (int j = 0; j < NP; j++) q1[j] = q2[j] = v2s{0, 0};
+                for (int j = 0; j < NP; j++) q1[j] = q2[j] = q3[j] = v2s{0, 0};
 #ifndef IIV_JOINT_U
 #define IIV_JOINT_U 8
 #endif
@@ -283,7 +289,13 @@ __global__ __launch_bounds__(256, JOINT ? 5 : 1) void greedy_kernel(StreamState 
                             const v2s d = nd[u][j] - bb;
                             const v2s lo2 = __builtin_elementwise_min(d, q1[j]), hi2 = __builtin_elementwise_max(d, q1[j]);
                             q1[j] = lo2;
-                            q2[j] = __builtin_elementwise_min(hi2, q2[j]);
+                            if constexpr (FOUR) {
+                                const v2s hi3 = __builtin_elementwise_max(hi2, q2[j]);
+                                q2[j] = __builtin_elementwise_min(hi2, q2[j]);
+                                q3[j] = __builtin_elementwise_min(hi3, q3[j]);
+                            } else {
+                                q2[j] = __builtin_elementwise_min(hi2, q2[j]);
+                            }
                         }
                     }
                 };
@@ -312,6 +324,7 @@ __global__ __launch_bounds__(256, JOINT ? 5 : 1) void greedy_kernel(StreamState 
                 for (int j = 0; j < NP; j++) {
                     m1[2 * j] = q1[j].x, m1[2 * j + 1] = q1[j].y;
                     m2[2 * j] = q2[j].x, m2[2 * j + 1] = q2[j].y;
+                    m3[2 * j] = q3[j].x, m3[2 * j + 1] = q3[j].y;
                 }
             } else {
 #pragma unroll
@@ -346,12 +359,19 @@ __global__ __launch_bounds__(256, JOINT ? 5 : 1) void greedy_kernel(StreamState 
                         const int d = nd[u][j] - dws[u];
                         const int lo = d < m1[j] ? d : m1[j], hi = d < m1[j] ? m1[j] : d;
                         m1[j] = lo;
+                        if constexpr (FOUR) {
+                            const int hi3 = hi < m2[j] ? m2[j] : hi;
+                            m3[j] = hi3 < m3[j] ? hi3 : m3[j];
+                        }
                         m2[j] = hi < m2[j] ? hi : m2[j];
                     }
             }
             }
 #pragma unroll
-            for (int j = 0; j < NS; j++) xw_m12[wave][lane + 64 * j] = (uint32_t)(uint16_t)m1[j] | ((uint32_t)(uint16_t)m2[j] << 16);
+            for (int j = 0; j < NS; j++) {
+                xw_m12[wave][lane + 64 * j] = (uint32_t)(uint16_t)m1[j] | ((uint32_t)(uint16_t)m2[j] << 16);
+                if constexpr (FOUR) xw_m3[wave][lane + 64 * j] = (uint16_t)m3[j];
+            }
             // the primary's own byte (uniform)
             const uint32_t winx = __builtin_amdgcn_readfirstlane(__shfl(win_m, x & 63, 64));  // valid in wave x >> 6 only
             if (wave == (x >> 6) && lane == 0) xw_joint[0] = (int)winx;
@@ -372,18 +392,33 @@ __global__ __launch_bounds__(256, JOINT ? 5 : 1) void greedy_kernel(StreamState 
             int best = -2147483647 - 1;
 #pragma unroll
             for (int j = 0; j < NS; j++) {
-                int a1 = 0, a2 = 0;
+                int a1 = 0, a2 = 0, a3 = 0;
+                // (a value goes into the sorted triple a1 <= a2 <= a3: five minima / maxima; the fourth-offset form merges the
+                // waves' triples that way, the reference form their pairs as before)
+                auto put = [&](int b) {
+                    const int lo = b < a1 ? b : a1, hi = b < a1 ? a1 : b;
+                    a1 = lo;
+                    const int lo2 = hi < a2 ? hi : a2, hi2 = hi < a2 ? a2 : hi;
+                    a2 = lo2;
+                    a3 = hi2 < a3 ? hi2 : a3;
+                };
 #pragma unroll
                 for (int w = 0; w < 4; w++) {
                     const uint32_t v = xw_m12[w][lane + 64 * j];
                     const int b1 = (int)(int16_t)(v & 0xffffu), b2 = (int)(int16_t)(v >> 16);
-                    const int lo = b1 < a1 ? b1 : a1, hi = b1 < a1 ? a1 : b1;
-                    a1 = lo;
-                    a2 = hi < a2 ? hi : a2;
-                    a2 = b2 < a2 ? b2 : a2;
+                    if constexpr (FOUR) {
+                        put(b1);
+                        put(b2);
+                        put((int)(int16_t)xw_m3[w][lane + 64 * j]);
+                    } else {
+                        const int lo = b1 < a1 ? b1 : a1, hi = b1 < a1 ? a1 : b1;
+                        a1 = lo;
+                        a2 = hi < a2 ? hi : a2;
+                        a2 = b2 < a2 ? b2 : a2;
+                    }
                 }
                 const int c = lane + 64 * j;
-                const int key = (dwx - ndx[j] - a1 - a2) * 512 + ((uint32_t)c == tc ? 256 : 0) + (255 - c);
+                const int key = (dwx - ndx[j] - a1 - a2 - (FOUR ? a3 : 0)) * 512 + ((uint32_t)c == tc ? 256 : 0) + (255 - c);
                 best = key > best ? key : best;
             }
             best = -wave_min_i32(-best);
@@ -453,36 +488,50 @@ __global__ __launch_bounds__(256, JOINT ? 5 : 1) void greedy_kernel(StreamState 
                 if (nzy)  // video.py:159
                     key = ((uint32_t)(d + 2048) << 17) | (nonce << 9) | ((uint32_t)y << 1) | (nd != 0 ? 1u : 0u);
             }
-            uint32_t k1 = key, k2 = INF;
+            uint32_t k1 = key, k2 = INF, k3 = INF;
 #pragma unroll
             for (int s = 1; s < 64; s <<= 1) {
                 uint32_t o1 = __shfl_xor(k1, s, 64), o2 = __shfl_xor(k2, s, 64);
                 uint32_t lo = k1 < o1 ? k1 : o1, hi = k1 < o1 ? o1 : k1;
                 uint32_t m2 = k2 < o2 ? k2 : o2;
+                if constexpr (FOUR) {   // third of the two sorted triples: the smallest of what is left behind the first two
+                    const uint32_t o3 = __shfl_xor(k3, s, 64);
+                    const uint32_t M2 = k2 < o2 ? o2 : k2, r = hi < m2 ? m2 : hi, m3 = k3 < o3 ? k3 : o3;
+                    const uint32_t t = r < M2 ? r : M2;
+                    k3 = t < m3 ? t : m3;
+                }
                 k1 = lo;
                 k2 = hi < m2 ? hi : m2;
             }
             if (lane == 0) {
-                xw_key[2 * wave] = k1;
-                xw_key[2 * wave + 1] = k2;
+                xw_key[3 * wave] = k1;
+                xw_key[3 * wave + 1] = k2;
+                xw_key[3 * wave + 2] = FOUR ? k3 : INF;
             }
             __syncthreads();
-            uint32_t K1 = INF, K2 = INF;
+            uint32_t K1 = INF, K2 = INF, K3 = INF;
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
+            for (int q = 0; q < 12; q++) {
                 uint32_t k = xw_key[q];
                 if (k < K1) {
+                    K3 = K2;
                     K2 = K1;
                     K1 = k;
                 } else if (k < K2) {
+                    K3 = K2;
                     K2 = k;
+                } else if (k < K3) {
+                    K3 = k;
                 }
             }
+            if (!FOUR) K3 = INF;
             const int y1 = K1 != INF ? (int)((K1 >> 1) & 255) : -1;
             const int f1 = K1 != INF ? (int)(K1 & 1) : 0;
             const int y2 = K2 != INF ? (int)((K2 >> 1) & 255) : -1;
             const int f2 = K2 != INF ? (int)(K2 & 1) : 0;
-            if (n_pushed + f1 + f2 > kPushedCap) {
+            const int y3 = K3 != INF ? (int)((K3 >> 1) & 255) : -1;
+            const int f3 = K3 != INF ? (int)(K3 & 1) : 0;
+            if (n_pushed + f1 + f2 + f3 > kPushedCap) {
                 err = kErrPushedOverflow;
                 break;
             }
@@ -496,16 +545,16 @@ __global__ __launch_bounds__(256, JOINT ? 5 : 1) void greedy_kernel(StreamState 
                 S.up16[is_aux][p * 256 + x] = JOINT ? (uint16_t)joint_res : (uint16_t)0;   // (store values are <= 2047: the 16-bit copy)
                 S.mem[is_aux][p * 256 + x] = (uint8_t)c;
             }
-            if (y == y1 || y == y2) {
-                const int second = (y == y2) ? 1 : 0;
+            if (y == y1 || y == y2 || y == y3) {
+                const int before = (y == y2) ? f1 : (y == y3) ? f1 + f2 : 0;   // re-queued entries of this step in front of this one
                 S.up16[is_aux][p * 256 + y] = (uint16_t)nd;  // byte_pair_difference == nd[y] (screen.py:383-398)
                 S.mem[is_aux][p * 256 + y] = (uint8_t)c;
                 dwf[p * 256 + y] = (uint16_t)((w & 0x7fffu) | (nd ? 0x8000u : 0u));
                 if (nd) {
-                    int j = mt_idx + C + (second ? f1 : 0);
+                    int j = mt_idx + C + before;
                     uint32_t word = j < 624 ? mt[cb][j] : mt[cb ^ 1][j - 624];
                     uint32_t nonce = mt_temper(word) >> 24;  // video.py:178
-                    S.pushed[n_pushed + (second ? f1 : 0)] =
+                    S.pushed[n_pushed + before] =
                         ((2047u - nd) << 21) | (nonce << 13) | ((uint32_t)p << 8) | (uint32_t)y;
                 }
             }
@@ -516,7 +565,7 @@ __global__ __launch_bounds__(256, JOINT ? 5 : 1) void greedy_kernel(StreamState 
                 q[2] = (uint8_t)x;
                 q[3] = (uint8_t)(y1 >= 0 ? y1 : x);  // video.py:185-186
                 q[4] = (uint8_t)(y2 >= 0 ? y2 : x);
-                q[5] = (uint8_t)x;
+                q[5] = (uint8_t)(y3 >= 0 ? y3 : x);   // (FOUR only: y3 is -1 otherwise)
             }
             // later chunk entries that this step resolved exactly are now dead
 #pragma unroll
@@ -524,10 +573,11 @@ __global__ __launch_bounds__(256, JOINT ? 5 : 1) void greedy_kernel(StreamState 
                 if (m2 > m && m2 < cnt) {
                     if (y1 >= 0 && !f1 && ent[m2] == (uint32_t)((p << 8) | y1)) dead |= 1u << m2;
                     if (y2 >= 0 && !f2 && ent[m2] == (uint32_t)((p << 8) | y2)) dead |= 1u << m2;
+                    if (y3 >= 0 && !f3 && ent[m2] == (uint32_t)((p << 8) | y3)) dead |= 1u << m2;
                 }
-            mt_idx += C + f1 + f2;
-            draws += (unsigned long long)(C + f1 + f2);
-            n_pushed += f1 + f2;
+            mt_idx += C + f1 + f2 + f3;
+            draws += (unsigned long long)(C + f1 + f2 + f3);
+            n_pushed += f1 + f2 + f3;
             done++;
             if (!from_pushed) head = pos[m] + 1;
             if (mt_idx >= 624) {
@@ -566,12 +616,16 @@ __global__ __launch_bounds__(256, JOINT ? 5 : 1) void greedy_kernel(StreamState 
         if (err && S.error == 0) S.error = err;
     }
 }
-int launch_greedy_workgroup(int mode, int joint, const WorkgroupArgs &a, hipStream_t st)
+int launch_greedy_workgroup(int mode, int joint, bool fourth, const WorkgroupArgs &a, hipStream_t st)
 {
 #define IIV_GREEDY(K)                                                                                                     \
     hipLaunchKernelGGL(K, dim3(a.n_streams), dim3(256), 0, st, a.states, a.frames_main, a.frames_aux, a.n_frames, a.segs, \
                        a.seg_stride, a.store, a.left_t, a.right_t, a.ops_out, a.ops_stride)
-    if (joint == 2) {
+    if (joint == 2 && fourth) {
+        if (mode == kDHGR) IIV_GREEDY((greedy_kernel<kDHGR, 2, true>)); else IIV_GREEDY((greedy_kernel<kHGR, 2, true>));
+    } else if (joint && fourth) {
+        if (mode == kDHGR) IIV_GREEDY((greedy_kernel<kDHGR, 1, true>)); else IIV_GREEDY((greedy_kernel<kHGR, 1, true>));
+    } else if (joint == 2) {
         if (mode == kDHGR) IIV_GREEDY((greedy_kernel<kDHGR, 2>)); else IIV_GREEDY((greedy_kernel<kHGR, 2>));
     } else if (joint) {
         if (mode == kDHGR) IIV_GREEDY((greedy_kernel<kDHGR, 1>)); else IIV_GREEDY((greedy_kernel<kHGR, 1>));

@@ -254,7 +254,9 @@ void iiv_encoder_destroy(iiv_encoder *enc);
                                   * (orc_video_set_fourth_offset), which is pinned against the reference run with that one
                                   * literal changed (tests/golden/g8_fourth_offset.npz).  Runs in the one-wave greedy kernel (both
                                   * forms) and, for few streams, the eight-wave one (IIV_GREEDY_WORKGROUP falls back to the
-                                  * one-wave kernel; needs dm at creation); not together with IIV_CONTENT_JOINT. */
+                                  * one-wave kernel; needs dm at creation).  Together with IIV_CONTENT_JOINT (round 6): the
+                                  * joint score of a byte value then takes its THREE smallest deltas, and the step -- in the
+                                  * workgroup kernel, the joint choice's home -- hands out three extra offsets. */
 #define IIV_OPT_STREAM_ORDER 8   /* 1 (default) / 0: batches of 2048 streams and more launch the one-wave greedy kernel longest
                                   * stream first -- every stream's shader clocks of a launch are recorded, and every fourth
                                   * launch the streams are sorted by them (a launch ends when its slowest stream does: on

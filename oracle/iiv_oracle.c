@@ -936,6 +936,8 @@ static void emit_pad(orc_video *v, uint8_t *out)
  *         accounting; on the screen itself a single step may, a frame of them does not.
  *   :140  update_priority[page, offset] = nd_c[primary], the error the chosen byte leaves
  *         (0 when c is the target byte); it is not re-queued -- the next generator sees it.
+ * Together with the fourth-offset flag (orc_video_set_fourth_offset) an opcode has three extra offsets, so R(c) takes
+ * the THREE smallest negative deltas: R(c) = (dw[primary] - nd_c[primary]) - (d1 + d2 + d3).
  * Everything else (candidate order, nonce draws, re-queueing of the extra offsets) is the
  * reference's, applied to the chosen byte. */
 static uint8_t choose_content_joint(orc_video *v, int page, int offset, int ia, int32_t *residual)
@@ -949,7 +951,7 @@ static uint8_t choose_content_joint(orc_video *v, int page, int offset, int ia, 
     int best_c = tc;
     int32_t best_res = 0;
     for (int c = 0; c < ncontent; c++) {
-        int32_t m1 = 0, m2 = 0, nd_primary = 0; /* m1 <= m2 <= 0: the two smallest negative deltas */
+        int32_t m1 = 0, m2 = 0, m3 = 0, nd_primary = 0; /* m1 <= m2 <= m3 <= 0: the smallest negative deltas */
         for (int y = 0; y < 256; y++) {
             int bo = orc_byte_offset(v->mode, y, ia);
             uint64_t t = orc_mask_and_shift(v->mode, row[y / 2], bo);
@@ -963,13 +965,17 @@ static uint8_t choose_content_joint(orc_video *v, int page, int offset, int ia, 
             if (d >= 0 || up[page * 256 + y] == 0)
                 continue;
             if (d < m1) {
+                m3 = m2;
                 m2 = m1;
                 m1 = d;
             } else if (d < m2) {
+                m3 = m2;
                 m2 = d;
+            } else if (d < m3) {
+                m3 = d;
             }
         }
-        int64_t r = (int64_t)v->dw[page * 256 + offset] - nd_primary - m1 - m2;
+        int64_t r = (int64_t)v->dw[page * 256 + offset] - nd_primary - m1 - m2 - (v->fourth ? m3 : 0);
         int64_t key = r * 512 + (c == tc ? 256 : 0) + (255 - c);
         if (key > best_key) {
             best_key = key;

@@ -64,8 +64,9 @@ for rnd in range(rounds):
         n = 2 if marathon else 3
         fm, fa = fm[:n], (fa[:n] if fa is not None else None)
         sched = [(f_, a_, r_, min(k_, 4200 if marathon else 90)) for (f_, a_, r_, k_) in sched[:5]]
-    # one round in five of the others: a real fourth offset per opcode (IIV_OPT_FOURTH_OFFSET), against the oracle's flag
-    fourth = bool(not joint and rng.random() < 0.2)
+    # one round in five: a real fourth offset per opcode (IIV_OPT_FOURTH_OFFSET), against the oracle's flag -- also together
+    # with the joint choice (round 6)
+    fourth = bool(rng.random() < 0.2)
     enc = native.Encoder(mode, dtab[key][0], dtab[key][1], n, dm=dms[pal])
     enc.set_content_choice("split" if joint and rng.random() < 0.3 else joint)   # (both implementations of the joint choice)
     enc.set_fourth_offset(fourth)

@@ -166,16 +166,15 @@ def test_team_kernel_to_exhaustion_on_picture_like_input(native, O, oracle_table
 
 
 def test_option_rules(native, device_tables):
-    """Off unless asked for; needs the split store table (dm); not together with the joint content choice."""
+    """Off unless asked for; needs the split store table (dm); together with the joint content choice since round 6, in
+    either order (tests/test_gpu_joint.py holds the pair to the oracle's definition)."""
     t, s = device_tables.get(1, 5)
     enc = native.Encoder(1, t, s, 1, dm=device_tables.dm[(1, 5)])
     enc.set_fourth_offset(True)
-    with pytest.raises(native.IIVError):
-        enc.set_content_choice(True)
+    enc.set_content_choice(True)
     enc.set_fourth_offset(False)
     enc.set_content_choice(True)
-    with pytest.raises(native.IIVError):
-        enc.set_fourth_offset(True)
+    enc.set_fourth_offset(True)
     enc.close()
     enc = native.Encoder(1, t, s, 1)          # no dm: workgroup kernel only
     with pytest.raises(native.IIVError):

@@ -12,12 +12,13 @@ from test_gpu_encode import _seed_states, _synth
 pytestmark = pytest.mark.gpu
 
 
-def _device(native, device_tables, mode, frames_list, sched, seeds, O, joint):
+def _device(native, device_tables, mode, frames_list, sched, seeds, O, joint, fourth=False):
     import torch
     t, s = device_tables.get(mode, 5)
     n = len(frames_list)
     enc = native.Encoder(mode, t, s, n, dm=device_tables.dm[(mode, 5)])
     enc.set_content_choice(joint)
+    enc.set_fourth_offset(fourth)
     fr = np.stack(frames_list)
     fm = torch.from_numpy(np.ascontiguousarray(fr[:, :, 0])).cuda()
     fa = torch.from_numpy(np.ascontiguousarray(fr[:, :, 1])).cuda() if mode == 1 else None
@@ -29,9 +30,10 @@ def _device(native, device_tables, mode, frames_list, sched, seeds, O, joint):
     return enc, ops.cpu().numpy()
 
 
-def _oracle(O, oracle_tables, mode, frames, sched, sp, sn, joint):
+def _oracle(O, oracle_tables, mode, frames, sched, sp, sn, joint, fourth=False):
     v = O.Video(mode, oracle_tables.get(mode, 5), seed_py=sp, seed_np=sn)
     v.set_joint(joint)
+    v.set_fourth_offset(fourth)
     out = []
     for fi, ia, n in sched:
         v.encode_frame(frames[fi, 0], frames[fi, 1] if mode == 1 else None, ia)
@@ -39,21 +41,26 @@ def _oracle(O, oracle_tables, mode, frames, sched, sp, sn, joint):
     return v, np.concatenate(out)
 
 
+@pytest.mark.parametrize("fourth", [False, True])
 @pytest.mark.parametrize("impl", [True, "split"])
 @pytest.mark.parametrize("mode", [1, 0])
-def test_joint_steps_equal_the_definition(native, O, oracle_tables, device_tables, mode, impl):
+def test_joint_steps_equal_the_definition(native, O, oracle_tables, device_tables, mode, impl, fourth):
     """Four streams (iid and coherent data), generators on both banks, a continued frame: opcodes,
     memory maps, priorities (the primary keeps its residual), packed screen and both RNG positions
     equal the oracle's joint run -- both implementations (packed 16-bit sums of the narrow form, IIV_CONTENT_JOINT;
-    the two-component split table one byte value at a time, IIV_CONTENT_JOINT_SPLIT)."""
+    the two-component split table one byte value at a time, IIV_CONTENT_JOINT_SPLIT), and (round 6) both together with
+    the fourth offset per opcode (IIV_OPT_FOURTH_OFFSET: the joint score then takes three deltas)."""
     n = 4
     sched = [(0, 0, 60), (0, 1 if mode == 1 else 0, 45), (1, 0, 70), (1, 1 if mode == 1 else 0, 1), (2, 0, 40)]
     frames = [_synth(mode, 3, 300 + i, coherent=(i % 2 == 1)) for i in range(n)]
     seeds = [(i + 5, 70 + i) for i in range(n)]
-    enc, got = _device(native, device_tables, mode, frames, sched, seeds, O, impl)
+    enc, got = _device(native, device_tables, mode, frames, sched, seeds, O, impl, fourth)
     differs_from_greedy = 0
+    if fourth:   # (the mode does hand out a fourth offset)
+        o = np.sort(got[0][:, 2:6], axis=1)
+        assert ((o[:, 1:] != o[:, :-1]).sum(axis=1) + 1).max() == 4
     for i in range(n):
-        v, exp = _oracle(O, oracle_tables, mode, frames[i], sched, *seeds[i], True)
+        v, exp = _oracle(O, oracle_tables, mode, frames[i], sched, *seeds[i], True, fourth)
         bad = np.nonzero((got[i] != exp).any(axis=1))[0]
         assert len(bad) == 0, "stream %d: first mismatch at op %d: got %s want %s" % (i, bad[0], got[i][bad[0]], exp[bad[0]])
         assert (enc.get_state(native.STATE_MEM_MAIN, i) == v.memory(0)).all()
@@ -64,7 +71,7 @@ def test_joint_steps_equal_the_definition(native, O, oracle_tables, device_table
         assert (enc.get_state(native.STATE_PACKED, i) == v.packed).all()
         cnt = enc.get_state(native.STATE_COUNTERS, i)
         assert (int(cnt[0]), int(cnt[1])) == v.draws()
-        _, greedy = _oracle(O, oracle_tables, mode, frames[i], sched, *seeds[i], False)
+        _, greedy = _oracle(O, oracle_tables, mode, frames[i], sched, *seeds[i], False, fourth)
         differs_from_greedy += int((greedy != exp).any())
     enc.close()
     assert differs_from_greedy == n          # the mode really does something else
@@ -107,8 +114,8 @@ def test_joint_leaves_less_error_per_opcode(native, O, device_tables, mode):
     assert 0.01 < gain < 0.2, gain
 
 
-@pytest.mark.parametrize("mode,ops,impl", [(1, 6000, True), (0, 4500, True), (1, 6000, "split")])
-def test_joint_runs_past_the_list_into_the_bag(native, O, oracle_tables, device_tables, mode, ops, impl):
+@pytest.mark.parametrize("mode,ops,impl,fourth", [(1, 6000, True, False), (0, 4500, True, False), (1, 6000, "split", False), (1, 5000, True, True), (0, 4000, "split", True)])
+def test_joint_runs_past_the_list_into_the_bag(native, O, oracle_tables, device_tables, mode, ops, impl, fourth):
     """A generator pulled far past its sorted list: the joint choice leaves a primary with a residual priority (it is not
     re-queued, video.py:140 with IIV_CONTENT_JOINT), so a stale bag entry of that location, pushed when it was an extra
     offset, finds it live when it is popped and the location is encoded again -- as the oracle's definition does.  (Until
@@ -119,9 +126,9 @@ def test_joint_runs_past_the_list_into_the_bag(native, O, oracle_tables, device_
     frames = [np.stack([fm[i].numpy(), fa[i].numpy() if fa is not None else np.zeros_like(fm[i].numpy())], axis=1) for i in range(n)]
     sched = [(0, 0, ops), (1, 0, 1500)]
     seeds = [(i + 3, i + 9) for i in range(n)]
-    enc, got = _device(native, device_tables, mode, frames, sched, seeds, O, impl)
+    enc, got = _device(native, device_tables, mode, frames, sched, seeds, O, impl, fourth)
     for i in range(n):
-        v, exp = _oracle(O, oracle_tables, mode, frames[i], sched, *seeds[i], True)
+        v, exp = _oracle(O, oracle_tables, mode, frames[i], sched, *seeds[i], True, fourth)
         bad = np.nonzero((got[i] != exp).any(axis=1))[0]
         assert len(bad) == 0, "stream %d: first mismatch at op %d: got %s want %s" % (i, bad[0], got[i][bad[0]], exp[bad[0]])
         assert (enc.get_state(native.STATE_UP_MAIN, i) == v.update_priority(0)).all()
