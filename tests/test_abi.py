@@ -71,3 +71,22 @@ def test_torch_custom_operators_are_registered_over_the_c_abi(native):
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError):
             torch.ops.iivision.cie2000_matrix(torch.zeros((16, 3), dtype=torch.uint8))
+
+
+def test_library_and_committed_counters_are_of_the_current_sources():
+    """The build id compiled into iiv_version() is a hash of csrc/, the headers and the flags (csrc/Makefile: BUILD_ID).  The
+    in-tree library must be a build of the sources as they stand, and every entry of profiles/pmc_latest.json -- the counter run
+    bench.py quotes -- must carry that id: a kernel (or header) change that is not followed by tools/round_evidence.sh would
+    otherwise leave bench.py printing `counters: "stale"` at the driver's end-of-round run."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    want = subprocess.run(["make", "-s", "-C", os.path.join(root, "ii-vision_amd", "csrc"), "build-id"],
+                          capture_output=True, text=True, check=True).stdout.strip()
+    assert len(want) == 12
+    import _iiv_native
+    assert _iiv_native.build_id() == want, "ii-vision_amd/libiivision.so is not a build of the current sources: run make -C ii-vision_amd/csrc"
+    with open(os.path.join(root, "profiles", "pmc_latest.json")) as f:
+        latest = json.load(f)
+    stale = {k: v.get("build_id") for k, v in latest.items() if v.get("build_id") != want}
+    assert not stale, "profiles/pmc_latest.json holds counter runs of another build %s (this one: %s): run tools/round_evidence.sh" % (stale, want)
