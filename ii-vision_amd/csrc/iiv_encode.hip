@@ -80,6 +80,10 @@ struct Encoder {
     int fourth_offset;      // IIV_OPT_FOURTH_OFFSET
     StreamState *d_states;
     StreamState *d_snapshot[2];  // iiv_encoder_snapshot copies (lazily allocated; slot 1: iiv_encoder_snapshot_slot)
+    // live hand-over (iiv_encode_live): two opcode queues in coherent host memory (lazily allocated), and the one / the tag
+    // the launches of the call in progress write to (NULL outside such a call)
+    unsigned long long *h_live[2], *live_now;
+    uint32_t live_tag;
     // generator bookkeeping: one entry while every stream has run the same schedule, else one per stream
     std::vector<GenState> gens, snap_gens[2];
     // launch descriptors: pinned staging ring -> device buffer, both grown on demand
@@ -256,8 +260,10 @@ void encoder_destroy(Encoder *e)
     if (e->d_perm) (void)hipFree(e->d_perm);
     if (e->d_packed) (void)hipFree(e->d_packed);
     if (e->d_states) (void)hipFree(e->d_states);
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < 2; k++) {
         if (e->d_snapshot[k]) (void)hipFree(e->d_snapshot[k]);
+        if (e->h_live[k]) (void)hipHostFree(e->h_live[k]);
+    }
     if (e->d_strings) (void)hipFree(e->d_strings);
     if (e->d_hgr_dots) (void)hipFree(e->d_hgr_dots);
     if (e->d_dw_pieces) (void)hipFree(e->d_dw_pieces);
@@ -308,6 +314,8 @@ int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, c
     e->d_joint_l = e->d_joint_r = nullptr;
     e->d_brief = nullptr;
     e->d_states = e->d_snapshot[0] = e->d_snapshot[1] = nullptr;
+    e->h_live[0] = e->h_live[1] = e->live_now = nullptr;
+    e->live_tag = 0;
     e->d_strings = nullptr;
     e->d_hgr_dots = nullptr;
     e->d_dw_pieces = nullptr;
@@ -942,6 +950,17 @@ static int tie_stats_request(Encoder *e, hipStream_t st)
     return IIV_OK;
 }
 
+// which greedy kernel an encoder's launches run (launch_round)
+static bool wave_kernels_run(const Encoder *e)
+{
+    return e->content_choice == IIV_CONTENT_TARGET &&
+           (e->fourth_offset || (e->d_left && e->nt.exact && e->greedy_mode != IIV_GREEDY_WORKGROUP));
+}
+static bool team_kernel_runs(const Encoder *e)
+{
+    return wave_kernels_run(e) && (e->greedy_mode == IIV_GREEDY_TEAM || (e->greedy_mode == IIV_GREEDY_AUTO && e->n_streams <= kTeamMaxStreams));
+}
+
 // launch round r: descriptors at d + r * round_stride, stream i reads entry i * seg_stride
 static int launch_round(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux, int n_frames, const LaunchSeg *d_round,
                         int seg_stride, bool any_prologue, bool any_greedy, int uniform_bank, int *d_queue, uint8_t *d_ops,
@@ -967,12 +986,10 @@ static int launch_round(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux,
     // (e->nt.exact: the folded narrow form reproduced every entry of the caller's store table at creation -- always so for
     // tables built from the same dm; otherwise the dense-table workgroup kernel runs)
     // (round 6: together with the joint content choice the fourth offset runs in the workgroup kernel, the joint choice's home)
-    const bool use_wave = e->content_choice == IIV_CONTENT_TARGET &&
-                          (e->fourth_offset || (e->d_left && e->nt.exact && e->greedy_mode != IIV_GREEDY_WORKGROUP));
+    const bool use_wave = wave_kernels_run(e);
     // few streams: a team of eight waves per stream scores the next entries of the list
     // concurrently (iiv_team.hip); from ~900 streams on, one wave per stream fills the GPU
-    const bool use_team = use_wave && (e->greedy_mode == IIV_GREEDY_TEAM ||
-                                       (e->greedy_mode == IIV_GREEDY_AUTO && e->n_streams <= kTeamMaxStreams));
+    const bool use_team = team_kernel_runs(e);
     if (use_wave) {
         // longest first: every kOrderEvery launches the streams are sorted by what their latest launch cost them (d_perm holds
         // the identity until the first sort)
@@ -993,10 +1010,16 @@ static int launch_round(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux,
                      d_queue, e->fourth_offset != 0, e->d_tie_stats != nullptr && tie_stats_wanted(e),
                      ordered ? e->d_perm : (const int *)nullptr, ordered ? e->d_cost : (uint32_t *)nullptr};
         int form = 0;   // what launch_greedy_wave ran: 0 plain, 1 LDS-shared (it needs one bank per round and the stream counter)
+        if (e->live_now) {
+            if (!use_team) return set_error(IIV_ERR_INVALID, "iiv_encode_live: this encoder's launches do not run the team kernel");
+            a.live = e->live_now;
+            a.live_tag = e->live_tag;
+        }
         int rc = use_team ? launch_greedy_team(e->mode, a, st) : launch_greedy_wave(e->mode, a, st, &form);
         if (rc) return rc;
         if (e->profiling) e->form_launches[use_team ? 2 : form]++;
     } else {
+        if (e->live_now) return set_error(IIV_ERR_INVALID, "iiv_encode_live: this encoder's launches do not run the team kernel");
         const bool packed = e->content_choice == IIV_CONTENT_JOINT;
         const WorkgroupArgs wa{e->d_states, d_main, d_aux, n_frames, e->n_streams, d_round, seg_stride, e->d_store,
                                packed ? e->d_joint_l : e->d_left_t, packed ? e->d_joint_r : e->d_right_t, d_ops, ops_stride};
@@ -1033,6 +1056,46 @@ int encode(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux, int n_frames
                                total * 6, st)))
             return rc;
     return tie_stats_request(e, st);
+}
+
+// ---- live hand-over (include/iivision.h: iiv_encode_live)
+constexpr int kLiveCap = 4096;   // opcodes per queue: what one call may emit
+
+int encoder_live_queue(Encoder *e, int slot, uint64_t **host_queue, int *capacity)
+{
+    if (!e || slot < 0 || slot > 1 || !host_queue || !capacity) return set_error(IIV_ERR_INVALID, "live_queue: bad argument");
+    if (e->n_streams != 1) return set_error(IIV_ERR_INVALID, "live_queue: a one-stream encoder's (this one has %d)", e->n_streams);
+    if (!e->h_live[slot]) {
+        // coherent (fine-grained) and mapped: a kernel's store is a write into host memory, seen by the host without any
+        // synchronisation call
+        void *p = nullptr;
+        IIV_HIP(hipHostMalloc(&p, (size_t)kLiveCap * 8, hipHostMallocCoherent | hipHostMallocMapped));
+        memset(p, 0, (size_t)kLiveCap * 8);   // (tag 0 is never used)
+        e->h_live[slot] = static_cast<unsigned long long *>(p);
+    }
+    *host_queue = reinterpret_cast<uint64_t *>(e->h_live[slot]);
+    *capacity = kLiveCap;
+    return IIV_OK;
+}
+
+int encode_live(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux, int n_frames, const iiv_segment *segs, int n_segs,
+                uint8_t *d_ops, int slot, uint32_t tag, hipStream_t st)
+{
+    if (!e || slot < 0 || slot > 1 || !segs) return set_error(IIV_ERR_INVALID, "iiv_encode_live: bad argument");
+    if (!e->h_live[slot]) return set_error(IIV_ERR_INVALID, "iiv_encode_live: no queue in that slot (iiv_encoder_live_queue)");
+    if (tag == 0 || tag > 0xffffu) return set_error(IIV_ERR_INVALID, "iiv_encode_live: the tag must be 1 .. 65535");
+    if (!team_kernel_runs(e))   // (refused before anything is launched: the caller falls back to iiv_encode)
+        return set_error(IIV_ERR_INVALID, "iiv_encode_live: this encoder's launches do not run the team kernel (options)");
+    long long total = 0;
+    for (int i = 0; i < n_segs; i++) total += segs[i].n_ops > 0 ? segs[i].n_ops : 0;
+    if (total > kLiveCap) return set_error(IIV_ERR_INVALID, "iiv_encode_live: %lld opcodes, the queue holds %d", total, kLiveCap);
+    void *dev = nullptr;
+    IIV_HIP(hipHostGetDevicePointer(&dev, e->h_live[slot], 0));
+    e->live_now = static_cast<unsigned long long *>(dev);
+    e->live_tag = tag;
+    const int rc = encode(e, d_main, d_aux, n_frames, segs, n_segs, d_ops, st);
+    e->live_now = nullptr;
+    return rc;
 }
 
 // stream s runs segs[seg_begin[s] .. seg_begin[s + 1])
@@ -1239,6 +1302,20 @@ int iiv_encode(iiv_encoder *enc, const uint8_t *d_frames_main, const uint8_t *d_
     if (!enc) return iiv::set_error(IIV_ERR_INVALID, "null encoder");
     return iiv::encode(enc->impl, d_frames_main, d_frames_aux, n_frames, segments, n_segments, d_ops_out,
                        (hipStream_t)stream);
+}
+
+int iiv_encoder_live_queue(iiv_encoder *enc, int slot, uint64_t **host_queue, int *capacity)
+{
+    if (!enc) return iiv::set_error(IIV_ERR_INVALID, "null encoder");
+    return iiv::encoder_live_queue(enc->impl, slot, host_queue, capacity);
+}
+
+int iiv_encode_live(iiv_encoder *enc, const uint8_t *d_frames_main, const uint8_t *d_frames_aux, int n_frames,
+                    const iiv_segment *segments, int n_segments, uint8_t *d_ops_out, int slot, uint32_t tag, void *stream)
+{
+    if (!enc) return iiv::set_error(IIV_ERR_INVALID, "null encoder");
+    return iiv::encode_live(enc->impl, d_frames_main, d_frames_aux, n_frames, segments, n_segments, d_ops_out, slot, tag,
+                            (hipStream_t)stream);
 }
 
 int iiv_encode_streams(iiv_encoder *enc, const uint8_t *d_frames_main, const uint8_t *d_frames_aux, int n_frames,

@@ -457,6 +457,10 @@ struct GreedyArgs {
     // stream perm[i].  Streams are independent: the order changes no byte.  Either may be NULL.
     const int *perm;
     uint32_t *cost;
+    // live hand-over (iiv_encode_live; the team kernel, one stream): a queue in coherent host memory that receives every
+    // opcode as one tagged 8-byte store; NULL otherwise
+    unsigned long long *live = nullptr;
+    uint32_t live_tag = 0;
 };
 
 int launch_greedy_wave(int mode, const GreedyArgs &a, hipStream_t st, int *form_out = nullptr);   // iiv_greedy.hip; *form_out: 0 plain form launched, 1 LDS-shared

@@ -41,6 +41,7 @@
 
 namespace iiv {
 
+constexpr unsigned long long kLiveEnd = 0xffull;   // byte 0 of a live-queue slot: "the launch ended here, short of its n_ops" (a page byte is 32..63)
 constexpr int kScoringWaves = 8;            // waves 0..6 score, wave 7 generates MT19937 blocks; further waves only
 constexpr int kScorers = kScoringWaves - 1;  // follow the rounds
 // a round reads < 623 + kScorers * 258 + 2 words past block 0's start (7 scorers: 2431 -> 4 blocks; 15: 4495 -> 8)
@@ -55,7 +56,8 @@ template <int MODE, int TW, bool FOUR = false>
 __device__ __forceinline__ void team_body(StreamState *__restrict__ states, const uint8_t *__restrict__ frames_main,
                                           const uint8_t *__restrict__ frames_aux, int n_frames, const LaunchSeg &g,
                                           const NarrowTables &nt,
-                                          uint8_t *__restrict__ ops_out, size_t ops_stride)
+                                          uint8_t *__restrict__ ops_out, size_t ops_stride,
+                                          unsigned long long *__restrict__ live = nullptr, uint32_t live_tag = 0)
 {
     constexpr int kTeamWaves = TW, kTeamThreads = 64 * TW;
     using T = SplitTraits<MODE>;
@@ -83,9 +85,17 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
     const int n_ops = IIV_SGPR(g.n_ops), is_aux = IIV_SGPR(g.is_aux), frame = IIV_SGPR(g.frame);
     if (n_ops <= 0) return;
     uint8_t *out = ops_out + (size_t)blockIdx.x * ops_stride + (size_t)IIV_SGPR(g.ops_base) * 6;
+    // Live hand-over (iiv_encode_live, include/iivision.h; one-stream encoders): every opcode also goes, as ONE aligned
+    // 8-byte store, into a queue in coherent host memory -- its six bytes and the launch's tag in the top two -- so that the
+    // caller's generator (video.py: one next() per opcode) hands opcode i out while the kernel works on i + 1 ...: a slot is
+    // valid when it carries the tag, no fence and no flag (an aligned 8-byte store arrives whole).  A launch that ends
+    // short of its n_ops (one of the reference's asserts, an internal error) puts kLiveEnd behind its last opcode.
+    unsigned long long *const lq = live ? live + IIV_SGPR(g.ops_base) : nullptr;
+    const unsigned long long lq_tag = (unsigned long long)(live_tag & 0xffffu) << 48;
 
     if (!S.gen_active || S.error) {
         if (tid == 0 && !S.error) S.error = kErrNoGenerator;
+        if (tid == 0 && lq) __builtin_nontemporal_store(lq_tag | kLiveEnd, lq);
         return;
     }
     for (int i = tid; i < 256; i += kTeamThreads) {
@@ -357,6 +367,11 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
                 q[3] = (uint8_t)y1e;
                 q[4] = (uint8_t)y2e;
                 q[5] = (uint8_t)(FOUR ? y3e : x);
+                if (lq)
+                    __builtin_nontemporal_store(lq_tag | (unsigned long long)(uint32_t)(p + 32) | ((unsigned long long)c << 8) |
+                                                    ((unsigned long long)(uint32_t)x << 16) | ((unsigned long long)(uint32_t)y1e << 24) |
+                                                    ((unsigned long long)(uint32_t)y2e << 32) | ((unsigned long long)(uint32_t)(FOUR ? y3e : x) << 40),
+                                                lq + op_at);
             }
         }
     };
@@ -640,6 +655,7 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
         for (int i = done + lane; i < n_ops; i += 64) {  // video.py:249-251
             uint8_t *q = out + (size_t)i * 6;
             q[0] = 32; q[1] = (uint8_t)pad_content; q[2] = 0; q[3] = 0; q[4] = 0; q[5] = 0;
+            if (lq) __builtin_nontemporal_store(lq_tag | 32ull | ((unsigned long long)(pad_content & 0xffu) << 8), lq + i);
         }
         pad_ops += (unsigned long long)(n_ops - done);
         done = n_ops;
@@ -660,6 +676,7 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
         S.ops += (unsigned long long)done;
         S.pad_ops += pad_ops;
         if (err && S.error == 0) S.error = err;
+        if (lq && done < n_ops) __builtin_nontemporal_store(lq_tag | kLiveEnd, lq + done);
     }
 }
 

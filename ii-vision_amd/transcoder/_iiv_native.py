@@ -42,7 +42,7 @@ SYMBOLS = [
     "iiv_encoder_snapshot", "iiv_encoder_rollback", "iiv_encoder_snapshot_slot", "iiv_encoder_rollback_slot", "iiv_encoder_get_state", "iiv_encoder_set_state",
     "iiv_encoder_set_state_range", "iiv_encoder_get_video_state", "iiv_encoder_set_video_state",
     "iiv_encoder_get_video_brief", "iiv_encoder_get_video_brief_async",
-    "iiv_encode", "iiv_encode_streams",
+    "iiv_encode", "iiv_encode_streams", "iiv_encoder_live_queue", "iiv_encode_live",
     "iiv_encoder_check", "iiv_encoder_profile", "iiv_encoder_profile_read", "iiv_encoder_input_stats",
     "iiv_encoder_launch_forms",
     "iiv_build_split_store_table", "iiv_split_table_entries", "iiv_check_split_diff_table",
@@ -140,6 +140,9 @@ def lib():
     L.iiv_encoder_set_video_state.argtypes = [vp, i32, C.POINTER(VideoState)]
     L.iiv_encode.argtypes = [vp, vp, vp, i32, C.POINTER(Segment), i32, vp, vp]
     L.iiv_encode_streams.argtypes = [vp, vp, vp, i32, C.POINTER(Segment), C.POINTER(C.c_int32), vp, sz, vp]
+    if hasattr(L, "iiv_encode_live") or "IIV_LIB" not in os.environ:
+        L.iiv_encoder_live_queue.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_int)]
+        L.iiv_encode_live.argtypes = [vp, vp, vp, i32, C.POINTER(Segment), i32, vp, i32, C.c_uint32, vp]
     L.iiv_build_split_store_table.argtypes = [i32, vp, vp, vp, vp, vp]
     L.iiv_split_table_entries.restype = sz
     L.iiv_check_split_diff_table.argtypes = [i32, vp, vp, vp, vp]
@@ -159,7 +162,8 @@ def lib():
     if hasattr(L, "iiv_encoder_launch_forms") or "IIV_LIB" not in os.environ:
         L.iiv_encoder_launch_forms.argtypes = [vp, C.POINTER(C.c_int64)]
     for name in SYMBOLS:
-        if "IIV_LIB" in os.environ and name in ("iiv_encoder_launch_forms", "iiv_check_diff_weight_pieces", "iiv_encoder_info", "iiv_encoder_get_video_brief_async") and not hasattr(L, name):
+        if "IIV_LIB" in os.environ and name in ("iiv_encoder_launch_forms", "iiv_check_diff_weight_pieces", "iiv_encoder_info", "iiv_encoder_get_video_brief_async",
+                                                 "iiv_encoder_live_queue", "iiv_encode_live") and not hasattr(L, name):
             continue   # (an older build under IIV_LIB: tools/ab_libs.sh)
         getattr(L, name)  # AttributeError if the library lacks a declared symbol
     _lib = L
@@ -592,6 +596,24 @@ class Encoder:
                                dptr(ops_out), stream_ptr()))
         # the rows as they were written: (n_streams, total, 6) over the front of the buffer
         return ops_out.view(-1)[:need].view(self.n_streams, total, 6)
+
+    def live_queue(self, slot=0):
+        """Queue `slot` of the live hand-over (include/iivision.h: iiv_encoder_live_queue) as a numpy uint64 view of the
+        coherent host memory the team kernel writes its opcodes into: slot j = six opcode bytes | tag << 48."""
+        addr, cap = C.c_void_p(0), C.c_int(0)
+        check(lib().iiv_encoder_live_queue(self._h, int(slot), C.byref(addr), C.byref(cap)))
+        return np.frombuffer((C.c_uint64 * cap.value).from_address(addr.value), dtype=np.uint64)
+
+    def encode_live(self, frames_main, frames_aux, segment, ops_out, slot, tag):
+        """iiv_encode_live of ONE segment (frame, is_aux, restart, n_ops): iiv_encode, the opcodes also appearing one by one
+        in live_queue(slot) under `tag`.  Raises IIVError(ERR_INVALID) -- nothing launched -- if this encoder's options
+        keep it off the team kernel."""
+        _, n_frames = validate_frames(self._h, frames_main, frames_aux)
+        f, a, r, k = segment
+        seg = (Segment * 1)(Segment(int(f), int(a), int(r), int(k)))
+        validate_ops_out(ops_out, self.n_streams * int(k) * 6)
+        check(lib().iiv_encode_live(self._h, dptr(frames_main), dptr(frames_aux), int(n_frames), seg, 1, dptr(ops_out),
+                                    int(slot), int(tag), stream_ptr()))
 
     def snapshot(self, slot=0):
         check(lib().iiv_encoder_snapshot_slot(self._h, int(slot), stream_ptr()))

@@ -41,10 +41,20 @@ the caller will start next -- the other bank of the SAME target (movie.py:139-14
 snapshot, so that the device computes it while Python hands out this generator's opcodes.  If encode_frame() is then called
 with that target and bank (and nobody touched the state or the global generators in between) its launch has already run; if not,
 the snapshot is restored and nothing of it is observable.
+
+Live hand-over (round 6, `Video.LIVE`): a speculative launch no longer has to END before its first opcode is handed out.  The
+eight-wave team kernel writes every opcode, as one tagged 8-byte store, into a queue in coherent host memory
+(include/iivision.h: iiv_encode_live), and the generator yields opcode i as soon as slot i carries the launch's tag -- while the
+kernel works on i + 1.  One clip's chain of steps runs at ~0.55 us per opcode on the device, about what a Python caller takes
+to pull one: the two now overlap instead of adding up.  What is observable is unchanged: a generator abandoned after k opcodes
+is rolled back and replayed for exactly k, as before; a launch that ends short (one of the reference's asserts) marks the queue
+behind its last opcode, and the generator then steps exactly from there, so the next() that raises in the reference raises here.
 """
 
 import ctypes
+import operator
 import random
+import time
 from typing import Iterator, List, Tuple
 
 import numpy as np
@@ -110,6 +120,94 @@ def _np_rng_write(words):
     np.random.set_state((old[0], w[:624].copy(), int(w[624].astype(np.int32) if hasattr(w[624], "astype") else w[624]), old[3], old[4]))
 
 
+_py_global = [None, None]   # [the random.Random instance the address belongs to, that address or 0 = "use getstate / setstate"]
+
+
+def _py_rng_addr():
+    """Address of `index` in the process-wide `random` generator's C struct (CPython _randommodule.c RandomObject: PyObject_HEAD,
+    int index, uint32_t state[624]) -- random.getstate()[1] is state[0..623] followed by index.  getstate() builds a tuple of 625
+    ints and setstate() parses one (~15 and ~40 microseconds, both at every generator start); the 2500 bytes themselves move in
+    under one.  The layout is CPython's private business, so -- as for np.random above -- the address is believed only after
+    the bytes there have been seen to BE what getstate() reports, before and after a draw and after a write through it; if
+    not, 0 is returned and this module goes through getstate() / setstate() (slower, same results)."""
+    inst = getattr(random, "_inst", None)
+    if _py_global[0] is not inst or inst is None:
+        addr = 0
+        try:
+            if inst is not None and random.getstate.__self__ is inst and type(inst).__mro__[1].__name__ == "Random":
+                cand = id(inst) + object.__basicsize__      # (PyObject_HEAD of a non-GC base: refcount, type)
+
+                def same():
+                    words = np.array(random.getstate()[1], dtype=np.uint32)
+                    raw = np.frombuffer(ctypes.string_at(cand, 2500), dtype=np.uint32)
+                    return bool(np.array_equal(raw[1:], words[:624]) and raw[0] == words[624])
+                saved = random.getstate()
+                try:
+                    ok = same()
+                    random.getrandbits(8)               # (moves index, or refills the block)
+                    ok = ok and same()
+                    if ok:
+                        probe = np.arange(7, 7 + 625, dtype=np.uint32)
+                        probe[0] = 3                    # index
+                        ctypes.memmove(cand, probe.ctypes.data, 2500)
+                        got = random.getstate()[1]
+                        ok = got[624] == 3 and got[:624] == tuple(range(8, 8 + 624))
+                finally:
+                    random.setstate(saved)              # (the caller's stream is where it was)
+                if ok and same():
+                    addr = cand
+        except Exception:
+            addr = 0
+        _py_global[0], _py_global[1] = inst, addr
+    return _py_global[1]
+
+
+def _py_rng_raw():
+    """random's MT19937 words as 2500 bytes in getstate() order: state[624], index"""
+    addr = _py_rng_addr()
+    if addr:
+        return ctypes.string_at(addr + 4, 2496) + ctypes.string_at(addr, 4)
+    return np.array(random.getstate()[1], dtype=np.uint32).tobytes()
+
+
+def _py_rng_write(words):
+    """the 625 words (getstate() order; a ctypes array / buffer of 2500 bytes) become random's state; gauss_next is cleared, as
+    random.setstate((3, words, None)) would"""
+    addr = _py_rng_addr()
+    if addr:
+        base = ctypes.addressof(words) if isinstance(words, ctypes.Array) else np.frombuffer(words, dtype=np.uint8).ctypes.data
+        ctypes.memmove(addr + 4, base, 2496)
+        ctypes.memmove(addr, base + 2496, 4)
+        random._inst.gauss_next = None
+        return
+    random.setstate((3, tuple(np.frombuffer(bytes(words), dtype=np.uint32).tolist()), None))
+
+
+class _Chunk:
+    """A speculative launch whose opcodes are being handed out: what _settle needs to make the device state that of the
+    opcodes CONSUMED.  The hand-out is `yield from` a list iterator (no Python statement per opcode), so the count is read
+    off that iterator when somebody asks: opcodes given to iterators so far, less what the current one still holds."""
+    __slots__ = ("token", "restart", "produced", "prev_live", "slot", "items", "it", "base")
+
+    def __init__(self, token, restart, produced, prev_live, slot):
+        self.token, self.restart, self.produced, self.prev_live, self.slot = token, restart, produced, prev_live, slot
+        self.items, self.it, self.base = None, None, 0
+
+    def hand_out(self, items):
+        """the iterator to `yield from`: the next opcodes of the launch"""
+        self.items, self.base = items, self.base + len(items)
+        self.it = iter(items)
+        return self.it
+
+    def consumed(self):
+        return self.base - (operator.length_hint(self.it) if self.it is not None else 0)
+
+    def stop(self):
+        """nothing more is handed out (the launch was settled underneath its generator)"""
+        if self.items is not None:
+            del self.items[:]
+
+
 class Video:
     """Encodes sequence of images into prioritized screen byte changes."""
 
@@ -141,6 +239,12 @@ class Video:
 
     #: True (default): run one generator ahead of a movie.py-paced caller (module docstring).  Speed only.
     LOOKAHEAD = True
+
+    #: True (default): hand the opcodes of a speculative launch out WHILE the kernel produces them (module docstring: live
+    #: hand-over) instead of after it has ended.  Speed only; encoders whose options keep them off the team kernel
+    #: (joint_content) fall back by themselves.
+    LIVE = True
+    LIVE_TIMEOUT = 20.0   # seconds without a new opcode before the launch is declared dead
 
     def __init__(
             self,
@@ -215,6 +319,13 @@ class Video:
         self._ahead = None
         self.lookahead_stats = {"launched": 0, "adopted": 0, "undone": 0}   # (what became of the generators enqueued ahead)
         self._ahead_bufs = None   # second set of opcode / brief buffers (the look-ahead's results must not overwrite the live generator's)
+        # live hand-over: the two host queues the team kernel writes opcodes into (None until first used; False: this encoder's
+        # launches do not run that kernel), the tag of the latest launch, the event behind the brief that follows a launch
+        self._live_q = None
+        self._live_tag = 0
+        self._brief_event = None
+        # (launches handed out live; polls of the queue; polls that found nothing and waited, and for how long)
+        self.live_stats = {"launches": 0, "takes": 0, "waits": 0, "wait_s": 0.0}
 
     # ---- the reference's public attributes; reading one settles any speculation first
     def _settled(name):  # noqa: N805
@@ -314,8 +425,8 @@ class Video:
         if dhgr:
             st.array("mem_aux", np.uint8, (32, 256))[...] = self._aux_memory_map.page_offset
             st.array("up_aux", np.int32, (32, 256))[...] = self._aux_update_priority
-        py = random.getstate()[1]
-        st.array("rng_py", np.uint32, (625,))[...] = py
+        py = _py_rng_raw()
+        st.array("rng_py", np.uint32, (625,))[...] = np.frombuffer(py, dtype=np.uint32)
         raw = _np_rng_raw()
         st.array("rng_np", np.uint32, (625,))[...] = np.frombuffer(raw, dtype=np.uint32)
         self._rng_seen = (py, raw)
@@ -346,25 +457,25 @@ class Video:
 
     def _set_global_rng(self, st):
         """the device's random / np.random positions (st.rng_py, st.rng_np) become the process's"""
-        py = tuple(np.frombuffer(st.rng_py, dtype=np.uint32).tolist())
-        random.setstate((3, py, None))
+        _py_rng_write(st.rng_py)
         _np_rng_write(st.rng_np)
-        self._rng_seen = (py, bytes(st.rng_np))
+        self._rng_seen = (bytes(st.rng_py), bytes(st.rng_np))
 
     def _global_rng_moved(self):
         """did anyone draw from / reseed random or np.random since this object last synchronised them?"""
         if self._rng_seen is None:
             return True
-        return (random.getstate()[1], _np_rng_raw()) != self._rng_seen
+        return (_py_rng_raw(), _np_rng_raw()) != self._rng_seen
 
     def _upload_rng(self):
-        py = np.array(random.getstate()[1], dtype=np.uint32)
+        pyraw = _py_rng_raw()
+        py = np.frombuffer(pyraw, dtype=np.uint32).copy()
         raw = _np_rng_raw()
         rn = np.frombuffer(raw, dtype=np.uint32).copy()
         self._enc.set_state(native.STATE_RNG_PY, py)
         self._enc.set_state(native.STATE_RNG_NP, rn)
         self._brief_fresh = False
-        self._rng_seen = (tuple(py.tolist()), raw)
+        self._rng_seen = (pyraw, raw)
 
     def _pinned_brief(self):
         """self._vb in page-locked memory (allocated with the first launch: torch is needed for it)"""
@@ -387,6 +498,10 @@ class Video:
             self._brief_fresh = True
             self._brief_applied = False
         b = self._vb
+        if self._brief_event is not None:
+            # (a live launch: its opcodes were handed out while it ran; the brief behind it arrives with its end)
+            self._brief_event.synchronize()
+            self._brief_event = None
         if not self._brief_applied:
             if not self._global_rng_moved():  # (else the caller's draws / reseed win: uploaded at the next launch)
                 self._set_global_rng(b)
@@ -395,17 +510,22 @@ class Video:
             self._brief_applied = True
         return b
 
+    def _launch_buffers(self, n_ops):
+        import torch
+        if self._ops_dev is None or self._ops_dev.shape[1] < n_ops:
+            cap = max(n_ops, 2048)
+            self._ops_dev = torch.empty((1, cap, 6), dtype=torch.uint8, device="cuda")
+            self._ops_host = torch.empty((cap, 6), dtype=torch.uint8).pin_memory()
+
     def _launch(self, token, restart, n_ops, fetch=True):
         """[prologue +] n_ops greedy steps on the device state as it stands.  fetch=False: a replay of opcodes the caller has
         already consumed (after a roll-back): nothing to bring home and nothing that can fail -- the speculative launch they
         came from passed its check, and this is a prefix of it -- so the launch is only enqueued."""
         import torch
         self._brief_fresh = False
+        self._brief_event = None
         n_ops = int(n_ops)
-        if self._ops_dev is None or self._ops_dev.shape[1] < n_ops:
-            cap = max(n_ops, 2048)
-            self._ops_dev = torch.empty((1, cap, 6), dtype=torch.uint8, device="cuda")
-            self._ops_host = torch.empty((cap, 6), dtype=torch.uint8).pin_memory()
+        self._launch_buffers(n_ops)
         ops = self._enc.encode(token.fm, token.fa, [(0, int(bool(token.is_aux)), int(restart), n_ops)], ops_out=self._ops_dev)
         self._host_current = False
         if not fetch:
@@ -419,6 +539,72 @@ class Video:
         self._brief_fresh = True
         self._brief_applied = False
         return self._ops_host[:n_ops].numpy()
+
+    def _live_queues(self):
+        """the two host queues of the live hand-over, or None if this Video does without (LIVE off, or its encoder's
+        launches do not run the team kernel: found out at the first attempt)"""
+        if not self.LIVE or self._live_q is False or self.STRICT_SYNC:
+            return None
+        if self._live_q is None:
+            try:
+                self._live_q = [self._enc.live_queue(0), self._enc.live_queue(1)]
+            except (native.IIVError, AttributeError):
+                self._live_q = False
+                return None
+        return self._live_q
+
+    def _launch_live(self, token, is_aux, restart, n_ops, qslot, ops_dev, vb):
+        """[prologue +] n_ops greedy steps, the opcodes appearing one by one in host queue `qslot` under a fresh tag; the brief
+        of the state behind them follows into `vb` (pinned), an event behind it.  Nothing waits.  Returns what the consumer
+        needs (_live_take), or None -- nothing launched -- if this encoder cannot (the caller then launches the old way)."""
+        import torch
+        qs = self._live_queues()
+        if qs is None or n_ops > len(qs[qslot]):
+            return None
+        self._live_tag = self._live_tag % 65535 + 1
+        try:
+            self._enc.encode_live(token.fm, token.fa, (0, int(bool(is_aux)), int(restart), int(n_ops)), ops_dev, qslot, self._live_tag)
+        except native.IIVError as e:
+            if e.code != native.ERR_INVALID:
+                raise
+            self._live_q = False     # (refused before anything was launched: options that keep the encoder off the team kernel)
+            return None
+        self._host_current = False
+        self._enc.get_video_brief_async(vb)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.live_stats["launches"] += 1
+        return dict(q=qs[qslot], tag=self._live_tag, n=int(n_ops), event=ev)
+
+    def _live_take(self, lv, k):
+        """Opcodes k .. of a live launch that have arrived -- at least one: this waits for slot k -- as a list of
+        (page, content, offsets) tuples, and whether the launch ENDED behind them, short of its n_ops (then the list may be
+        empty)."""
+        q, tag, n = lv["q"], lv["tag"], lv["n"]
+        st = self.live_stats
+        st["takes"] += 1
+        if (int(q[k]) >> 48) != tag:
+            t0 = time.perf_counter()
+            spins = 0
+            while (int(q[k]) >> 48) != tag:
+                spins += 1
+                if not spins & 0xfff and time.perf_counter() - t0 > self.LIVE_TIMEOUT:
+                    self._enc.check()     # (synchronises; raises what the device reports)
+                    if (int(q[k]) >> 48) != tag:
+                        raise RuntimeError("live hand-over: opcode %d of %d never arrived" % (k, n))
+            st["waits"] += 1
+            st["wait_s"] += time.perf_counter() - t0
+        w = q[k:n]
+        ok = (w >> np.uint64(48)) == np.uint64(tag)
+        r = len(w) if ok.all() else int(ok.argmin())
+        b = w[:r].view(np.uint8).reshape(r, 8)
+        pages = b[:, 0]
+        ended = False
+        if pages.max() == 0xFF:
+            r = int((pages == 0xFF).argmax())
+            ended = True
+            b = b[:r]
+        return list(zip(b[:, 0].tolist(), b[:, 1].tolist(), b[:, 2:6].tolist())), ended
 
     def _look_ahead(self, token, n_live, slot):
         """Behind the live generator's launch (its n_live opcodes are in hand): if they end at a bank flip inside the frame,
@@ -441,18 +627,22 @@ class Video:
                 vb_mem=torch.empty(ctypes.sizeof(native.VideoBrief), dtype=torch.uint8).pin_memory())
         bufs = self._ahead_bufs
         self._enc.snapshot(slot)
-        ops = self._enc.encode(token.fm, token.fa, [(0, int(not token.is_aux), 1, int(n))], ops_out=bufs["ops_dev"])
-        bufs["ops_host"][:n].copy_(ops[0], non_blocking=True)
         vb = native.VideoBrief.from_address(bufs["vb_mem"].data_ptr())
-        self._enc.get_video_brief_async(vb)
+        lv = self._launch_live(token, not token.is_aux, 1, int(n), slot, bufs["ops_dev"], vb)
+        if lv is None:
+            ops = self._enc.encode(token.fm, token.fa, [(0, int(not token.is_aux), 1, int(n))], ops_out=bufs["ops_dev"])
+            bufs["ops_host"][:n].copy_(ops[0], non_blocking=True)
+            self._enc.get_video_brief_async(vb)
         self._host_current = False
-        self._ahead = dict(is_aux=not token.is_aux, main=token.main, aux=token.aux, n=int(n), slot=slot)
+        self._ahead = dict(is_aux=not token.is_aux, main=token.main, aux=token.aux, n=int(n), slot=slot, live=lv)
         self.lookahead_stats["launched"] += 1
 
     def _adopt(self, a):
         """The generator enqueued ahead is the one the caller asked for: its launch has run (or is running); wait, check, and
         swap the buffer sets so that the brief and the opcodes of this generator are the current ones."""
-        self._enc.check()          # (synchronises; raises what the reference's asserts would)
+        lv = a.get("live")
+        if lv is None:
+            self._enc.check()      # (synchronises; raises what the reference's asserts would)
         self.lookahead_stats["adopted"] += 1
         bufs = self._ahead_bufs
         self._pinned_brief()
@@ -463,7 +653,8 @@ class Video:
         self._host_current = False
         self._brief_fresh = True
         self._brief_applied = False
-        return self._ops_host[:a["n"]].numpy()
+        self._brief_event = lv["event"] if lv is not None else None
+        return (None, lv) if lv is not None else (self._ops_host[:a["n"]].numpy(), None)
 
     def _settle(self, download=True, keep_ahead=False):
         """Make the device state -- and, with download, the host's -- reflect exactly the opcodes consumed so far.
@@ -471,9 +662,12 @@ class Video:
         all consumed (the caller is about to ask for a generator: maybe this one); otherwise it is undone here."""
         p = self._pending
         self._pending = None
+        consumed = 0
         if p is not None:
-            self._ops_done += p["consumed"]
-        partial = p is not None and p["consumed"] < p["produced"]
+            consumed = p.consumed()
+            p.stop()
+            self._ops_done += consumed
+        partial = p is not None and consumed < p.produced
         a = self._ahead
         if a is not None and (partial or download or not keep_ahead):
             self._ahead = None
@@ -484,14 +678,14 @@ class Video:
                 self._host_current = False
         if partial:
             # abandoned mid-chunk: restore the snapshot and replay only what was consumed (a look-ahead behind it goes with it)
-            self._enc.rollback(p["slot"])
+            self._enc.rollback(p.slot)
             self._host_current = False
             self._brief_fresh = False   # (what travelled behind the launch describes all of its opcodes)
-            if p["consumed"]:
-                self._launch(p["token"], p["restart"], p["consumed"], fetch=False)
-            elif p["restart"]:
-                self._live = p["prev_live"]  # the prologue never happened
-                p["token"].started = False
+            if consumed:
+                self._launch(p.token, p.restart, consumed, fetch=False)
+            elif p.restart:
+                self._live = p.prev_live  # the prologue never happened
+                p.token.started = False
         if download and not self._host_current:
             self._download()
 
@@ -563,7 +757,7 @@ class Video:
                     # opcodes all consumed, nothing touched, nobody drew from the global generators since
                     a = self._ahead
                     ok = (paced and not self._touched and not self.STRICT_SYNC and a["is_aux"] == token.is_aux
-                          and (self._pending is None or self._pending["consumed"] == self._pending["produced"])
+                          and (self._pending is None or self._pending.consumed() == self._pending.produced)
                           and np.array_equal(a["main"], token.main)
                           and (token.aux is None or np.array_equal(a["aux"], token.aux)) and not self._global_rng_moved())
                     self._settle(download=False, keep_ahead=ok)
@@ -591,15 +785,25 @@ class Video:
                         self._dev_aux.copy_(torch.from_numpy(token.aux))
                         self._up_aux = token.aux
                 slot = 0
+                live = None     # the launch's opcodes arrive one by one in a host queue (LIVE): what _live_take needs
                 if speculative:
                     try:
                         if adopt is not None:
                             slot = adopt["slot"]
-                            ops = self._adopt(adopt)
-                            chunk = len(ops)
+                            ops, live = self._adopt(adopt)
+                            chunk = adopt["n"]
                         else:
                             self._enc.snapshot(slot)
-                            ops = self._launch(token, restart, chunk)
+                            self._brief_fresh = False
+                            self._brief_event = None
+                            self._launch_buffers(chunk)
+                            live = self._launch_live(token, token.is_aux, restart, chunk, slot, self._ops_dev, self._pinned_brief())
+                            if live is not None:
+                                self._brief_fresh = True
+                                self._brief_applied = False
+                                self._brief_event = live["event"]
+                            else:
+                                ops = self._launch(token, restart, chunk)
                     except native.IIVAssertionError:
                         # one of the reference's asserts fires somewhere in this chunk -- maybe past
                         # what the caller will pull: step exactly from here on, so that it is raised
@@ -616,25 +820,40 @@ class Video:
                 if self.STRICT_SYNC:
                     self._download()
                 rec = None
+                produced = live["n"] if live is not None else len(ops)
                 if speculative:
-                    rec = dict(token=token, restart=restart, consumed=0, produced=len(ops), prev_live=prev_live, slot=slot)
+                    rec = _Chunk(token, restart, produced, prev_live, slot)
                     self._pending = rec
                     if paced and self.LOOKAHEAD and self.mode == VideoMode.DHGR:
-                        self._look_ahead(token, len(ops), 1 - slot)
-                rows = ops.tolist()  # plain ints, converted once per chunk
-                for k in range(len(rows)):
-                    if rec is not None:
-                        rec["consumed"] = k + 1
-                    row = rows[k]
-                    yield row[0], row[1], row[2:6]
-                    if rec is not None and self._pending is not rec:
-                        break  # settled underneath us: the rest of this chunk was rolled back
+                        self._look_ahead(token, produced, 1 - slot)
+                if live is not None:
+                    # hand out what has arrived, as it arrives
+                    ended = False
+                    while rec.base < produced and not ended and self._pending is rec:
+                        items, ended = self._live_take(live, rec.base)
+                        yield from rec.hand_out(items)
+                    if self._pending is not rec:
+                        continue   # settled underneath us: the rest of this launch was rolled back
+                    if rec.base < produced:
+                        # the launch ended short of its opcodes: one of the reference's asserts fires at the next one (or an
+                        # internal limit was hit).  Settle to exactly the opcodes consumed -- roll back, replay them -- and
+                        # step exactly from here: the next() that raises in the reference raises here
+                        self._settle(download=False)
+                        speculative, chunk = False, 1
+                        continue
+                    self._pending = None
+                    self._ops_done += produced
+                    continue
+                # plain ints, converted once per chunk
+                items = list(zip(ops[:, 0].tolist(), ops[:, 1].tolist(), ops[:, 2:6].tolist()))
+                if rec is None:
+                    yield from items
+                    self._ops_done += len(items)
                 else:
-                    if rec is not None and self._pending is rec:
+                    yield from rec.hand_out(items)
+                    if self._pending is rec:   # (else: settled underneath us, the rest of this chunk was rolled back)
                         self._pending = None
-                        self._ops_done += len(rows)
-                    elif rec is None:
-                        self._ops_done += len(rows)
+                        self._ops_done += len(items)
                 if not speculative:
                     chunk = 1
         except GeneratorExit:

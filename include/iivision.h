@@ -370,6 +370,28 @@ int iiv_encode_streams(iiv_encoder *enc, const uint8_t *d_frames_main, const uin
                        int n_frames, const iiv_segment *segments, const int32_t *seg_begin,
                        uint8_t *d_ops_out, size_t ops_stride, void *stream);
 
+/* Live hand-over of ONE stream's opcodes: the reference's caller pulls its opcodes one next() at a time from a lazy
+ * generator (video.py:72-93, movie.py:94-109), and a single clip's chain of steps cannot be computed faster than ~0.5 us per
+ * opcode -- about what a Python caller takes to consume one.  So instead of waiting for a launch and then handing its
+ * opcodes out, a one-stream encoder can let the caller consume opcode i while the kernel works on i + 1:
+ * iiv_encode_live is iiv_encode, with every opcode ALSO written -- one aligned 8-byte store -- into a queue in coherent,
+ * GPU-mapped host memory: slot j (j = the opcode's index in the call's output, as in d_ops_out) =
+ *   byte 0 page + 32, byte 1 content, bytes 2..5 offsets (the six bytes of d_ops_out), bytes 6..7 `tag` (little endian).
+ * A slot is valid as soon as it carries the call's tag (1 .. 65535: the caller changes it from call to call; the queue is
+ * zeroed at creation, tag 0 is never valid); an aligned 8-byte store arrives whole, so no fence, flag or synchronisation
+ * call is involved.  If a launch ends short of its n_ops (one of the reference's asserts fired -- iiv_encoder_check() says
+ * which -- or an internal limit) the slot behind its last opcode holds byte 0 = 0xFF with the tag, and later launches of
+ * the call write their own end marks: a reader never waits for a slot that will not be written.
+ * iiv_encoder_live_queue: the host address and capacity (opcodes per call) of queue `slot` (0 / 1: one for the live
+ * generator, one for a generator enqueued ahead), allocated at the first call; one-stream encoders only.
+ * iiv_encode_live: IIV_ERR_INVALID -- before anything is launched or any generator bookkeeping changes -- if the
+ * encoder's options keep its launches off the eight-wave team kernel (IIV_CONTENT_JOINT*, IIV_GREEDY_WORKGROUP / WAVE*):
+ * the caller then uses iiv_encode.  State, d_ops_out and every other effect are exactly iiv_encode's. */
+int iiv_encoder_live_queue(iiv_encoder *enc, int slot, uint64_t **host_queue, int *capacity);
+int iiv_encode_live(iiv_encoder *enc, const uint8_t *d_frames_main, const uint8_t *d_frames_aux,
+                    int n_frames, const iiv_segment *segments, int n_segments, uint8_t *d_ops_out,
+                    int slot, uint32_t tag, void *stream);
+
 /* Synchronises `stream` and returns IIV_ERR_ASSERT / IIV_ERR_OVERFLOW if any
  * stream hit one of the reference's asserts (video.py:87,117,124,137,154-155)
  * or an internal capacity limit; *bad_stream (may be NULL) gets its index. */

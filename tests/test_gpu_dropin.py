@@ -229,11 +229,12 @@ def test_speculation_raises_where_the_reference_would():
     main, aux = frame(), frame()
     main[7, 33] |= 0x80
 
-    def run(spec):
+    def run(spec, live=True):
         random.seed(3)
         np.random.seed(4)
         v = video.Video(_FG(), ticks_per_second=14700., mode=video_mode.VideoMode.DHGR, palette=palette.Palette.NTSC)
         v.SPECULATE = spec
+        v.LIVE = live
         tgt = screen.DHGRBitmap(main_memory=screen.MemoryMap(1, main.copy()), aux_memory=screen.MemoryMap(1, aux.copy()),
                                 palette=palette.Palette.NTSC)
         out = []
@@ -248,8 +249,10 @@ def test_speculation_raises_where_the_reference_would():
 
     exact, raised = run(0)
     assert raised and 0 < len(exact) < 8000
-    spec, raised_spec = run(64)
-    assert raised_spec and spec == exact
+    for live in (True, False):   # (live: the launch marks its queue behind the last opcode; else iiv_encoder_check reports)
+        for chunk in (64, 2048):
+            spec, raised_spec = run(chunk, live)
+            assert raised_spec and spec == exact, (live, chunk)
 
 
 def test_reseeding_between_generators_is_carried_to_the_device(O, oracle_tables):
@@ -297,7 +300,8 @@ def test_reseeding_between_generators_is_carried_to_the_device(O, oracle_tables)
 
 
 @pytest.mark.parametrize("mode,seed,fourth", [(1, 1, False), (1, 2, False), (0, 3, False), (0, 4, False), (1, 5, False), (0, 6, False),
-                                              (1, 7, True), (0, 8, True), (1, 9, "strict"), (0, 10, "strict")])
+                                              (1, 7, True), (0, 8, True), (1, 9, "strict"), (0, 10, "strict"),
+                                              (1, 11, "nolive"), (0, 12, "nolive"), (1, 13, False), (0, 14, False)])
 def test_video_random_interleavings(O, oracle_tables, mode, seed, fourth, monkeypatch):
     """What a caller of the reference's Video may do between and inside generators, in random order and with random
     Video.SPECULATE: start a generator, pull a few or many opcodes, abandon it, look at a state attribute in the middle
@@ -316,6 +320,9 @@ def test_video_random_interleavings(O, oracle_tables, mode, seed, fourth, monkey
     np.random.seed(seed + 50)
     if fourth == "strict":      # Video.STRICT_SYNC: the literal behaviour, every next() a full state round trip
         monkeypatch.setattr(video.Video, "STRICT_SYNC", True)
+        fourth = False
+    if fourth == "nolive":      # Video.LIVE off: a speculative launch's opcodes are handed out after it has ended (round 5's path)
+        monkeypatch.setattr(video.Video, "LIVE", False)
         fourth = False
     v = video.Video(_FG(), ticks_per_second=14700., mode=video_mode.VideoMode.DHGR if mode else video_mode.VideoMode.HGR,
                     palette=palette.Palette.NTSC, fourth_offset=fourth)
@@ -384,8 +391,9 @@ def test_video_random_interleavings(O, oracle_tables, mode, seed, fourth, monkey
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("live", [True, False])
 @pytest.mark.parametrize("mode,n_frames", [(1, 4), (0, 3)])
-def test_movie_paced_generators_are_single_launches(O, oracle_tables, mode, n_frames):
+def test_movie_paced_generators_are_single_launches(O, oracle_tables, mode, n_frames, live, monkeypatch):
     """Driven exactly as movie.Movie.encode + emit_stream drive it (movie.py:56-150: tick() every audio sample, a new
     generator per frame and per bank flip, one next() per sample), the default Video sizes every speculative launch to
     what the caller then pulls: no roll-back, one launch per generator -- and the reference's opcodes."""
@@ -399,13 +407,15 @@ def test_movie_paced_generators_are_single_launches(O, oracle_tables, mode, n_fr
     random.seed(11)
     np.random.seed(12)
     pal = palette.Palette.NTSC
+    monkeypatch.setattr(video.Video, "LIVE", live)    # (live hand-over of the opcodes while the kernel runs, or after it has ended)
     v = video.Video(_FG(), ticks_per_second=14700., mode=video_mode.VideoMode.DHGR if mode else video_mode.VideoMode.HGR, palette=pal)
     assert v.SPECULATE is None
     ov = O.Video(mode, oracle_tables.get(mode, 5), seed_py=11, seed_np=12)
-    calls = {"rollback": 0, "encode": 0}
-    rb, en = v._enc.rollback, v._enc.encode
+    calls = {"rollback": 0, "encode": 0, "live": 0}
+    rb, en, el = v._enc.rollback, v._enc.encode, v._enc.encode_live
     v._enc.rollback = lambda *a, **k: (calls.__setitem__("rollback", calls["rollback"] + 1), rb(*a, **k))[1]
     v._enc.encode = lambda *a, **k: (calls.__setitem__("encode", calls["encode"] + 1), en(*a, **k))[1]
+    v._enc.encode_live = lambda *a, **k: (calls.__setitem__("live", calls["live"] + 1), el(*a, **k))[1]
     segs = stream_batch.MovieClock(bool(mode)).segments(n_frames)
     ticks, stream_pos, aux, last_bank = 0, 7, False, False
     op_seq, target, got, pulled = None, None, [], []
@@ -449,7 +459,8 @@ def test_movie_paced_generators_are_single_launches(O, oracle_tables, mode, n_fr
         want.append(ov.next(k))
     assert (np.array(got, np.uint8) == np.concatenate(want)).all()
     assert calls["rollback"] == 0, calls
-    assert calls["encode"] == len(segs), (calls, len(segs))
+    assert calls["encode"] + calls["live"] == len(segs), (calls, len(segs))
+    assert (calls["live"] if live else calls["encode"]) == len(segs), calls
     # DHGR: the generator behind every bank flip inside a frame was enqueued ahead of the caller (Video.LOOKAHEAD), every
     # one of them was the one the caller then asked for, none had to be undone
     st = v.lookahead_stats

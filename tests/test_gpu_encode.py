@@ -304,3 +304,82 @@ def test_generator_advanced_a_few_opcodes_per_launch(native, O, oracle_tables, d
         enc.check()
         assert (got[:n] == exp).all(), (mode, kernel, chunk)
         enc.close()
+
+
+@pytest.mark.parametrize("mode,fourth", [(1, False), (0, False), (1, True)])
+def test_live_queue_carries_every_opcode(native, O, oracle_tables, device_tables, mode, fourth):
+    """iiv_encode_live (include/iivision.h): the call is iiv_encode -- same d_ops_out, same state -- and every opcode also
+    stands in the host queue, slot j = its six bytes | tag << 48; tags of earlier calls never validate a slot; both queues
+    work; a launch that ends short marks the slot behind its last opcode; an encoder whose options keep it off the team
+    kernel refuses before anything is launched."""
+    import torch
+    frames = _synth(mode, 3, 91 + mode)
+    sp, sn = 21, 22
+    sched = [(0, 0, 1, 292), (0, 1 if mode else 0, 1, 198), (1, 0, 1, 2000), (2, 0, 1, 7), (2, 0, 0, 300)]
+    t, s = device_tables.get(mode, 5)
+    enc = native.Encoder(mode, t, s, 1, dm=device_tables.dm[(mode, 5)])
+    if fourth:
+        enc.set_fourth_offset(True)
+    fm = torch.from_numpy(np.ascontiguousarray(frames[None, :, 0])).cuda()
+    fa = torch.from_numpy(np.ascontiguousarray(frames[None, :, 1])).cuda() if mode == 1 else None
+    py, npw = _seed_states(O, sp, sn)
+    enc.set_state_all(native.STATE_RNG_PY, py[None])
+    enc.set_state_all(native.STATE_RNG_NP, npw[None])
+    ov = O.Video(mode, oracle_tables.get(mode, 5), seed_py=sp, seed_np=sn)
+    ov.set_fourth_offset(fourth)
+    queues = [enc.live_queue(0), enc.live_queue(1)]
+    assert len(queues[0]) >= 2048 and not queues[0].any() and not queues[1].any()
+    ops_dev = torch.empty((1, 2048, 6), dtype=torch.uint8, device="cuda")
+    for j, (f, a, r, k) in enumerate(sched):
+        slot, tag = j & 1, 1000 + j
+        enc.encode_live(fm, fa, (f, a, r, k), ops_dev, slot, tag)
+        enc.check()
+        if r:
+            ov.encode_frame(frames[f, 0], frames[f, 1] if mode else None, a)
+        want = ov.next(k)
+        got = ops_dev[0, :k].cpu().numpy()
+        assert (got == want).all(), (j, "d_ops_out")
+        q = queues[slot][:k].copy()
+        assert ((q >> np.uint64(48)) == tag).all(), (j, "tags")
+        assert (q.view(np.uint8).reshape(k, 8)[:, :6] == want).all(), (j, "queue rows")
+        if k < len(queues[slot]):
+            assert int(queues[slot][k]) >> 48 != tag    # (nothing behind the last opcode)
+    assert (enc.get_state(native.STATE_UP_MAIN) == ov.update_priority(0)).all()
+    # a launch that ends short of its opcodes: the reference's assert at video.py:137 (DHGR: a content byte with the palette bit)
+    if mode == 1 and not fourth:
+        bad = frames[:1].copy()
+        bad[0, 0, np.arange(64) % 32, (np.arange(64) * 37) % 120] |= 0x80    # (64 bytes: one of them is popped within the launch)
+        fmb = torch.from_numpy(np.ascontiguousarray(bad[None, :, 0])).cuda()
+        fab = torch.from_numpy(np.ascontiguousarray(bad[None, :, 1])).cuda()
+        enc.snapshot(0)
+        enc.encode_live(fmb, fab, (0, 0, 1, 2048), ops_dev, 0, 77)
+        with pytest.raises(AssertionError):
+            enc.check()
+        q = queues[0][:2048].copy()
+        valid = (q >> np.uint64(48)) == 77
+        n_ok = int(valid.argmin())
+        assert 0 < n_ok < 2048 and not valid[n_ok:].any()
+        rows = q[:n_ok].view(np.uint8).reshape(n_ok, 8)
+        assert rows[-1, 0] == 0xFF and (rows[:-1, 0] < 64).all()     # the end mark behind n_ok - 1 opcodes
+        # ... which are the opcodes the exact path yields before it raises
+        enc.rollback(0)
+        ops = enc.encode(fmb, fab, [(0, 0, 1, n_ok - 1)])
+        enc.check()
+        assert (ops[0].cpu().numpy() == rows[:-1, :6]).all()
+    enc.close()
+    # options that keep the launches off the team kernel: refused, nothing launched, the generator bookkeeping untouched
+    enc = native.Encoder(mode, t, s, 1, dm=device_tables.dm[(mode, 5)])
+    enc.set_greedy_kernel("plain")
+    enc.live_queue(0)
+    enc.set_state_all(native.STATE_RNG_PY, py[None])
+    enc.set_state_all(native.STATE_RNG_NP, npw[None])
+    with pytest.raises(native.IIVError) as ei:
+        enc.encode_live(fm, fa, (0, 0, 1, 50), ops_dev, 0, 5)
+    assert ei.value.code == native.ERR_INVALID
+    ov = O.Video(mode, oracle_tables.get(mode, 5), seed_py=sp, seed_np=sn)
+    ov.set_fourth_offset(False)
+    ov.encode_frame(frames[0, 0], frames[0, 1] if mode else None, 0)
+    ops = enc.encode(fm, fa, [(0, 0, 1, 50)])
+    enc.check()
+    assert (ops[0].cpu().numpy() == ov.next(50)).all()
+    enc.close()

@@ -53,7 +53,11 @@ def run(budget):
                     if dhgr:
                         aux = not aux
                     stream_pos += 4
-            return n_frames / (time.perf_counter() - t0)
+            dt = time.perf_counter() - t0
+            ls = getattr(v, "live_stats", None)
+            if ls:
+                print("   live hand-over: %s; per frame: %.0f us in all, %.0f us waiting for the device" % (ls, 1e6 * dt / n_frames, 1e6 * ls["wait_s"] / n_frames), file=sys.__stdout__)
+            return n_frames / dt
         for (fr, ia, _, k) in segs:
             gen = v.encode_frame(target_of(fr), is_aux=bool(ia), **({"budget": k} if budget else {}))
             for _ in range(k):
