@@ -977,12 +977,13 @@ def _dropin_video(args, n_frames=20):
                         if dhgr else screen.HGRBitmap(main_memory=main, palette=pal))
         return tgts[fr]
 
-    def run(budget, lookahead=True):
+    def run(budget, lookahead=True, live=True):
         random.seed(1)
         np.random.seed(1)
         v = video.Video(FrameGrabber(), ticks_per_second=14700., palette=pal,
                         mode=video_mode.VideoMode.DHGR if dhgr else video_mode.VideoMode.HGR)
         v.LOOKAHEAD = lookahead
+        v.LIVE = live
         tgts = {}
         t0 = time.perf_counter()
         with contextlib.redirect_stdout(io.StringIO()):
@@ -1011,17 +1012,25 @@ def _dropin_video(args, n_frames=20):
                         if dhgr:
                             aux = not aux
                         stream_pos += 4
+        dt = time.perf_counter() - t0
         stats.update(getattr(v, "lookahead_stats", {}))
-        return n_frames / (time.perf_counter() - t0)
+        ls = getattr(v, "live_stats", None)
+        if ls and live and not budget:
+            live_stats.update({"launches": ls["launches"], "polls": ls["takes"], "polls_that_waited": ls["waits"],
+                               "us_per_frame_waiting_for_the_device": round(1e6 * ls["wait_s"] / n_frames, 1)})
+        return n_frames / dt
 
-    stats = {}
+    stats, live_stats = {}, {}
     try:
         run(False)   # (warm-up: table build, first launches)
-        return {"value": run(False), "lookahead": dict(stats), "without_lookahead": run(False, lookahead=False), "with_budget": run(True),
+        return {"value": run(False), "lookahead": dict(stats), "live": dict(live_stats),
+                "without_live": run(False, live=False), "without_lookahead": run(False, lookahead=False), "with_budget": run(True),
                 "unit": "frames/s", "frames": n_frames,
                 "what": "video.Video driven from Python as movie.Movie.encode drives it (tick() per audio sample, a generator per "
                         "frame and bank flip, one next() per opcode), %s, one clip; lookahead: the generators behind a bank flip enqueued ahead of the caller "
-                        "(Video.LOOKAHEAD) and what became of them; with_budget: encode_frame(..., budget=k)" % args.mode}
+                        "(Video.LOOKAHEAD) and what became of them; live: the opcodes handed out while the kernel produces them (Video.LIVE, "
+                        "iiv_encode_live: a queue in coherent host memory) -- launches, polls of the queue and how long they waited; "
+                        "with_budget: encode_frame(..., budget=k)" % args.mode}
     except Exception as e:
         return {"value": None, "error": repr(e)}
 

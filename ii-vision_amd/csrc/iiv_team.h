@@ -42,6 +42,13 @@
 namespace iiv {
 
 constexpr unsigned long long kLiveEnd = 0xffull;   // byte 0 of a live-queue slot: "the launch ended here, short of its n_ops" (a page byte is 32..63)
+// one slot of the live queue: a relaxed atomic store at SYSTEM scope -- global_store_dwordx2 ... sc0 sc1, written through to
+// host memory at once (a plain or nontemporal store stays in the L2 until the kernel's end: measured -- the host then sees a
+// launch's opcodes all together)
+__device__ __forceinline__ void live_put(unsigned long long *slot, unsigned long long v)
+{
+    __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 constexpr int kScoringWaves = 8;            // waves 0..6 score, wave 7 generates MT19937 blocks; further waves only
 constexpr int kScorers = kScoringWaves - 1;  // follow the rounds
 // a round reads < 623 + kScorers * 258 + 2 words past block 0's start (7 scorers: 2431 -> 4 blocks; 15: 4495 -> 8)
@@ -95,7 +102,7 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
 
     if (!S.gen_active || S.error) {
         if (tid == 0 && !S.error) S.error = kErrNoGenerator;
-        if (tid == 0 && lq) __builtin_nontemporal_store(lq_tag | kLiveEnd, lq);
+        if (tid == 0 && lq) live_put(lq, lq_tag | kLiveEnd);
         return;
     }
     for (int i = tid; i < 256; i += kTeamThreads) {
@@ -368,10 +375,9 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
                 q[4] = (uint8_t)y2e;
                 q[5] = (uint8_t)(FOUR ? y3e : x);
                 if (lq)
-                    __builtin_nontemporal_store(lq_tag | (unsigned long long)(uint32_t)(p + 32) | ((unsigned long long)c << 8) |
-                                                    ((unsigned long long)(uint32_t)x << 16) | ((unsigned long long)(uint32_t)y1e << 24) |
-                                                    ((unsigned long long)(uint32_t)y2e << 32) | ((unsigned long long)(uint32_t)(FOUR ? y3e : x) << 40),
-                                                lq + op_at);
+                    live_put(lq + op_at, lq_tag | (unsigned long long)(uint32_t)(p + 32) | ((unsigned long long)c << 8) |
+                                             ((unsigned long long)(uint32_t)x << 16) | ((unsigned long long)(uint32_t)y1e << 24) |
+                                             ((unsigned long long)(uint32_t)y2e << 32) | ((unsigned long long)(uint32_t)(FOUR ? y3e : x) << 40));
             }
         }
     };
@@ -655,7 +661,7 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
         for (int i = done + lane; i < n_ops; i += 64) {  // video.py:249-251
             uint8_t *q = out + (size_t)i * 6;
             q[0] = 32; q[1] = (uint8_t)pad_content; q[2] = 0; q[3] = 0; q[4] = 0; q[5] = 0;
-            if (lq) __builtin_nontemporal_store(lq_tag | 32ull | ((unsigned long long)(pad_content & 0xffu) << 8), lq + i);
+            if (lq) live_put(lq + i, lq_tag | 32ull | ((unsigned long long)(pad_content & 0xffu) << 8));
         }
         pad_ops += (unsigned long long)(n_ops - done);
         done = n_ops;
@@ -676,7 +682,7 @@ __device__ __forceinline__ void team_body(StreamState *__restrict__ states, cons
         S.ops += (unsigned long long)done;
         S.pad_ops += pad_ops;
         if (err && S.error == 0) S.error = err;
-        if (lq && done < n_ops) __builtin_nontemporal_store(lq_tag | kLiveEnd, lq + done);
+        if (lq && done < n_ops) live_put(lq + done, lq_tag | kLiveEnd);
     }
 }
 

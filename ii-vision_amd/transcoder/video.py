@@ -325,7 +325,7 @@ class Video:
         self._live_tag = 0
         self._brief_event = None
         # (launches handed out live; polls of the queue; polls that found nothing and waited, and for how long)
-        self.live_stats = {"launches": 0, "takes": 0, "waits": 0, "wait_s": 0.0}
+        self.live_stats = {"launches": 0, "takes": 0, "waits": 0, "wait_s": 0.0, "first_wait_s": 0.0}
 
     # ---- the reference's public attributes; reading one settles any speculation first
     def _settled(name):  # noqa: N805
@@ -592,8 +592,11 @@ class Video:
                     self._enc.check()     # (synchronises; raises what the device reports)
                     if (int(q[k]) >> 48) != tag:
                         raise RuntimeError("live hand-over: opcode %d of %d never arrived" % (k, n))
+            dt = time.perf_counter() - t0
             st["waits"] += 1
-            st["wait_s"] += time.perf_counter() - t0
+            st["wait_s"] += dt
+            if k == 0:
+                st["first_wait_s"] += dt     # (of that: for a launch's first opcode -- its prologue, mostly)
         w = q[k:n]
         ok = (w >> np.uint64(48)) == np.uint64(tag)
         r = len(w) if ok.all() else int(ok.argmin())

@@ -299,9 +299,13 @@ def test_reseeding_between_generators_is_carried_to_the_device(O, oracle_tables)
     assert (v.update_priority == ov.update_priority(0)).all() and (v.aux_update_priority == ov.update_priority(1)).all()
 
 
+# (IIV_DROPIN_FUZZ=N: N more seeds, both modes alternating, a third of them with the fourth offset -- profiles/r06_dropin_fuzz.txt)
+_MORE = [(s & 1, 100 + s, (s % 3 == 0)) for s in range(int(os.environ.get("IIV_DROPIN_FUZZ", "0")))]
+
+
 @pytest.mark.parametrize("mode,seed,fourth", [(1, 1, False), (1, 2, False), (0, 3, False), (0, 4, False), (1, 5, False), (0, 6, False),
                                               (1, 7, True), (0, 8, True), (1, 9, "strict"), (0, 10, "strict"),
-                                              (1, 11, "nolive"), (0, 12, "nolive"), (1, 13, False), (0, 14, False)])
+                                              (1, 11, "nolive"), (0, 12, "nolive"), (1, 13, False), (0, 14, False)] + _MORE)
 def test_video_random_interleavings(O, oracle_tables, mode, seed, fourth, monkeypatch):
     """What a caller of the reference's Video may do between and inside generators, in random order and with random
     Video.SPECULATE: start a generator, pull a few or many opcodes, abandon it, look at a state attribute in the middle
