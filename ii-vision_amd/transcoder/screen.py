@@ -192,10 +192,26 @@ class Bitmap:
         self.aux_memory = aux_memory
         self.PACKED_BITS = self.HEADER_BITS + self.BODY_BITS + self.FOOTER_BITS
         self.SCREEN_BYTES = np.uint64(len(self.BYTE_MASKS))
-        self.packed = np.empty(shape=(32, 128), dtype=np.uint64)
-        self._pack()
+        # `packed` is what the reference computes here (screen.py:151-152: self._pack()); this mirror computes it -- from the
+        # bytes as they are NOW -- when it is first looked at: a Bitmap that is only handed to Video.encode_frame as a target
+        # (frame_grabber.py:111-115 makes one per frame) is read through its memory maps by the kernels, never through
+        # `packed`, and the device round trip of the packing kernel is then a tenth of the drop-in frame's time for nothing
+        self._packed = None
+        self._pack_src = (np.array(main_memory.page_offset, dtype=np.uint8),
+                          np.array(aux_memory.page_offset, dtype=np.uint8) if aux_memory is not None else None)
 
     # ---- packing (device)
+    @property
+    def packed(self) -> np.ndarray:
+        if self._packed is None:
+            self._packed = native.pack(self.MODE, *self._pack_src)
+            self._pack_src = None
+        return self._packed
+
+    @packed.setter
+    def packed(self, value) -> None:
+        self._packed, self._pack_src = value, None
+
     def _pack(self) -> None:
         """Pack the memory map(s) into (32,128) uint64 columns on the GPU (K4)."""
         aux = self.aux_memory.page_offset if self.aux_memory is not None else None

@@ -49,6 +49,28 @@ def test_video_test_diff_weights():
     assert expect0 == diff[0, 0] and expect2 == diff[0, 1]
 
 
+def test_bitmap_packed_is_the_construction_time_screen():
+    """screen.py:151-152 packs in __init__; the mirror packs when `packed` is first read (a target handed to
+    Video.encode_frame never is) -- from the bytes as they were at construction, whatever happened to the maps since."""
+    import palette
+    import screen
+    rng = np.random.default_rng(8)
+    holes = (np.arange(256) & 127) >= 120
+    a, b = (rng.integers(0, 128, (32, 256), dtype=np.uint8) for _ in range(2))
+    a[:, holes] = b[:, holes] = 0
+    main, aux = screen.MemoryMap(1, a.copy()), screen.MemoryMap(1, b.copy())
+    eager = screen.DHGRBitmap(palette=palette.Palette.NTSC, main_memory=main, aux_memory=aux)
+    want = eager.packed.copy()
+    lazy = screen.DHGRBitmap(palette=palette.Palette.NTSC, main_memory=main, aux_memory=aux)
+    main.page_offset[3, 7] ^= 0x55
+    aux.page_offset[...] = 0
+    assert (lazy.packed == want).all()
+    lazy._pack()      # (an explicit _pack() reads the maps as they are now, as the reference's does)
+    assert (lazy.packed != want).any()
+    fresh = screen.DHGRBitmap(palette=palette.Palette.NTSC, main_memory=main, aux_memory=aux)
+    assert (lazy.packed == fresh.packed).all()
+
+
 @pytest.mark.parametrize("name", ["HGR", "DHGR"])
 def test_bitmap_apply_and_delta(golden, name):
     """screen.*Bitmap: pack, apply() neighbour propagation, compute_delta_page,
