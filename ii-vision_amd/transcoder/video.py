@@ -816,6 +816,18 @@ class Video:
                         self._brief_fresh = False
                         speculative, chunk = False, 1
                         continue
+                elif budget and chunk >= 32 and not self.STRICT_SYNC:
+                    # a promised budget: one launch, nothing to roll back -- handed out while it runs, too
+                    self._brief_fresh = False
+                    self._brief_event = None
+                    self._launch_buffers(chunk)
+                    live = self._launch_live(token, token.is_aux, restart, chunk, 0, self._ops_dev, self._pinned_brief())
+                    if live is not None:
+                        self._brief_fresh = True
+                        self._brief_applied = False
+                        self._brief_event = live["event"]
+                    else:
+                        ops = self._launch(token, restart, chunk)
                 else:
                     ops = self._launch(token, restart, chunk)
                 self._live = token
@@ -829,6 +841,19 @@ class Video:
                     self._pending = rec
                     if paced and self.LOOKAHEAD and self.mode == VideoMode.DHGR:
                         self._look_ahead(token, produced, 1 - slot)
+                if live is not None and rec is None:
+                    # (a promised budget, live: nothing is pending -- the state may run ahead of the caller, that is the promise)
+                    tally = _Chunk(token, restart, produced, prev_live, slot)
+                    ended = False
+                    while tally.base < produced and not ended:
+                        items, ended = self._live_take(live, tally.base)
+                        yield from tally.hand_out(items)
+                    if tally.base < produced:
+                        self._enc.check()     # the launch ended short: raises what the device reports, at the next() it belongs to
+                        raise RuntimeError("live hand-over: the launch ended after %d of %d opcodes" % (tally.base, produced))
+                    self._ops_done += produced
+                    chunk = 1
+                    continue
                 if live is not None:
                     # hand out what has arrived, as it arrives
                     ended = False
