@@ -574,7 +574,9 @@ class Video:
         ev = torch.cuda.Event()
         ev.record()
         self.live_stats["launches"] += 1
-        return dict(q=qs[qslot], tag=self._live_tag, n=int(n_ops), event=ev)
+        q = qs[qslot]
+        # (views of the queue: the tags as uint16 -- the top quarter of every slot --, the slots as bytes)
+        return dict(q=q, q16=q.view(np.uint16).reshape(-1, 4)[:, 3], q8=q.view(np.uint8).reshape(-1, 8), tag=self._live_tag, n=int(n_ops), event=ev)
 
     def _live_take(self, lv, k):
         """Opcodes k .. of a live launch that have arrived -- at least one: this waits for slot k -- as a list of
@@ -597,16 +599,14 @@ class Video:
             st["wait_s"] += dt
             if k == 0:
                 st["first_wait_s"] += dt     # (of that: for a launch's first opcode -- its prologue, mostly)
-        w = q[k:n]
-        ok = (w >> np.uint64(48)) == np.uint64(tag)
-        r = len(w) if ok.all() else int(ok.argmin())
-        b = w[:r].view(np.uint8).reshape(r, 8)
-        pages = b[:, 0]
-        ended = False
-        if pages.max() == 0xFF:
-            r = int((pages == 0xFF).argmax())
-            ended = True
-            b = b[:r]
+        # the slots from k on that carry the tag, up to the first that does not (the waves of a round commit in any order)
+        ok = lv["q16"][k:n] == tag
+        r = int(ok.argmin()) or len(ok)      # (slot k carries it: argmin is 0 only when all of them do)
+        b = lv["q8"][k:k + r]
+        # an end mark is the last slot its launch writes: if it has arrived it is the last of these
+        ended = int(b[r - 1, 0]) == 0xFF
+        if ended:
+            b = b[:r - 1]
         return list(zip(b[:, 0].tolist(), b[:, 1].tolist(), b[:, 2:6].tolist())), ended
 
     def _look_ahead(self, token, n_live, slot):
