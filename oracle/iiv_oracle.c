@@ -699,6 +699,9 @@ struct orc_video {
     uint64_t draws_py, draws_np;
     int joint;               /* f4: joint choice of the content byte (not the reference's behaviour) */
     int fourth;              /* f4: a real fourth offset per opcode (video.py:181 with 4 for 3; not the reference's behaviour) */
+    /* diagnostic (tools/joint_prune_rate.py): what a pruning of the joint step's bytes would skip; see joint_prune_stats */
+    int joint_stats_on;
+    uint64_t joint_stats[6];
     /* generator */
     int gen_active, gen_started, gen_is_aux, gen_exhausted, gen_form;
     uint8_t tgt[2][8192];
@@ -740,6 +743,14 @@ void orc_video_destroy(orc_video *v)
 }
 
 void orc_video_set_joint(orc_video *v, int joint) { v->joint = joint ? 1 : 0; }
+/* diagnostic: switch joint_prune_stats on / read its six counters (steps, eligible bytes, of those with dw == 0, bytes a
+ * descending-dw walk looks at before its bound stops it, bytes behind the 16 largest, of those prunable by the bound reached there) */
+void orc_video_joint_stats(orc_video *v, int on, uint64_t out[6])
+{
+    v->joint_stats_on = on ? 1 : 0;
+    if (out)
+        memcpy(out, v->joint_stats, sizeof(v->joint_stats));
+}
 /* f4 -- the opcode's fourth offset.  The player stores every opcode's content byte at FOUR offsets
  * (opcodes.py: tick opcodes), and video.py:146 says "Need to find 3 more offsets to fill this opcode", but the
  * loop's exit test `if len(offsets) == 3: break` (video.py:180-181) counts the primary: it stops after TWO more, and
@@ -940,8 +951,85 @@ static void emit_pad(orc_video *v, uint8_t *out)
  * the THREE smallest negative deltas: R(c) = (dw[primary] - nd_c[primary]) - (d1 + d2 + d3).
  * Everything else (candidate order, nonce draws, re-queueing of the extra offsets) is the
  * reference's, applied to the chosen byte. */
+/* Diagnostic, not part of any parity path: how many of a joint step's bytes could be PRUNED.  The joint score of a byte
+ * value c takes its two (three) smallest negative deltas over the page's eligible bytes; delta(y, c) = nd - dw[y] >= -dw[y],
+ * so a byte y cannot enter any value's top two (three) once every value's second (third) smallest delta is already <= -dw[y].
+ * Walking the eligible bytes in DESCENDING dw, the walk can stop at the first byte for which that holds: everything behind it
+ * is pruned.  Counted per step: eligible bytes (priority != 0, not the primary), of those with dw == 0 (no delta of theirs is
+ * negative: prunable without any bound), bytes the walk looks at before it stops, and -- a weaker kernel-friendly form --
+ * the bytes a walk in plain offset order could skip given the bound reached after a first pass over the 16 largest. */
+static void joint_prune_stats(orc_video *v, int page, int offset, int ia)
+{
+    const int bits = orc_masked_bits(v->mode);
+    const int32_t *up = v->up[ia];
+    const int ncontent = v->mode == ORC_DHGR ? 128 : 256;
+    const uint64_t *row = v->tgt_packed + page * 128;
+    const int k_th = v->fourth ? 3 : 2;
+    int order[256], n = 0, n_zero = 0;
+    for (int y = 0; y < 256; y++) {
+        if (y == offset || up[page * 256 + y] == 0)
+            continue;
+        if (v->dw[page * 256 + y] == 0)
+            n_zero++;
+        order[n++] = y;
+    }
+    for (int i = 1; i < n; i++) { /* insertion sort, dw descending */
+        int y = order[i], j = i;
+        while (j > 0 && v->dw[page * 256 + order[j - 1]] < v->dw[page * 256 + y]) {
+            order[j] = order[j - 1];
+            j--;
+        }
+        order[j] = y;
+    }
+    int32_t m[256][3];
+    memset(m, 0, sizeof(m));
+    int looked = 0, after16 = -1;
+    for (int i = 0; i < n; i++) {
+        int y = order[i];
+        int32_t bound = INT32_MIN; /* the weakest k-th smallest delta over all byte values */
+        for (int c = 0; c < ncontent; c++)
+            if (m[c][k_th - 1] > bound)
+                bound = m[c][k_th - 1];
+        if (i == 16) { /* bytes (of all eligible) whose -dw is already >= the bound reached after the 16 largest */
+            after16 = 0;
+            for (int j = 16; j < n; j++)
+                if (-v->dw[page * 256 + order[j]] >= bound)
+                    after16++;
+        }
+        if (-v->dw[page * 256 + y] >= bound)
+            break;
+        looked++;
+        int bo = orc_byte_offset(v->mode, y, ia);
+        uint64_t t = orc_mask_and_shift(v->mode, row[y / 2], bo);
+        for (int c = 0; c < ncontent; c++) {
+            uint64_t sv = orc_mask_and_shift(v->mode, orc_masked_update(v->mode, bo, row[y / 2], (uint8_t)c), bo);
+            int32_t d = (int32_t)v->table[((size_t)bo << (2 * bits)) + ((sv << bits) + t)] - v->dw[page * 256 + y];
+            if (d >= 0)
+                continue;
+            if (d < m[c][0]) {
+                m[c][2] = m[c][1];
+                m[c][1] = m[c][0];
+                m[c][0] = d;
+            } else if (d < m[c][1]) {
+                m[c][2] = m[c][1];
+                m[c][1] = d;
+            } else if (d < m[c][2]) {
+                m[c][2] = d;
+            }
+        }
+    }
+    v->joint_stats[0] += 1;
+    v->joint_stats[1] += (uint64_t)n;
+    v->joint_stats[2] += (uint64_t)n_zero;
+    v->joint_stats[3] += (uint64_t)looked;
+    v->joint_stats[4] += (uint64_t)(n > 16 ? n - 16 : 0);
+    v->joint_stats[5] += (uint64_t)(after16 > 0 ? after16 : 0);
+}
+
 static uint8_t choose_content_joint(orc_video *v, int page, int offset, int ia, int32_t *residual)
 {
+    if (v->joint_stats_on)
+        joint_prune_stats(v, page, offset, ia);
     const int bits = orc_masked_bits(v->mode);
     const int32_t *up = v->up[ia];
     const int ncontent = v->mode == ORC_DHGR ? 128 : 256;

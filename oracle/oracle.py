@@ -136,6 +136,8 @@ def _declare(L):
     L.orc_video_out_of_work.argtypes = [C.c_void_p, C.c_int]
     L.orc_video_reset_out_of_work.argtypes = [C.c_void_p]
     L.orc_video_set_joint.argtypes = [C.c_void_p, C.c_int]
+    L.orc_video_joint_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+    L.orc_video_joint_stats.restype = None
     L.orc_video_set_fourth_offset.argtypes = [C.c_void_p, C.c_int]
     L.orc_video_encode_frame.argtypes = [C.c_void_p, u8p, u8p, C.c_int]
     L.orc_video_next.restype = C.c_int
@@ -369,6 +371,12 @@ class Video:
     def set_joint(self, joint):
         """f4: joint choice of the content byte (README.md:212-215); not reference behaviour."""
         self._L.orc_video_set_joint(self._h, 1 if joint else 0)
+
+    def joint_stats(self, on=True):
+        """diagnostic (iiv_oracle.c: joint_prune_stats): switch the counters on / off and read them"""
+        out = (C.c_uint64 * 6)()
+        self._L.orc_video_joint_stats(self._h, 1 if on else 0, out)
+        return dict(zip(("steps", "eligible", "eligible_dw0", "looked_at", "behind_16", "behind_16_prunable"), [int(x) for x in out]))
 
     def set_fourth_offset(self, fourth):
         """f4: up to three extra offsets per opcode (video.py:181 with 4 for 3); not reference behaviour."""
