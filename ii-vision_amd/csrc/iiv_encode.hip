@@ -57,6 +57,9 @@ struct GenState {
     int is_aux, frame;
 };
 
+constexpr int kSmallSlots = 4;          // iiv_encoder_set_state_async's staging ring
+constexpr size_t kSmallBytes = 2560;    // >= 625 words
+
 struct Encoder {
     int mode;
     int n_streams;
@@ -80,9 +83,13 @@ struct Encoder {
     int fourth_offset;      // IIV_OPT_FOURTH_OFFSET
     StreamState *d_states;
     StreamState *d_snapshot[2];  // iiv_encoder_snapshot copies (lazily allocated; slot 1: iiv_encoder_snapshot_slot)
+    // iiv_encoder_set_state_async: a small ring of pinned staging slots (one allocation), an event behind each slot's copies
+    uint8_t *h_small[1];
+    hipEvent_t small_ev[4];
+    int small_slot;
     // live hand-over (iiv_encode_live): two opcode queues in coherent host memory (lazily allocated), and the one / the tag
     // the launches of the call in progress write to (NULL outside such a call)
-    unsigned long long *h_live[2], *live_now;
+    unsigned long long *h_live[2], *d_live[2], *live_now;   // (d_live: the same memory as the device addresses it)
     uint32_t live_tag;
     // generator bookkeeping: one entry while every stream has run the same schedule, else one per stream
     std::vector<GenState> gens, snap_gens[2];
@@ -264,6 +271,9 @@ void encoder_destroy(Encoder *e)
         if (e->d_snapshot[k]) (void)hipFree(e->d_snapshot[k]);
         if (e->h_live[k]) (void)hipHostFree(e->h_live[k]);
     }
+    if (e->h_small[0]) (void)hipHostFree(e->h_small[0]);
+    for (int k = 0; k < kSmallSlots; k++)
+        if (e->small_ev[k]) (void)hipEventDestroy(e->small_ev[k]);
     if (e->d_strings) (void)hipFree(e->d_strings);
     if (e->d_hgr_dots) (void)hipFree(e->d_hgr_dots);
     if (e->d_dw_pieces) (void)hipFree(e->d_dw_pieces);
@@ -314,7 +324,10 @@ int encoder_create(int mode, const uint16_t *d_table, const uint16_t *d_store, c
     e->d_joint_l = e->d_joint_r = nullptr;
     e->d_brief = nullptr;
     e->d_states = e->d_snapshot[0] = e->d_snapshot[1] = nullptr;
-    e->h_live[0] = e->h_live[1] = e->live_now = nullptr;
+    e->h_live[0] = e->h_live[1] = e->d_live[0] = e->d_live[1] = e->live_now = nullptr;
+    e->h_small[0] = nullptr;
+    for (int k = 0; k < kSmallSlots; k++) e->small_ev[k] = nullptr;
+    e->small_slot = 0;
     e->live_tag = 0;
     e->d_strings = nullptr;
     e->d_hgr_dots = nullptr;
@@ -594,6 +607,42 @@ int encoder_set_state(Encoder *e, int s0, int n, int what, const void *buf, size
         if (int rc = hip_check(hipGetLastError(), "compact_up_kernel launch")) return rc;
         return hip_check(hipDeviceSynchronize(), "compact_up sync");
     }
+    return IIV_OK;
+}
+
+// The small items of ONE stream, enqueued on `st` behind the launches already there -- no device-wide synchronisation, no
+// blocking copy: the bytes are taken into a pinned slot before the call returns.
+int encoder_set_state_async(Encoder *e, int s, int what, const void *buf, size_t bytes, hipStream_t st)
+{
+    if (!e || !buf || s < 0 || s >= e->n_streams) return set_error(IIV_ERR_INVALID, "set_state_async: bad argument");
+    if (what != IIV_STATE_OUT_OF_WORK && what != IIV_STATE_RNG_PY && what != IIV_STATE_RNG_NP)
+        return set_error(IIV_ERR_INVALID, "set_state_async: item %d (only OUT_OF_WORK, RNG_PY, RNG_NP)", what);
+    const size_t want = what == IIV_STATE_OUT_OF_WORK ? 8 : 625 * 4;
+    if (bytes != want) return set_error(IIV_ERR_INVALID, "set_state_async: item %d is %zu bytes, got %zu", what, want, bytes);
+    if (what != IIV_STATE_OUT_OF_WORK && ((const uint32_t *)buf)[624] > 624)
+        return set_error(IIV_ERR_INVALID, "set_state_async: RNG index %u > 624", ((const uint32_t *)buf)[624]);
+    if (!e->h_small[0]) {
+        void *p = nullptr;
+        IIV_HIP(hipHostMalloc(&p, kSmallSlots * kSmallBytes, hipHostMallocDefault));
+        e->h_small[0] = static_cast<uint8_t *>(p);
+        for (int k = 0; k < kSmallSlots; k++) IIV_HIP(hipEventCreateWithFlags(&e->small_ev[k], hipEventDisableTiming));
+        e->small_slot = -kSmallSlots;   // (the first round of the ring has nothing to wait for)
+    }
+    const int k = e->small_slot < 0 ? e->small_slot + kSmallSlots : e->small_slot;
+    if (e->small_slot >= 0) IIV_HIP(hipEventSynchronize(e->small_ev[k]));   // the copies that last used this slot are done
+    e->small_slot = e->small_slot < 0 ? e->small_slot + 1 : (e->small_slot + 1) % kSmallSlots;
+    uint8_t *slot = e->h_small[0] + (size_t)k * kSmallBytes;
+    memcpy(slot, buf, bytes);
+    uint8_t *base = reinterpret_cast<uint8_t *>(e->d_states + s);
+    if (what == IIV_STATE_OUT_OF_WORK) {
+        IIV_HIP(hipMemcpyAsync(base + offsetof(StreamState, out_of_work), slot, 8, hipMemcpyHostToDevice, st));
+    } else {
+        const size_t o_mt = what == IIV_STATE_RNG_PY ? offsetof(StreamState, mt_py) : offsetof(StreamState, mt_np);
+        const size_t o_ix = what == IIV_STATE_RNG_PY ? offsetof(StreamState, mt_py_idx) : offsetof(StreamState, mt_np_idx);
+        IIV_HIP(hipMemcpyAsync(base + o_mt, slot, 624 * 4, hipMemcpyHostToDevice, st));
+        IIV_HIP(hipMemcpyAsync(base + o_ix, slot + 624 * 4, 4, hipMemcpyHostToDevice, st));
+    }
+    IIV_HIP(hipEventRecord(e->small_ev[k], st));
     return IIV_OK;
 }
 
@@ -1049,10 +1098,12 @@ int encode(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux, int n_frames
     e->gens[0] = gs;
     if (rounds.empty()) return IIV_OK;
     if ((rc = upload_segs(e, rounds, st))) return rc;
-    if ((rc = reset_queues(e, rounds.size(), st))) return rc;
+    // (the stream counters are the LDS-shared form's: the team kernel's launches -- few streams, the drop-in Video's path,
+    // where a 4 us memset in front of every generator is felt -- do without)
+    if (!team_kernel_runs(e) && (rc = reset_queues(e, rounds.size(), st))) return rc;
     tie_stats_poll(e);
     for (size_t r = 0; r < rounds.size(); r++)
-        if ((rc = launch_round(e, d_main, d_aux, n_frames, e->d_segs + r, 0, rounds[r].need >= 0, true, rounds[r].is_aux, e->d_queue + r, d_ops,
+        if ((rc = launch_round(e, d_main, d_aux, n_frames, e->d_segs + r, 0, rounds[r].need >= 0, true, rounds[r].is_aux, e->d_queue ? e->d_queue + r : nullptr, d_ops,
                                total * 6, st)))
             return rc;
     return tie_stats_request(e, st);
@@ -1071,7 +1122,10 @@ int encoder_live_queue(Encoder *e, int slot, uint64_t **host_queue, int *capacit
         void *p = nullptr;
         IIV_HIP(hipHostMalloc(&p, (size_t)kLiveCap * 8, hipHostMallocCoherent | hipHostMallocMapped));
         memset(p, 0, (size_t)kLiveCap * 8);   // (tag 0 is never used)
+        void *dev = nullptr;
+        IIV_HIP(hipHostGetDevicePointer(&dev, p, 0));
         e->h_live[slot] = static_cast<unsigned long long *>(p);
+        e->d_live[slot] = static_cast<unsigned long long *>(dev);
     }
     *host_queue = reinterpret_cast<uint64_t *>(e->h_live[slot]);
     *capacity = kLiveCap;
@@ -1089,9 +1143,7 @@ int encode_live(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux, int n_f
     long long total = 0;
     for (int i = 0; i < n_segs; i++) total += segs[i].n_ops > 0 ? segs[i].n_ops : 0;
     if (total > kLiveCap) return set_error(IIV_ERR_INVALID, "iiv_encode_live: %lld opcodes, the queue holds %d", total, kLiveCap);
-    void *dev = nullptr;
-    IIV_HIP(hipHostGetDevicePointer(&dev, e->h_live[slot], 0));
-    e->live_now = static_cast<unsigned long long *>(dev);
+    e->live_now = e->d_live[slot];
     e->live_tag = tag;
     const int rc = encode(e, d_main, d_aux, n_frames, segs, n_segs, d_ops, st);
     e->live_now = nullptr;
@@ -1135,11 +1187,11 @@ int encode_streams(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux, int 
         }
     int rc = upload_segs(e, table, st);
     if (rc) return rc;
-    if ((rc = reset_queues(e, n_rounds, st))) return rc;
+    if (!team_kernel_runs(e) && (rc = reset_queues(e, n_rounds, st))) return rc;
     tie_stats_poll(e);
     for (size_t r = 0; r < n_rounds; r++)
         if ((rc = launch_round(e, d_main, d_aux, n_frames, e->d_segs + r * (size_t)S, 1, any_pro[r] != 0, true, bank[r] < 0 ? -1 : bank[r],
-                               e->d_queue + r, d_ops,
+                               e->d_queue ? e->d_queue + r : nullptr, d_ops,
                                ops_stride, st)))
             return rc;
     return tie_stats_request(e, st);
@@ -1263,6 +1315,12 @@ int iiv_encoder_set_state(iiv_encoder *enc, int stream_index, int what, const vo
 {
     if (!enc) return iiv::set_error(IIV_ERR_INVALID, "null encoder");
     return iiv::encoder_set_state(enc->impl, stream_index, 1, what, host_buf, bytes);
+}
+
+int iiv_encoder_set_state_async(iiv_encoder *enc, int stream_index, int what, const void *host_buf, size_t bytes, void *stream)
+{
+    if (!enc) return iiv::set_error(IIV_ERR_INVALID, "null encoder");
+    return iiv::encoder_set_state_async(enc->impl, stream_index, what, host_buf, bytes, (hipStream_t)stream);
 }
 
 int iiv_encoder_get_video_state(iiv_encoder *enc, int stream_index, iiv_video_state *host_out)

@@ -42,7 +42,7 @@ SYMBOLS = [
     "iiv_encoder_snapshot", "iiv_encoder_rollback", "iiv_encoder_snapshot_slot", "iiv_encoder_rollback_slot", "iiv_encoder_get_state", "iiv_encoder_set_state",
     "iiv_encoder_set_state_range", "iiv_encoder_get_video_state", "iiv_encoder_set_video_state",
     "iiv_encoder_get_video_brief", "iiv_encoder_get_video_brief_async",
-    "iiv_encode", "iiv_encode_streams", "iiv_encoder_live_queue", "iiv_encode_live",
+    "iiv_encode", "iiv_encode_streams", "iiv_encoder_live_queue", "iiv_encode_live", "iiv_encoder_set_state_async",
     "iiv_encoder_check", "iiv_encoder_profile", "iiv_encoder_profile_read", "iiv_encoder_input_stats",
     "iiv_encoder_launch_forms",
     "iiv_build_split_store_table", "iiv_split_table_entries", "iiv_check_split_diff_table",
@@ -143,6 +143,8 @@ def lib():
     if hasattr(L, "iiv_encode_live") or "IIV_LIB" not in os.environ:
         L.iiv_encoder_live_queue.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_int)]
         L.iiv_encode_live.argtypes = [vp, vp, vp, i32, C.POINTER(Segment), i32, vp, i32, C.c_uint32, vp]
+    if hasattr(L, "iiv_encoder_set_state_async") or "IIV_LIB" not in os.environ:
+        L.iiv_encoder_set_state_async.argtypes = [vp, i32, i32, vp, sz, vp]
     L.iiv_build_split_store_table.argtypes = [i32, vp, vp, vp, vp, vp]
     L.iiv_split_table_entries.restype = sz
     L.iiv_check_split_diff_table.argtypes = [i32, vp, vp, vp, vp]
@@ -163,7 +165,7 @@ def lib():
         L.iiv_encoder_launch_forms.argtypes = [vp, C.POINTER(C.c_int64)]
     for name in SYMBOLS:
         if "IIV_LIB" in os.environ and name in ("iiv_encoder_launch_forms", "iiv_check_diff_weight_pieces", "iiv_encoder_info", "iiv_encoder_get_video_brief_async",
-                                                 "iiv_encoder_live_queue", "iiv_encode_live") and not hasattr(L, name):
+                                                 "iiv_encoder_live_queue", "iiv_encode_live", "iiv_encoder_set_state_async") and not hasattr(L, name):
             continue   # (an older build under IIV_LIB: tools/ab_libs.sh)
         getattr(L, name)  # AttributeError if the library lacks a declared symbol
     _lib = L
@@ -526,6 +528,13 @@ class Encoder:
         shape, dt = self._ITEMS[what]
         a = np.ascontiguousarray(value, dtype=dt).reshape(shape)
         check(lib().iiv_encoder_set_state(self._h, int(stream), what, hptr(a), a.nbytes))
+
+    def set_state_async(self, what, value, stream=0):
+        """STATE_OUT_OF_WORK / STATE_RNG_PY / STATE_RNG_NP of one stream, enqueued behind the launches already on the current
+        HIP stream: no device-wide synchronisation (iiv_encoder_set_state_async)."""
+        shape, dt = self._ITEMS[what]
+        a = np.ascontiguousarray(value, dtype=dt).reshape(shape)
+        check(lib().iiv_encoder_set_state_async(self._h, int(stream), what, hptr(a), a.nbytes, stream_ptr()))
 
     def get_video_state(self, stream=0, out=None):
         out = out if out is not None else VideoState()

@@ -356,8 +356,13 @@ class Video:
         self._settle(download=False)
         self._out_of_work = value
         if not self._touched:  # the device's copy is the one the next launch reads
-            self._enc.set_state(native.STATE_OUT_OF_WORK, np.array([int(bool(value[False])), int(bool(value[True]))], np.int32))
-            # (the brief at hand stays good: the two flags are all that changed on the device, and they are known)
+            # (enqueued behind whatever is in flight: the next launch, on the same stream, reads them)
+            self._enc.set_state_async(native.STATE_OUT_OF_WORK, np.array([int(bool(value[False])), int(bool(value[True]))], np.int32))
+            # (the brief at hand stays good: the two flags are all that changed on the device, and they are known -- once it HAS
+            # arrived: a brief still on its way behind a live launch would land on top of what is written here)
+            if self._brief_event is not None:
+                self._brief_event.synchronize()
+                self._brief_event = None
             self._vb.out_of_work[0] = int(bool(value[False]))
             self._vb.out_of_work[1] = int(bool(value[True]))
 
@@ -472,8 +477,8 @@ class Video:
         py = np.frombuffer(pyraw, dtype=np.uint32).copy()
         raw = _np_rng_raw()
         rn = np.frombuffer(raw, dtype=np.uint32).copy()
-        self._enc.set_state(native.STATE_RNG_PY, py)
-        self._enc.set_state(native.STATE_RNG_NP, rn)
+        self._enc.set_state_async(native.STATE_RNG_PY, py)
+        self._enc.set_state_async(native.STATE_RNG_NP, rn)
         self._brief_fresh = False
         self._rng_seen = (pyraw, raw)
 

@@ -284,6 +284,10 @@ int iiv_encoder_info(iiv_encoder *enc, int *mode, int *n_streams);
 #define IIV_STATE_COUNTERS 8 /* get only: u64[4] = draws_py, draws_np, ops, pad_ops */
 int iiv_encoder_get_state(iiv_encoder *enc, int stream_index, int what, void *host_buf, size_t bytes);
 int iiv_encoder_set_state(iiv_encoder *enc, int stream_index, int what, const void *host_buf, size_t bytes);
+/* The small items -- IIV_STATE_OUT_OF_WORK (movie.py:96 resets the flags at every frame), IIV_STATE_RNG_PY, IIV_STATE_RNG_NP -- of one
+ * stream, enqueued on `stream` behind the launches already there: no device-wide synchronisation, no blocking copy (the
+ * drop-in Video sets the flags once per frame, between two generators).  host_buf is read before the call returns. */
+int iiv_encoder_set_state_async(iiv_encoder *enc, int stream_index, int what, const void *host_buf, size_t bytes, void *stream);
 /* the same item of n_streams consecutive streams in one upload: host_buf holds n_streams
  * items of bytes_per_stream back to back (e.g. the seeds of every stream of a batch) */
 int iiv_encoder_set_state_range(iiv_encoder *enc, int first_stream, int n_streams, int what, const void *host_buf,

@@ -383,3 +383,45 @@ def test_live_queue_carries_every_opcode(native, O, oracle_tables, device_tables
     enc.check()
     assert (ops[0].cpu().numpy() == ov.next(50)).all()
     enc.close()
+
+
+def test_set_state_async_is_set_state_in_stream_order(native, O, oracle_tables, device_tables):
+    """iiv_encoder_set_state_async (out_of_work flags, both RNG states): what iiv_encoder_set_state does, enqueued behind the
+    launches already on the stream -- a generator launched after it sees the new values, one launched before does not."""
+    import torch
+    mode = 1
+    frames = _synth(mode, 2, 17)
+    t, s = device_tables.get(mode, 5)
+    fm = torch.from_numpy(np.ascontiguousarray(frames[None, :, 0])).cuda()
+    fa = torch.from_numpy(np.ascontiguousarray(frames[None, :, 1])).cuda()
+    runs = []
+    for use_async in (False, True):
+        enc = native.Encoder(mode, t, s, 1, dm=device_tables.dm[(mode, 5)])
+        put = enc.set_state_async if use_async else enc.set_state
+        py, npw = _seed_states(O, 5, 6)
+        put(native.STATE_RNG_PY, py)
+        put(native.STATE_RNG_NP, npw)
+        a = enc.encode(fm, fa, [(0, 0, 1, 300)]).cpu().numpy()
+        py2, npw2 = _seed_states(O, 7, 8)
+        for _ in range(6):      # (more calls than the staging ring has slots)
+            put(native.STATE_RNG_PY, py2)
+            put(native.STATE_RNG_NP, npw2)
+        put(native.STATE_OUT_OF_WORK, np.array([1, 1], np.int32))
+        b = enc.encode(fm, fa, [(1, 1, 1, 300)]).cpu().numpy()
+        enc.check()
+        runs.append((a, b, enc.get_state(native.STATE_OUT_OF_WORK).copy(), enc.get_state(native.STATE_RNG_PY).copy(),
+                     enc.get_state(native.STATE_UP_MAIN).copy()))
+        with pytest.raises(native.IIVError):
+            enc.set_state_async(native.STATE_UP_MAIN, np.zeros((32, 256), np.int32))
+        enc.close()
+    for x, y in zip(*runs):
+        assert (x == y).all()
+    # and against the oracle: the first generator under seeds 5 / 6, the second under 7 / 8
+    ov = O.Video(mode, oracle_tables.get(mode, 5), seed_py=5, seed_np=6)
+    ov.encode_frame(frames[0, 0], frames[0, 1], 0)
+    assert (runs[1][0][0] == ov.next(300)).all()
+    L = O.lib()
+    L.orc_mt_seed_py(L.orc_video_rng_py(ov._h), 7)
+    L.orc_mt_seed_np(L.orc_video_rng_np(ov._h), 8)
+    ov.encode_frame(frames[1, 0], frames[1, 1], 1)
+    assert (runs[1][1][0] == ov.next(300)).all()
