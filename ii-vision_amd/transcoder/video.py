@@ -566,7 +566,14 @@ class Video:
         qs = self._live_queues()
         if qs is None or n_ops > len(qs[qslot]):
             return None
-        self._live_tag = self._live_tag % 65535 + 1
+        if self._live_tag >= 65535:
+            # the 16-bit tag starts over: a slot that no launch since has written could still carry a tag that is about to be
+            # used again -- wait for whatever may still write into the queues, and clear them
+            torch.cuda.current_stream().synchronize()
+            for q in qs:
+                q[:] = 0
+            self._live_tag = 0
+        self._live_tag += 1
         try:
             self._enc.encode_live(token.fm, token.fa, (0, int(bool(is_aux)), int(restart), int(n_ops)), ops_dev, qslot, self._live_tag)
         except native.IIVError as e:

@@ -49,6 +49,44 @@ def test_video_test_diff_weights():
     assert expect0 == diff[0, 0] and expect2 == diff[0, 1]
 
 
+def test_live_tags_start_over_on_clean_queues(O, oracle_tables):
+    """The live hand-over's 16-bit launch tag wraps after 65535 launches: the queues are cleared then, so that a slot written
+    long ago under the same tag cannot pass for an opcode of the new launch."""
+    import palette
+    import screen
+    import video
+    import video_mode
+    from test_gpu_encode import _synth
+    frames = _synth(1, 3, 4711)
+    random.seed(21)
+    np.random.seed(22)
+    v = video.Video(_FG(), ticks_per_second=14700., mode=video_mode.VideoMode.DHGR, palette=palette.Palette.NTSC)
+    ov = O.Video(1, oracle_tables.get(1, 5), seed_py=21, seed_np=22)
+    got, want = [], []
+    with contextlib.redirect_stdout(io.StringIO()):
+        for step, (fi, ia, k) in enumerate([(0, 0, 600), (0, 1, 100), (1, 0, 600), (1, 1, 90), (2, 0, 300)]):
+            v.SPECULATE = k      # (a launch writes exactly the slots of the opcodes that are pulled)
+            if step == 1:
+                # as if 65534 launches had gone by -- and slots 200.. still held, from long ago, the tag the launch after next
+                # will use (without the clearing its hand-out would run into them as soon as the kernel has written slot 199)
+                assert v._live_q and v.live_stats["launches"] == 1
+                v._live_tag = 65534
+                for q in v._live_q:
+                    q[200:700] = (np.uint64(1) << np.uint64(48)) | np.uint64(0x0102030405)
+            tgt = screen.DHGRBitmap(main_memory=screen.MemoryMap(1, frames[fi, 0].copy()),
+                                    aux_memory=screen.MemoryMap(1, frames[fi, 1].copy()), palette=palette.Palette.NTSC)
+            gen = v.encode_frame(tgt, is_aux=bool(ia))
+            for _ in range(k):
+                page, content, offsets = next(gen)
+                got.append([page, content] + list(offsets))
+            gen = None
+            ov.encode_frame(frames[fi, 0], frames[fi, 1], ia)
+            want.append(ov.next(k))
+    assert v.live_stats["launches"] >= 5 and 1 <= v._live_tag < 10     # (65535, then 1, 2, ...)
+    assert (np.array(got, np.uint8) == np.concatenate(want)).all()
+    assert (v.update_priority == ov.update_priority(0)).all()
+
+
 def test_bitmap_packed_is_the_construction_time_screen():
     """screen.py:151-152 packs in __init__; the mirror packs when `packed` is first read (a target handed to
     Video.encode_frame never is) -- from the bytes as they were at construction, whatever happened to the maps since."""
