@@ -323,6 +323,8 @@ class Video:
         # launches do not run that kernel), the tag of the latest launch, the event behind the brief that follows a launch
         self._live_q = None
         self._live_tag = 0
+        self._live_epoch = 0             # how often the tag has started over; per queue: the epoch it was last cleared in
+        self._live_q_epoch = [0, 0]
         self._brief_event = None
         # (launches handed out live; polls of the queue; polls that found nothing and waited, and for how long)
         self.live_stats = {"launches": 0, "takes": 0, "waits": 0, "wait_s": 0.0, "first_wait_s": 0.0}
@@ -567,13 +569,17 @@ class Video:
         if qs is None or n_ops > len(qs[qslot]):
             return None
         if self._live_tag >= 65535:
-            # the 16-bit tag starts over: a slot that no launch since has written could still carry a tag that is about to be
-            # used again -- wait for whatever may still write into the queues, and clear them
-            torch.cuda.current_stream().synchronize()
-            for q in qs:
-                q[:] = 0
             self._live_tag = 0
+            self._live_epoch += 1
         self._live_tag += 1
+        if self._live_q_epoch[qslot] != self._live_epoch:
+            # the 16-bit tag has started over since this queue was last cleared: a slot that no launch since has written could
+            # still carry a tag that is about to be used again.  Wait for whatever may still write into the queue and clear
+            # it -- THIS queue only: the other one may hold opcodes of the live generator that are yet to be handed out (this
+            # launch is then the one enqueued ahead of it); its turn comes with its own next launch
+            torch.cuda.current_stream().synchronize()
+            qs[qslot][:] = 0
+            self._live_q_epoch[qslot] = self._live_epoch
         try:
             self._enc.encode_live(token.fm, token.fa, (0, int(bool(is_aux)), int(restart), int(n_ops)), ops_dev, qslot, self._live_tag)
         except native.IIVError as e:

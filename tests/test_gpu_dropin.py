@@ -474,6 +474,7 @@ def test_movie_paced_generators_are_single_launches(O, oracle_tables, mode, n_fr
     monkeypatch.setattr(video.Video, "LIVE", live)    # (live hand-over of the opcodes while the kernel runs, or after it has ended)
     v = video.Video(_FG(), ticks_per_second=14700., mode=video_mode.VideoMode.DHGR if mode else video_mode.VideoMode.HGR, palette=pal)
     assert v.SPECULATE is None
+    v._live_tag = 65531      # (the live hand-over's 16-bit launch tag starts over a few generators in, a look-ahead in flight)
     ov = O.Video(mode, oracle_tables.get(mode, 5), seed_py=11, seed_np=12)
     calls = {"rollback": 0, "encode": 0, "live": 0}
     rb, en, el = v._enc.rollback, v._enc.encode, v._enc.encode_live
@@ -530,3 +531,5 @@ def test_movie_paced_generators_are_single_launches(O, oracle_tables, mode, n_fr
     st = v.lookahead_stats
     n_flips = sum(1 for j in range(1, len(segs)) if segs[j][0] == segs[j - 1][0])
     assert st["undone"] == 0 and st["adopted"] == st["launched"] == (n_flips if mode else 0), (st, n_flips)
+    if live and mode:
+        assert v._live_epoch == 1 and v._live_q_epoch == [1, 1] and v._live_tag < 100
