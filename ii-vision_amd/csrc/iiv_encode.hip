@@ -37,7 +37,12 @@ constexpr int kSharedDhgrMinStreams = 2048;  // (at 1024 clips the LDS-shared fo
 // and it loses 5 %.  Both forms produce the same bytes, so the encoder picks by what its own kernels saw: they count the
 // steps the nonces decided and the opcodes emitted, the counters come back with an asynchronous copy (never waited for:
 // a call uses what an earlier call's copy has delivered), and a batch above this share runs the plain form.
-constexpr unsigned kTieHeavyPercent = 30;
+// Round 6, re-measured per content (tools/content_kernel_split.py, greedy ms per 14336-stream launch, shared / plain):
+//   DHGR  S-iid (share 0.03) 1.01 / 1.22   error-diffusion frames (0.14) 1.02 / 1.24   ordered-dither frames (0.36) 1.06 / 1.25
+//         S-img (0.90) 1.30 / 1.30   -- two rounds of diets later the shared form is the better one up to ~85 %;
+//   HGR   S-iid (0.02) 2.83 / 3.45   error-diffusion frames (0.11) 2.82 / 3.25   ordered-dither frames (0.36) 3.67 / 3.33
+//         S-img (0.85) 6.26 / 3.37   -- its shared form keeps MT19937 in registers: the exact-nonce path is dear there.
+constexpr unsigned kTieHeavyPercentDHGR = 85, kTieHeavyPercentHGR = 30;
 // ... and so does a batch whose streams have little left to do per launch (converging content that is mostly out of work:
 // a frame shown four times runs 5.7 M frames/s plain, 4.6 M shared -- the workgroups' table copy and stream queue are
 // overhead that a launch of a few dozen real opcodes per stream does not repay)
@@ -101,7 +106,7 @@ struct Encoder {
     LaunchSeg *d_segs;
     int *d_queue;           // one stream counter per launch round of a call (persistent greedy workgroups), zeroed per call
     size_t queue_cap;
-    // what the one-wave kernels saw (kTieHeavyPercent): device counters, their pinned host copy, the event behind the copy
+    // what the one-wave kernels saw (kTieHeavyPercentDHGR / HGR): device counters, their pinned host copy, the event behind the copy
     unsigned long long *d_tie_stats, *h_tie_stats, tie_seen[3];
     hipEvent_t tie_ev;
     bool tie_copy_pending;
@@ -966,7 +971,7 @@ __global__ void tie_stats_kernel(const StreamState *states, int n, unsigned long
     }
 }
 
-// tie statistics (kTieHeavyPercent): take in what an earlier call's copy has delivered, if it has
+// tie statistics (kTieHeavyPercentDHGR / HGR): take in what an earlier call's copy has delivered, if it has
 static void tie_stats_poll(Encoder *e)
 {
     if (!e->tie_copy_pending || hipEventQuery(e->tie_ev) != hipSuccess) return;
@@ -982,7 +987,8 @@ static void tie_stats_poll(Encoder *e)
     e->tie_rate = ops ? (double)ties / (double)ops : 0.0;
     e->ops_per_launch = (double)ops / (double)runs;
     // (`tie_heavy` = the plain form is the better one for this input)
-    e->tie_heavy = (ties * 100ull > (unsigned long long)kTieHeavyPercent * ops || ops < (unsigned long long)kSharedMinOpsPerLaunch * runs) ? 1 : 0;
+    const unsigned heavy = e->mode == kDHGR ? kTieHeavyPercentDHGR : kTieHeavyPercentHGR;
+    e->tie_heavy = (ties * 100ull > (unsigned long long)heavy * ops || ops < (unsigned long long)kSharedMinOpsPerLaunch * runs) ? 1 : 0;
 }
 
 // ... and ask for the counters as this call leaves them (asynchronous; one copy in flight at a time)
@@ -1053,7 +1059,7 @@ static int launch_round(Encoder *e, const uint8_t *d_main, const uint8_t *d_aux,
                      ops_stride, e->greedy_lds_pad,
                      e->greedy_mode == IIV_GREEDY_WAVE_PLAIN ? -1 : uniform_bank,
                      // the LDS-shared form: on request; otherwise for batches that fill the GPU with its workgroups, unless the
-                     // kernels have reported input on which the plain form is the faster one (kTieHeavyPercent; until they
+                     // kernels have reported input on which the plain form is the faster one (kTieHeavyPercentDHGR / HGR; until they
                      // have reported: HGR shared, DHGR plain -- the better guess for each)
                      shared_form_now(e),
                      d_queue, e->fourth_offset != 0, e->d_tie_stats != nullptr && tie_stats_wanted(e),

@@ -210,9 +210,9 @@ void iiv_encoder_destroy(iiv_encoder *enc);
                                  *   every stream of a launch on the same bank); HGR: sixteen streams, the even bytes' L1 half
                                  *   (two of eight).  Same output.  WAVE / AUTO choose between this form and the plain one
                                  *   themselves, by what the kernels report about the input: batches that fill the GPU (>= 2048
-                                 *   DHGR / 4096 HGR streams) run the shared form unless the nonces decide more than 30 % of the
-                                 *   steps (picture-like input: the plain form's 28 waves per CU hide the exact-nonce path
-                                 *   better) or the streams emit fewer than 96 real opcodes per launch; until the first report
+                                 *   DHGR / 4096 HGR streams) run the shared form unless the nonces decide more than 85 % (DHGR) /
+                                 *   30 % (HGR) of the steps (picture-like input: the plain form's 28 waves per CU hide the
+                                 *   exact-nonce path better) or the streams emit fewer than 96 real opcodes per launch; until the first report
                                  *   HGR starts shared, DHGR plain (iiv_encoder_input_stats).  This value forces the form */
 #define IIV_GREEDY_WAVE_PLAIN 5  /*   WAVE with every table load from the L1 / L2, never the LDS-shared form */
 #define IIV_OPT_PREFIX_SORT 3    /* 1 (default): when a generator's opcode budget B is known
@@ -415,8 +415,8 @@ int iiv_encoder_profile_read(iiv_encoder *enc, double ms[2], int64_t launches[2]
  * are those of an earlier call.  stats[0] = that share over the latest interval looked at, stats[1] = real (not padding)
  * opcodes per stream and launch over the same interval (both 0 before any report);
  * *form = IIV_GREEDY_WAVE_SHARED or IIV_GREEDY_WAVE_PLAIN: batches that fill the GPU run the LDS-shared form unless
- * the share is above 30 % (picture-like input: the plain form's 28 waves per CU hide the exact-nonce path's latency
- * better than the shared form's 16) or the streams emit fewer than 96 real opcodes per launch (converging content that is
+ * the share is above 85 % (DHGR) / 30 % (HGR) (picture-like input: the plain form's 28 waves per CU hide the exact-nonce
+ * path's latency better than the shared form's 16; HGR's shared form, MT19937 in registers, pays more for that path) or the streams emit fewer than 96 real opcodes per launch (converging content that is
  * mostly out of work: the shared form's per-workgroup table copy is not repaid).  IIV_OPT_GREEDY_KERNEL = WAVE_SHARED /
  * WAVE_PLAIN overrule it. */
 int iiv_encoder_input_stats(iiv_encoder *enc, double stats[2], int *form);

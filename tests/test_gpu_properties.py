@@ -218,7 +218,8 @@ def test_kernel_forms_agree_at_batch_sizes(native, O, oracle_tables, device_tabl
 @pytest.mark.parametrize("mode", [1, 0])
 def test_encoder_picks_the_kernel_form_by_what_its_kernels_report(native, device_tables, mode):
     """A batch that fills the GPU runs the LDS-shared form of the one-wave kernel unless the kernels report input whose
-    steps are mostly decided by the nonces (picture-like: ~96 %), where the plain form is the faster one.  The report
+    steps are mostly decided by the nonces -- more than 85 % of them (DHGR) / 30 % (HGR): include/iivision.h,
+    iiv_encoder_input_stats -- where the plain form is the faster one.  The report
     travels by an asynchronous copy, so the choice follows a call or two behind; the bytes are the same either way
     (test_kernel_forms_agree_at_batch_sizes), only the rate differs."""
     import torch
@@ -236,6 +237,8 @@ def test_encoder_picks_the_kernel_form_by_what_its_kernels_report(native, device
         b.enc.check()
         share, form = b.enc.input_stats()
         assert lo <= share <= hi, (kind, share)
+        if kind == "img":     # (these few frames from an empty screen tie at 60-100 % of the steps: the rule, not a fixed answer)
+            want_form = "plain" if share > (0.85 if mode == 1 else 0.30) else "shared"
         assert form == want_form, (kind, share, form)
         # an explicit choice overrules the report
         b.enc.set_greedy_kernel("plain")
