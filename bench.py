@@ -1134,6 +1134,7 @@ def _emit_end_to_end(be, args, resident_fps):
     width = native.emit_chunk_range(be.mode, 0, n_ops)[1] + 16
     dev = [torch.empty(S * width, dtype=torch.uint8, device="cuda") for _ in range(2)]
     host = [torch.empty(S * width, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+    _dummies = [torch.cuda.Stream() for _ in range(int(os.environ.get("IIV_BENCH_DUMMY_STREAMS", "0")))]   # (experiment: HIP stream -> hardware queue mapping)
     copy_stream = torch.cuda.Stream()
     done = [torch.cuda.Event(), torch.cuda.Event()]
     ready = [torch.cuda.Event(), torch.cuda.Event()]
@@ -1239,6 +1240,12 @@ def _ingest_and_e2e(be, args, resident_fps, emit_fps):
                                   "peak_measured_copy": HBM_MEASURED_COPY_GBS, "over_measured_copy": gbs / HBM_MEASURED_COPY_GBS},
                      "vs_encoder_rate": fps / resident_fps}
 
+    # The copy and the conversion run on two side streams, made ONCE for all the e2e legs: HIP spreads streams over a handful
+    # of hardware queues in the order they are made, and a leg that made its own pair could find its copy stream on the
+    # encode's own queue -- the 45 ms copy of a step's 2.5 GB then ran between two launches instead of beside them, in one
+    # leg or another from run to run (round 6: emit_same_content read 2.80 or 3.30 M frames/s, its diffusion twin the other).
+    side_streams = (torch.cuda.Stream(), torch.cuda.Stream())
+
     def e2e(dither, overlap, pre=None):
         """pre: the steps' frames already converted (a list of buffers like bufs[j]) -- the same pipeline WITHOUT the conversion,
         on the same content: what e2e's rate is to be compared with"""
@@ -1250,7 +1257,7 @@ def _ingest_and_e2e(be, args, resident_fps, emit_fps):
         width = native.emit_chunk_range(be.mode, 0, n_ops)[1] + 16
         dev = [torch.empty(S * width, dtype=torch.uint8, device="cuda") for _ in range(2)]
         host = [torch.empty(S * width, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
-        copy_stream, ingest_stream = torch.cuda.Stream(), torch.cuda.Stream()
+        copy_stream, ingest_stream = side_streams      # (made once for all the legs below: see there)
         done = [torch.cuda.Event(), torch.cuda.Event()]
         ready = [torch.cuda.Event(), torch.cuda.Event()]
         converted = [torch.cuda.Event(), torch.cuda.Event()]     # buffer j holds its step's frames
